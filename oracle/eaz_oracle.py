@@ -1,0 +1,333 @@
+"""ctypes/numpy binding of the TEST-ONLY CPU oracle (oracle/eaz_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (e-alphazero_amd/) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libeaz_oracle.so")
+
+FIELD_IDS = {
+    "node_visits": 0, "raw_values": 1, "node_values": 2, "parents": 3, "action_from_parent": 4,
+    "children_index": 5, "children_prior_logits": 6, "children_values": 7, "children_visits": 8,
+    "children_rewards": 9, "children_discounts": 10, "raw_values_epistemic_variance": 11,
+    "node_values_epistemic_variance": 12, "children_values_epistemic_variance": 13,
+    "children_rewards_epistemic_variance": 14, "embeddings": 15, "root_gumbel": 16, "beta": 17,
+}
+_INT_FIELDS = {"node_visits", "parents", "action_from_parent", "children_index", "children_visits"}
+_NODE_FIELDS = {"node_visits", "raw_values", "node_values", "parents", "action_from_parent",
+                "raw_values_epistemic_variance", "node_values_epistemic_variance"}
+
+
+def build(force: bool = False) -> str:
+    src = [os.path.join(_HERE, f) for f in ("eaz_oracle.c", "o_math.h", "o_rng.h")]
+    if force or not os.path.exists(_LIB_PATH) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B" if force else "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        vp, i32, u32, f32 = C.c_void_p, C.c_int, C.c_uint32, C.c_float
+        sig = {
+            "eazo_env_deepsea": (vp, [i32, vp]),
+            "eazo_env_subleq": (vp, [i32, vp, i32, i32]),
+            "eazo_env_free": (None, [vp]),
+            "eazo_env_state_bytes": (i32, [vp]),
+            "eazo_env_num_actions": (i32, [vp]),
+            "eazo_env_obs_dim": (i32, [vp]),
+            "eazo_env_obs_rows": (i32, [vp]),
+            "eazo_env_obs_cols": (i32, [vp]),
+            "eazo_env_init": (None, [vp, i32, u32, u32, vp]),
+            "eazo_env_step": (None, [vp, i32, vp, vp, u32, u32, i32, vp]),
+            "eazo_env_observe": (None, [vp, i32, vp, vp]),
+            "eazo_env_fields": (None, [vp, i32, vp, vp, vp, vp, vp]),
+            "eazo_subleq_test_cases": (None, [i32, i32, vp, vp]),
+            "eazo_subleq_simulate": (None, [i32, vp, vp, vp, vp, vp, vp]),
+            "eazo_subleq_encode": (None, [vp, vp, i32, vp]),
+            "eazo_xxhash_indices": (None, [vp, i32, i32, i32, vp]),
+            "eazo_hash_update": (None, [vp, vp, i32]),
+            "eazo_hash_seen": (None, [vp, vp, i32, vp]),
+            "eazo_xxh_round": (u32, [u32, u32]),
+            "eazo_xxh_converge": (u32, [u32, u32, u32, u32]),
+            "eazo_xxh_avalanche": (u32, [u32]),
+            "eazo_net_create": (vp, [i32, i32, i32, vp, vp, f32, f32, i32, i32, i32, vp]),
+            "eazo_net_free": (None, [vp]),
+            "eazo_net_set_bitset": (None, [vp, vp]),
+            "eazo_net_forward": (None, [vp, i32, vp, vp, vp, vp, vp, vp]),
+            "eazo_considered_visits": (None, [i32, i32, vp]),
+            "eazo_tree_create": (vp, [vp, vp, i32, i32]),
+            "eazo_tree_free": (None, [vp]),
+            "eazo_tree_field": (vp, [vp, i32]),
+            "eazo_search_begin": (None, [vp, vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, i32, f32, f32, i32, i32]),
+            "eazo_search_sim": (None, [vp, i32]),
+            "eazo_search_finish": (None, [vp, vp, vp]),
+            "eazo_search_summary": (None, [vp, vp, vp, vp, vp, vp, vp]),
+            "eazo_selfplay": (None, [vp, vp, i32, vp, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+            "eazo_random_play": (None, [vp, i32, i32, u32, u32, vp, vp]),
+            "eazo_expf": (f32, [f32]),
+            "eazo_logf": (f32, [f32]),
+            "eazo_tanhf": (f32, [f32]),
+            "eazo_tree_sum": (f32, [vp, i32]),
+            "eazo_threefry2x32": (None, [u32, u32, u32, u32, vp]),
+            "eazo_gumbel": (None, [u32, u32, i32, vp]),
+            "eazo_fold": (None, [u32, u32, u32, vp]),
+            "eazo_num_threads": (i32, []),
+            "eazo_set_num_threads": (None, [i32]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class SelfplayCfg(C.Structure):
+    _fields_ = [
+        ("T", C.c_int), ("S", C.c_int), ("discount", C.c_float), ("two_player", C.c_int),
+        ("directed_exploration", C.c_int), ("exploration_beta", C.c_float), ("uniform_search_policy", C.c_int),
+        ("sample_actions", C.c_int), ("sample_from_improved", C.c_int), ("rescale", C.c_int),
+        ("gumbel_scale", C.c_float), ("max_considered", C.c_int),
+    ]
+
+
+class OracleEnv:
+    def __init__(self, handle, kind):
+        self.h = handle
+        self.kind = kind
+        L = lib()
+        self.state_bytes = L.eazo_env_state_bytes(handle)
+        self.num_actions = L.eazo_env_num_actions(handle)
+        self.obs_dim = L.eazo_env_obs_dim(handle)
+        self.obs_shape = (L.eazo_env_obs_rows(handle), L.eazo_env_obs_cols(handle))
+
+    @classmethod
+    def deepsea(cls, G, action_map=None):
+        am = None if action_map is None else np.ascontiguousarray(action_map, dtype=np.uint8).reshape(G * G)
+        e = cls(lib().eazo_env_deepsea(G, _p(am)), "deepsea")
+        e.G = G
+        return e
+
+    @classmethod
+    def subleq(cls, W, tasks=(1,), binary=True):
+        t = np.asarray(tasks, dtype=np.int32)
+        h = lib().eazo_env_subleq(W, _p(t), len(t), int(binary))
+        if not h:
+            raise ValueError("invalid subleq parameters")
+        e = cls(h, "subleq")
+        e.W = W
+        return e
+
+    def __del__(self):
+        try:
+            lib().eazo_env_free(self.h)
+        except Exception:
+            pass
+
+    def new_states(self, B):
+        return np.zeros((B, self.state_bytes), dtype=np.uint8)
+
+    def init(self, B, key=(0, 0)):
+        s = self.new_states(B)
+        lib().eazo_env_init(self.h, B, key[0], key[1], _p(s))
+        return s
+
+    def step(self, states, action, key=(0, 0), autoreset=False):
+        B = states.shape[0]
+        out = np.empty_like(states)
+        a = np.ascontiguousarray(action, dtype=np.int32)
+        lib().eazo_env_step(self.h, B, _p(states), _p(a), key[0], key[1], int(autoreset), _p(out))
+        return out
+
+    def observe(self, states):
+        B = states.shape[0]
+        obs = np.empty((B, self.obs_dim), dtype=np.uint8)
+        lib().eazo_env_observe(self.h, B, _p(states), _p(obs))
+        return obs
+
+    def fields(self, states):
+        B = states.shape[0]
+        term = np.empty(B, np.uint8)
+        trunc = np.empty(B, np.uint8)
+        rew = np.empty(B, np.float32)
+        sc = np.empty(B, np.int32)
+        lib().eazo_env_fields(self.h, B, _p(states), _p(term), _p(trunc), _p(rew), _p(sc))
+        return dict(terminated=term.astype(bool), truncated=trunc.astype(bool), rewards=rew, step_count=sc)
+
+
+class OracleNet:
+    """weights: list of 12 (w[in,out], b[out]) float32 pairs in haiku creation order."""
+
+    def __init__(self, in_dim, H, A, weights, max_u=1.0, nov_scale=1.0, hash_off=0, hash_len=None, hash_bits=24,
+                 bitset=None):
+        hash_len = in_dim - hash_off if hash_len is None else hash_len
+        assert hash_len % 4 == 0, "hash input length must be a multiple of 4 (hashes.py:210)"
+        self.in_dim, self.H, self.A = in_dim, H, A
+        self._w = [np.ascontiguousarray(w, np.float32) for w, _ in weights]
+        self._b = [np.ascontiguousarray(b, np.float32) for _, b in weights]
+        wp = (C.c_void_p * 12)(*[w.ctypes.data for w in self._w])
+        bp = (C.c_void_p * 12)(*[b.ctypes.data for b in self._b])
+        self.bitset = bitset
+        self.h = lib().eazo_net_create(in_dim, H, A, wp, bp, max_u, nov_scale, hash_off, hash_len, hash_bits, _p(bitset))
+
+    def set_bitset(self, bitset):
+        self.bitset = bitset
+        lib().eazo_net_set_bitset(self.h, _p(bitset))
+
+    def __del__(self):
+        try:
+            lib().eazo_net_free(self.h)
+        except Exception:
+            pass
+
+    def forward(self, obs):
+        obs = np.ascontiguousarray(obs, np.uint8).reshape(-1, self.in_dim)
+        B = obs.shape[0]
+        ex = np.empty((B, self.A), np.float32)
+        xp = np.empty((B, self.A), np.float32)
+        v = np.empty(B, np.float32)
+        u = np.empty(B, np.float32)
+        nov = np.empty(B, np.float32)
+        lib().eazo_net_forward(self.h, B, _p(obs), _p(ex), _p(xp), _p(v), _p(u), _p(nov))
+        return ex, xp, v, u, nov
+
+
+class OracleTree:
+    def __init__(self, env: OracleEnv, net: OracleNet, B, S):
+        self.env, self.net, self.B, self.S, self.N, self.A = env, net, B, S, S + 1, env.num_actions
+        self.h = lib().eazo_tree_create(env.h, net.h, B, S)
+
+    def __del__(self):
+        try:
+            lib().eazo_tree_free(self.h)
+        except Exception:
+            pass
+
+    def begin(self, root_logits, root_value, root_var, root_states, beta, invalid, gumbel, discount=0.997,
+              two_player=False, use_exploration_logits=False, rescale=True, use_mixed=True, value_scale=0.1,
+              maxvisit_init=50.0, max_considered=16, max_depth=0):
+        f = lambda a: np.ascontiguousarray(a, np.float32)
+        self._keep = [f(root_logits), f(root_value), f(root_var), np.ascontiguousarray(root_states), f(beta),
+                      None if invalid is None else np.ascontiguousarray(invalid, np.uint8), f(gumbel)]
+        k = self._keep
+        lib().eazo_search_begin(self.h, _p(k[0]), _p(k[1]), _p(k[2]), _p(k[3]), _p(k[4]), _p(k[5]), _p(k[6]), discount,
+                                int(two_player), int(use_exploration_logits), int(rescale), int(use_mixed), value_scale,
+                                maxvisit_init, max_considered, max_depth)
+
+    def sim(self, i):
+        lib().eazo_search_sim(self.h, i)
+
+    def finish(self):
+        act = np.empty(self.B, np.int32)
+        aw = np.empty((self.B, self.A), np.float32)
+        lib().eazo_search_finish(self.h, _p(act), _p(aw))
+        return act, aw
+
+    def summary(self):
+        B, A = self.B, self.A
+        o = dict(value=np.empty(B, np.float32), value_epistemic_std=np.empty(B, np.float32),
+                 qvalues=np.empty((B, A), np.float32), qvalues_epistemic_variance=np.empty((B, A), np.float32),
+                 visit_counts=np.empty((B, A), np.float32), visit_probs=np.empty((B, A), np.float32))
+        lib().eazo_search_summary(self.h, _p(o["value"]), _p(o["value_epistemic_std"]), _p(o["qvalues"]),
+                                  _p(o["qvalues_epistemic_variance"]), _p(o["visit_counts"]), _p(o["visit_probs"]))
+        return o
+
+    def field(self, name):
+        ptr = lib().eazo_tree_field(self.h, FIELD_IDS[name])
+        B, N, A = self.B, self.N, self.A
+        if name == "embeddings":
+            n, dt, shape = B * N * self.env.state_bytes, np.uint8, (B, N, self.env.state_bytes)
+        elif name in ("root_gumbel",):
+            n, dt, shape = B * A, np.float32, (B, A)
+        elif name == "beta":
+            n, dt, shape = B, np.float32, (B,)
+        elif name in _NODE_FIELDS:
+            n, dt, shape = B * N, (np.int32 if name in _INT_FIELDS else np.float32), (B, N)
+        else:
+            n, dt, shape = B * N * A, (np.int32 if name in _INT_FIELDS else np.float32), (B, N, A)
+        buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dt).reshape(shape).copy()
+
+    def dump(self):
+        return {k: self.field(k) for k in FIELD_IDS if k != "embeddings"}
+
+
+def search(env, net, states, num_simulations, root_logits, root_value, root_var, beta, gumbel, invalid=None, **kw):
+    """Full oracle search: returns (action, action_weights, summary, tree)."""
+    B = states.shape[0]
+    t = OracleTree(env, net, B, num_simulations)
+    t.begin(root_logits, root_value, root_var, states, beta, invalid, gumbel, **kw)
+    for i in range(num_simulations):
+        t.sim(i)
+    act, aw = t.finish()
+    return act, aw, t.summary(), t
+
+
+def selfplay(env, net, states, T, S, key=(0, 0), gumbel=None, discount=0.997, two_player=False,
+             directed_exploration=False, exploration_beta=0.0, uniform_search_policy=False, sample_actions=False,
+             sample_from_improved_policy=False, rescale=True, gumbel_scale=1.0, max_considered=16):
+    """src/selfplay.py:78-149 on the oracle.  `states` is updated in place (last_states)."""
+    B, A = states.shape[0], env.num_actions
+    cfg = SelfplayCfg(T, S, discount, int(two_player), int(directed_exploration), exploration_beta,
+                      int(uniform_search_policy), int(sample_actions), int(sample_from_improved_policy), int(rescale),
+                      gumbel_scale, max_considered)
+    out = dict(
+        state=np.empty((T, B, env.state_bytes), np.uint8), root_value=np.empty((T, B), np.float32),
+        root_epistemic_std=np.empty((T, B), np.float32), value_prediction=np.empty((T, B), np.float32),
+        ube_prediction=np.empty((T, B), np.float32), q_values_epistemic_variance=np.empty((T, B, A), np.float32),
+        action=np.empty((T, B), np.int32),
+    )
+    g = None if gumbel is None else np.ascontiguousarray(gumbel, np.float32)
+    lib().eazo_selfplay(env.h, net.h, B, C.byref(cfg), key[0], key[1], _p(states), _p(g), _p(out["state"]),
+                        _p(out["root_value"]), _p(out["root_epistemic_std"]), _p(out["value_prediction"]),
+                        _p(out["ube_prediction"]), _p(out["q_values_epistemic_variance"]), _p(out["action"]))
+    return out
+
+
+def random_play(env, B, T, key=(0, 0), want_traj=False):
+    states = env.new_states(B)
+    traj = np.empty((T, B, env.state_bytes), np.uint8) if want_traj else None
+    lib().eazo_random_play(env.h, B, T, key[0], key[1], _p(states), _p(traj))
+    return states, traj
+
+
+def considered_visits(m, S):
+    out = np.empty(S, np.int32)
+    lib().eazo_considered_visits(m, S, _p(out))
+    return out
+
+
+def gumbel(key, n):
+    out = np.empty(n, np.float32)
+    lib().eazo_gumbel(key[0], key[1], n, _p(out))
+    return out
+
+
+def fold(key, tag):
+    out = np.empty(2, np.uint32)
+    lib().eazo_fold(key[0], key[1], tag, _p(out))
+    return int(out[0]), int(out[1])
