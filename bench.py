@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play env-steps/sec of the HIP engine on BASELINE.json's headline configuration.
+
+A "step" is one selfplay() call (src/selfplay.py:78-149): T = 32 real environment steps (config.py:37) of a batch of
+B = 4096 DeepSea-32 environments per GPU, 64 Gumbel-MuZero simulations per real step, FC H=256 network -- BASELINE.json
+configs[1] ("C2").  env-steps = B_total * T per step (src/main.py:378); search-internal steps are not counted.
+
+N > 1: one process per GPU (torchrun), the batch is sharded (weak scaling, B per GPU fixed); the only collective is one RCCL
+all-gather per selfplay() call that pools the [T, B, ...] trajectory block of every rank (the counterpart of
+src/main.py:383-385), inside the timed region.
+
+Prints ONE JSON line on rank 0 (see the task contract), with `roofline` for the dominant kernel (fused FC forward,
+f32 MFMA) measured live with HIP events on the launch stream, `roofline_gather` for the leaf-gather kernel (HBM),
+and `cpu_baseline` = the CPU oracle timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import e_alphazero_amd as eaz  # noqa: E402
+from e_alphazero_amd import engine  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBPS = 8000.0        # MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def fc_flops_per_eval(in_dim, H, A, heads):
+    f = 0
+    for h in heads:
+        out = 1 if h < 2 else A
+        f += 2 * (in_dim * H + H * H + H * out)
+    return f
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=32, help="DeepSea size")
+    ap.add_argument("--batch", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--sims", type=int, default=64)
+    ap.add_argument("--selfplay-steps", type=int, default=32)
+    ap.add_argument("--hash-fill", type=float, default=0.5, help="fraction of the novelty bit-set that is set")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=1024)
+    ap.add_argument("--cpu-sample-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    n_gpus = world
+    dev = torch.device("cuda", local_rank)
+
+    G, B, S, T, A, H = args.grid, args.batch, args.sims, args.selfplay_steps, 2, 256
+    # synthetic inputs: action_map ~ Bernoulli(0.5) seed 0, random-init FC net seed 0, half-filled bit set
+    am = (np.random.default_rng(0).random((G, G)) < 0.5).astype(np.uint8)
+    params = eaz.params.init_fc_params(G * G, H, A, seed=0)
+    hstate = eaz.params.init_hash_state(fill=args.hash_fill, seed=0)
+    env = engine.EnvHandle.deepsea(G, am, device=local_rank)
+    net = engine.FCNet(env.ctx, G * G, H, A, params, hstate)
+    search = engine.Search(env, net, B, S, discount=0.997)
+    states = env.init(B, key=rank)
+    outputs = None
+    gathered = None
+
+    def one_step(i):
+        nonlocal outputs, gathered
+        outputs = search.selfplay(states, T, key=(1000 * rank + i), outputs=outputs)
+        if dist is not None:
+            # pool trajectories of all ranks (replay-buffer landing zone): one all-gather of the packed block
+            block = torch.cat([outputs["state"].reshape(T, B, -1),
+                               outputs["root_value"].view(torch.uint8).reshape(T, B, 4),
+                               outputs["root_epistemic_std"].view(torch.uint8).reshape(T, B, 4),
+                               outputs["value_prediction"].view(torch.uint8).reshape(T, B, 4),
+                               outputs["ube_prediction"].view(torch.uint8).reshape(T, B, 4),
+                               outputs["q_values_epistemic_variance"].view(torch.uint8).reshape(T, B, 4 * A)], dim=2)
+            if gathered is None:
+                gathered = torch.empty((world,) + tuple(block.shape), dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(gathered, block.contiguous())
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(-1 - i)
+    # timed region: EXACTLY K steps; HIP events around every FC-forward and leaf-gather launch feed the roofline objects
+    search.profile(True)
+    search.profile_read(reset=True)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = search.profile_read(reset=True)
+    search.profile(False)
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    env_steps = B * n_gpus * T * args.steps
+    value = env_steps / dt
+    result = {
+        "metric": "self-play env-steps/sec (batch 4096, 64 sims)",
+        "value": value,
+        "unit": "env-steps/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / max(args.steps, 1),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (seeded DeepSea action map, random-init FC net, half-filled novelty set)",
+        "config": {"workload": f"DeepSea size={G}, batch={B}/GPU, {S} sims, {T} real steps per selfplay() call, FC H={H} (BASELINE.json configs[1])",
+                   "global_batch": B * n_gpus, "parallelism": f"batch-sharded x{n_gpus}, RCCL all-gather of trajectories" if n_gpus > 1 else "single GPU"},
+    }
+    # ---- roofline of the dominant kernel (fused FC forward; 3 heads evaluated: value, ube, exploitation) -----------
+    heads = (0, 1, 2)
+    flops = fc_flops_per_eval(G * G, H, A, heads) * B
+    net_ms = prof["net"]["ms"] / max(prof["net"]["launches"], 1)
+    ach = flops / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0
+    result["roofline"] = {"kernel": "fc_forward_kernel", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                          "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                          "avg_launch_us": 1e3 * net_ms, "launches": prof["net"]["launches"],
+                          "flops_per_launch": flops}
+    # leaf gather: algorithmic bytes on the engine's compact layout = parent state + child state + observation row
+    gbytes = B * (2 * env.state_bytes + env.obs_dim)
+    g_ms = prof["gather"]["ms"] / max(prof["gather"]["launches"], 1)
+    gach = gbytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
+    result["roofline_gather"] = {"kernel": "leaf_gather_deepsea_kernel", "bound": "hbm", "achieved": gach, "peak": PEAK_HBM_GBPS,
+                                 "unit": "GB/s", "frac": gach / PEAK_HBM_GBPS, "traffic": None, "avg_launch_us": 1e3 * g_ms,
+                                 "launches": prof["gather"]["launches"], "bytes_per_launch": gbytes}
+    result["kernel_ms"] = {k: round(v["ms"], 3) for k, v in prof.items()}
+
+    # ---- CPU baseline: the oracle on a bounded sample of the same workload, rank 0 at N = 1 only -------------------
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import eaz_oracle as O
+
+        cb, ct = args.cpu_sample_batch, args.cpu_sample_steps
+        oenv = O.OracleEnv.deepsea(G, am)
+        onet = O.OracleNet(G * G, H, A, eaz.params.fc_weight_list(params), bitset=hstate[eaz.params.HASH_MODULE]["binary_set"])
+        ost = oenv.init(cb)
+        c0 = time.perf_counter()
+        O.selfplay(oenv, onet, ost, T=ct, S=S, key=(0, 0))
+        cdt = time.perf_counter() - c0
+        result["cpu_baseline"] = {"value": cb * ct / cdt, "unit": "env-steps/s", "cores": O.lib().eazo_num_threads(),
+                                  "kind": "port", "sample": f"DeepSea-{G}, batch {cb}, {S} sims, {ct} real steps ({cdt:.1f} s)"}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,824 @@
+// eaz_api.hip -- implementation of the C ABI declared in include/eaz.h (libeaz.so).
+//
+// Host-side orchestration only: object lifetimes, workspace allocation, kernel launches on the caller's stream.
+// No torch types, no CPU fallback: every entry point either enqueues gfx950 kernels or fails with an error.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/eaz.h"
+#include "env_kernels.hpp"
+#include "net_fc.hpp"
+#include "search_kernels.hpp"
+
+using namespace eaz;
+
+// ------------------------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+#define HIP_OK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define ARG_OK(cond)                                                       \
+    do {                                                                   \
+        if (!(cond)) return fail("invalid argument: %s (%s:%d)", #cond, __FILE__, __LINE__); \
+    } while (0)
+#define LAUNCH_OK() HIP_OK(hipGetLastError())
+
+extern "C" const char* eaz_last_error(void) { return g_err.c_str(); }
+extern "C" int eaz_version(void) { return 100; }
+
+static inline int cdiv(long a, long b) { return static_cast<int>((a + b - 1) / b); }
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// objects
+// ------------------------------------------------------------------------------------------------------------------
+struct eaz_ctx {
+    int device;
+};
+
+struct eaz_env {
+    eaz_ctx* ctx;
+    EnvDev dev;
+    uint8_t* d_action_map;
+};
+
+struct eaz_net {
+    eaz_ctx* ctx;
+    NetDev dev;
+    float* d_w[12];
+    float* d_b[12];
+    size_t bitset_bytes;
+};
+
+struct ProfSpan {
+    hipEvent_t a, b;
+    int cls;
+};
+
+struct eaz_search {
+    eaz_ctx* ctx;
+    eaz_env* env;
+    eaz_net* net;
+    eaz_search_opts opts;
+    int B, N, A, S;
+    int lpt, apl;
+    TreeDev tree;
+    std::vector<void*> allocs;
+    // workspace of one simulation
+    uint8_t* d_obs;
+    float *d_novelty, *d_exploit, *d_explore, *d_v, *d_u, *d_next_reward;
+    uint8_t *d_next_term, *d_next_legal;
+    int32_t* d_table;
+    // root buffers used by the self-play driver
+    float *d_root_logits, *d_root_beta, *d_root_gumbel, *d_aw, *d_vprobs;
+    uint8_t *d_root_invalid, *d_legal;
+    int32_t* d_action;
+    // profiling
+    int prof_on;
+    std::vector<ProfSpan> spans;
+    std::vector<hipEvent_t> ev_pool;
+    // graph replay of one real step
+    hipGraphExec_t step_graph;
+    bool step_graph_valid;
+    int pending_expand;  // simulation whose expand+backward has not run yet (-1: none)
+};
+
+extern "C" int eaz_ctx_create(int device, eaz_ctx** out) {
+    ARG_OK(out != nullptr);
+    int n = 0;
+    HIP_OK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail("device %d out of range (%d visible)", device, n);
+    HIP_OK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail("libeaz is built for gfx950 (MI355X); device %d is %s", device, prop.gcnArchName);
+    *out = new eaz_ctx{device};
+    return 0;
+}
+extern "C" int eaz_ctx_destroy(eaz_ctx* ctx) {
+    delete ctx;
+    return 0;
+}
+extern "C" int eaz_key_fold(uint64_t key, uint32_t tag, uint64_t* out) {
+    ARG_OK(out != nullptr);
+    const Key k = fold(key_from_u64(key), tag);
+    *out = static_cast<uint64_t>(k.k0) | (static_cast<uint64_t>(k.k1) << 32);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// environments
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int eaz_env_create_deepsea(eaz_ctx* ctx, int G, const uint8_t* h_action_map, eaz_env** out) {
+    ARG_OK(ctx && out && G >= 2 && G <= 1024);
+    HIP_OK(hipSetDevice(ctx->device));
+    eaz_env* e = new eaz_env();
+    e->ctx = ctx;
+    std::memset(&e->dev, 0, sizeof e->dev);
+    e->dev.kind = EAZ_ENV_DEEPSEA;
+    e->dev.A = 2;
+    e->dev.G = G;
+    e->dev.obs_rows = G;
+    e->dev.obs_cols = G;
+    e->dev.obs_dim = G * G;
+    e->dev.state_bytes = sizeof(eaz_deepsea_state);
+    HIP_OK(hipMalloc(&e->d_action_map, static_cast<size_t>(G) * G));
+    if (h_action_map) HIP_OK(hipMemcpy(e->d_action_map, h_action_map, static_cast<size_t>(G) * G, hipMemcpyHostToDevice));
+    else HIP_OK(hipMemset(e->d_action_map, 0, static_cast<size_t>(G) * G));
+    e->dev.action_map = e->d_action_map;
+    *out = e;
+    return 0;
+}
+
+extern "C" int eaz_env_create_subleq(eaz_ctx* ctx, int W, const int32_t* h_tasks, int n_tasks, int binary, eaz_env** out) {
+    ARG_OK(ctx && out && h_tasks);
+    if (W < 16 || W > 256) return fail("word_size must be in [16, 256] (subleq.py:606), got %d", W);
+    if (W % 4 != 0) return fail("the gfx950 Subleq kernel requires word_size %% 4 == 0, got %d", W);
+    ARG_OK(n_tasks >= 1 && n_tasks <= 16);
+    eaz_env* e = new eaz_env();
+    e->ctx = ctx;
+    e->d_action_map = nullptr;
+    std::memset(&e->dev, 0, sizeof e->dev);
+    e->dev.kind = EAZ_ENV_SUBLEQ;
+    e->dev.W = W;
+    e->dev.A = W;
+    e->dev.n_tasks = n_tasks;
+    for (int i = 0; i < n_tasks; ++i) e->dev.tasks[i] = h_tasks[i];
+    e->dev.binary = binary ? 1 : 0;
+    int bl = 0;
+    for (int v = W - 1; v > 0; v >>= 1) bl++;
+    e->dev.obs_rows = W + 4 * EAZ_SUBLEQ_IO;          // subleq.py:618-621
+    e->dev.obs_cols = binary ? bl + 1 : W + 1;        // subleq.py:59-60 / :613
+    e->dev.obs_dim = e->dev.obs_rows * e->dev.obs_cols;
+    e->dev.state_bytes = sizeof(eaz_subleq_state);
+    *out = e;
+    return 0;
+}
+
+extern "C" int eaz_env_destroy(eaz_env* env) {
+    if (!env) return 0;
+    if (env->d_action_map) (void)hipFree(env->d_action_map);
+    delete env;
+    return 0;
+}
+
+extern "C" int eaz_env_info(const eaz_env* env, int* kind, int* num_actions, int* obs_rows, int* obs_cols, int* state_bytes) {
+    ARG_OK(env != nullptr);
+    if (kind) *kind = env->dev.kind;
+    if (num_actions) *num_actions = env->dev.A;
+    if (obs_rows) *obs_rows = env->dev.obs_rows;
+    if (obs_cols) *obs_cols = env->dev.obs_cols;
+    if (state_bytes) *state_bytes = env->dev.state_bytes;
+    return 0;
+}
+
+// mode: 0 step, 1 auto-reset step, 2 init.  src/dst: plain [B] batches.
+static int env_step_launch(eaz_env* env, int B, const void* in, const int32_t* action, Key key, int mode, void* out,
+                           void* out_copy, hipStream_t st) {
+    if (B <= 0) return 0;
+    if (env->dev.kind == EAZ_ENV_DEEPSEA) {
+        deepsea_step_kernel<<<cdiv(B, 256), 256, 0, st>>>(env->dev, static_cast<const char*>(in), action, B, mode,
+                                                         static_cast<char*>(out), static_cast<char*>(out_copy));
+    } else {
+        StateRef src{const_cast<char*>(static_cast<const char*>(in ? in : out)), nullptr, 1};
+        StateRef dst{static_cast<char*>(out), nullptr, 1};
+        subleq_step_kernel<<<cdiv(B, 64), 192, 192 * env->dev.W, st>>>(env->dev, src, dst, action, B, mode, key,
+                                                                         static_cast<char*>(out_copy), nullptr, nullptr, nullptr);
+    }
+    LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int eaz_env_init(eaz_env* env, int B, uint64_t key, void* d_states, void* stream) {
+    ARG_OK(env && d_states && B >= 0);
+    return env_step_launch(env, B, nullptr, nullptr, key_from_u64(key), 2, d_states, nullptr, S(stream));
+}
+
+extern "C" int eaz_env_step(eaz_env* env, int B, const void* d_in, const int32_t* d_action, uint64_t key, int autoreset,
+                            void* d_out, void* stream) {
+    ARG_OK(env && d_in && d_action && d_out && B >= 0);
+    return env_step_launch(env, B, d_in, d_action, key_from_u64(key), autoreset ? 1 : 0, d_out, nullptr, S(stream));
+}
+
+static int obs_launch(eaz_env* env, int B, const void* states, uint8_t* obs, hipStream_t st) {
+    if (B <= 0) return 0;
+    StateRef src{const_cast<char*>(static_cast<const char*>(states)), nullptr, 1};
+    obs_emit_kernel<<<cdiv(static_cast<long>(B) * 64, 256), 256, 0, st>>>(env->dev, src, B, obs);
+    LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int eaz_env_observe(eaz_env* env, int B, const void* d_states, uint8_t* d_obs, void* stream) {
+    ARG_OK(env && d_states && d_obs && B >= 0);
+    return obs_launch(env, B, d_states, d_obs, S(stream));
+}
+
+extern "C" int eaz_env_fields(eaz_env* env, int B, const void* d_states, uint8_t* d_term, uint8_t* d_trunc, float* d_reward,
+                              int32_t* d_step_count, uint8_t* d_legal, void* stream) {
+    ARG_OK(env && d_states && B >= 0);
+    if (B == 0) return 0;
+    env_fields_kernel<<<cdiv(B, 256), 256, 0, S(stream)>>>(env->dev, static_cast<const char*>(d_states), B, d_term, d_trunc,
+                                                         d_reward, d_step_count, d_legal);
+    LAUNCH_OK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// network
+// ------------------------------------------------------------------------------------------------------------------
+static void layer_dims(int in_dim, int H, int A, int l, int* k, int* n) {
+    *k = (l % 3) == 0 ? in_dim : H;
+    *n = (l % 3) < 2 ? H : ((l / 3) < 2 ? 1 : A);
+}
+
+extern "C" int eaz_net_create_fc(eaz_ctx* ctx, int in_dim, int hidden, int num_actions, const float* const* h_w,
+                                 const float* const* h_b, float max_ube, float max_reward_variance, int hash_off,
+                                 int hash_len, int hash_bits, eaz_net** out) {
+    ARG_OK(ctx && out && h_w && h_b && in_dim > 0 && num_actions > 0 && num_actions <= 256);
+    if (hidden != kFcH) return fail("the gfx950 FC kernel is specialised for linear_layer_size = %d (config.py:24), got %d", kFcH, hidden);
+    if (hash_len <= 0 || hash_len % 4 != 0 || hash_off < 0 || hash_off + hash_len > in_dim)
+        return fail("hash slice [%d, %d) invalid: length must be a positive multiple of 4 (hashes.py:210) inside the observation", hash_off, hash_off + hash_len);
+    ARG_OK(hash_bits >= 4 && hash_bits <= 32);
+    HIP_OK(hipSetDevice(ctx->device));
+    eaz_net* n = new eaz_net();
+    n->ctx = ctx;
+    std::memset(&n->dev, 0, sizeof n->dev);
+    n->dev.in_dim = in_dim; n->dev.H = hidden; n->dev.A = num_actions;
+    n->dev.max_u = max_ube; n->dev.nov_scale = max_reward_variance;
+    n->dev.hash_off = hash_off; n->dev.hash_len = hash_len; n->dev.hash_bits = hash_bits;
+    for (int l = 0; l < 12; ++l) {
+        int k, m;
+        layer_dims(in_dim, hidden, num_actions, l, &k, &m);
+        HIP_OK(hipMalloc(&n->d_w[l], sizeof(float) * k * m));
+        HIP_OK(hipMalloc(&n->d_b[l], sizeof(float) * m));
+        HIP_OK(hipMemcpy(n->d_w[l], h_w[l], sizeof(float) * k * m, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(n->d_b[l], h_b[l], sizeof(float) * m, hipMemcpyHostToDevice));
+        n->dev.w[l] = n->d_w[l];
+        n->dev.b[l] = n->d_b[l];
+    }
+    n->bitset_bytes = static_cast<size_t>(1) << (hash_bits - 3);
+    if (n->bitset_bytes < 4) n->bitset_bytes = 4;
+    HIP_OK(hipMalloc(&n->dev.bitset, n->bitset_bytes));
+    HIP_OK(hipMemset(n->dev.bitset, 0, n->bitset_bytes));
+    *out = n;
+    return 0;
+}
+
+extern "C" int eaz_net_destroy(eaz_net* n) {
+    if (!n) return 0;
+    for (int l = 0; l < 12; ++l) { (void)hipFree(n->d_w[l]); (void)hipFree(n->d_b[l]); }
+    (void)hipFree(n->dev.bitset);
+    delete n;
+    return 0;
+}
+
+extern "C" int eaz_net_set_weights(eaz_net* n, const float* const* h_w, const float* const* h_b, void* stream) {
+    ARG_OK(n && h_w && h_b);
+    for (int l = 0; l < 12; ++l) {
+        int k, m;
+        layer_dims(n->dev.in_dim, n->dev.H, n->dev.A, l, &k, &m);
+        HIP_OK(hipMemcpyAsync(n->d_w[l], h_w[l], sizeof(float) * k * m, hipMemcpyHostToDevice, S(stream)));
+        HIP_OK(hipMemcpyAsync(n->d_b[l], h_b[l], sizeof(float) * m, hipMemcpyHostToDevice, S(stream)));
+    }
+    return 0;
+}
+
+extern "C" int eaz_net_set_bitset(eaz_net* n, const uint8_t* h_bitset, void* stream) {
+    ARG_OK(n && h_bitset);
+    HIP_OK(hipMemcpyAsync(n->dev.bitset, h_bitset, static_cast<size_t>(1) << (n->dev.hash_bits - 3), hipMemcpyHostToDevice, S(stream)));
+    return 0;
+}
+
+extern "C" int eaz_net_get_bitset(eaz_net* n, uint8_t* h_bitset, void* stream) {
+    ARG_OK(n && h_bitset);
+    HIP_OK(hipMemcpyAsync(h_bitset, n->dev.bitset, static_cast<size_t>(1) << (n->dev.hash_bits - 3), hipMemcpyDeviceToHost, S(stream)));
+    HIP_OK(hipStreamSynchronize(S(stream)));
+    return 0;
+}
+
+static int hash_launch(eaz_net* n, int B, const uint8_t* obs, float* novelty, uint8_t* seen, uint32_t* idx, int mode, hipStream_t st) {
+    if (B <= 0) return 0;
+    hash_kernel<<<cdiv(static_cast<long>(B) * 4, 256), 256, 0, st>>>(n->dev, obs, B, novelty, seen, idx, mode);
+    LAUNCH_OK();
+    return 0;
+}
+
+static int fc_launch(eaz_net* n, int B, const uint8_t* obs, const NetOut& o, const HeadList& heads, hipStream_t st) {
+    if (B <= 0 || heads.n <= 0) return 0;
+    const int n_tiles = cdiv(B, kFcM);
+    int cmin = 8;
+    for (int h = 0; h < heads.n; ++h) {
+        int c = 0;
+        for (int x = 0; x < 8; ++x) c += (x % heads.n) == h;
+        cmin = c < cmin ? c : cmin;
+    }
+    const int grid = 8 * cdiv(n_tiles, cmin);
+    fc_forward_kernel<<<grid, 256, 0, st>>>(n->dev, obs, B, o, heads);
+    LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int eaz_net_forward(eaz_net* n, int B, const uint8_t* d_obs, float* d_exploit, float* d_explore, float* d_value,
+                               float* d_ube, float* d_novelty, void* stream) {
+    ARG_OK(n && d_obs && B >= 0);
+    if (B == 0) return 0;
+    float* nov = d_novelty;
+    float* tmp = nullptr;
+    if (d_ube && !nov) {  // u needs the novelty lookup even when the caller does not want it back
+        HIP_OK(hipMallocAsync(reinterpret_cast<void**>(&tmp), sizeof(float) * B, S(stream)));
+        nov = tmp;
+    }
+    if (nov) {
+        int rc = hash_launch(n, B, d_obs, nov, nullptr, nullptr, 0, S(stream));
+        if (rc) return rc;
+    }
+    HeadList hl{0, {0, 0, 0, 0}};
+    if (d_value) hl.id[hl.n++] = 0;
+    if (d_ube) hl.id[hl.n++] = 1;
+    if (d_exploit) hl.id[hl.n++] = 2;
+    if (d_explore) hl.id[hl.n++] = 3;
+    NetOut o{d_exploit, d_explore, d_value, d_ube, nov};
+    int rc = fc_launch(n, B, d_obs, o, hl, S(stream));
+    if (tmp) HIP_OK(hipFreeAsync(tmp, S(stream)));
+    return rc;
+}
+
+extern "C" int eaz_hash_lookup(eaz_net* n, int B, const uint8_t* d_obs, uint8_t* d_seen, uint32_t* d_indices, void* stream) {
+    ARG_OK(n && d_obs && B >= 0);
+    return hash_launch(n, B, d_obs, nullptr, d_seen, d_indices, 0, S(stream));
+}
+extern "C" int eaz_hash_update(eaz_net* n, int B, const uint8_t* d_obs, void* stream) {
+    ARG_OK(n && d_obs && B >= 0);
+    return hash_launch(n, B, d_obs, nullptr, nullptr, nullptr, 1, S(stream));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// search
+// ------------------------------------------------------------------------------------------------------------------
+// mctx seq_halving.get_sequence_of_considered_visits [EXT] -- host-side integer table
+static void considered_visits(int m, int S_, int32_t* out) {
+    if (m <= 1) { for (int i = 0; i < S_; ++i) out[i] = i; return; }
+    int log2max = 0;
+    while ((1 << log2max) < m) log2max++;
+    std::vector<int> visits(m, 0);
+    int nc = m, len = 0;
+    while (len < S_) {
+        int extra = static_cast<int>(static_cast<double>(S_) / static_cast<double>(log2max * nc));
+        if (extra < 1) extra = 1;
+        for (int r = 0; r < extra; ++r) {
+            for (int i = 0; i < nc && len < S_; ++i) out[len++] = visits[i];
+            for (int i = 0; i < nc; ++i) visits[i] += 1;
+        }
+        nc = nc / 2 > 2 ? nc / 2 : 2;
+    }
+}
+
+template <typename T>
+static int dalloc(eaz_search* s, T** p, size_t count) {
+    void* q = nullptr;
+    HIP_OK(hipMalloc(&q, sizeof(T) * (count ? count : 1)));
+    s->allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return 0;
+}
+#define DALLOC(p, count)                    \
+    do {                                    \
+        int rc_ = dalloc(s, &(p), (count)); \
+        if (rc_) return rc_;                \
+    } while (0)
+
+// dispatch on (lanes per tree, actions per lane)
+#define TREE_DISPATCH(s, CALL)                                   \
+    do {                                                         \
+        switch ((s)->lpt * 8 + (s)->apl) {                       \
+            case 2 * 8 + 1: { CALL(2, 1); } break;               \
+            case 4 * 8 + 1: { CALL(4, 1); } break;               \
+            case 8 * 8 + 1: { CALL(8, 1); } break;               \
+            case 16 * 8 + 1: { CALL(16, 1); } break;             \
+            case 32 * 8 + 1: { CALL(32, 1); } break;             \
+            case 64 * 8 + 1: { CALL(64, 1); } break;             \
+            case 64 * 8 + 2: { CALL(64, 2); } break;             \
+            case 64 * 8 + 4: { CALL(64, 4); } break;             \
+            default: return fail("unsupported action count");    \
+        }                                                        \
+    } while (0)
+
+struct ProfScope {
+    eaz_search* s;
+    hipStream_t st;
+    int idx;
+    ProfScope(eaz_search* s_, int cls, hipStream_t st_) : s(s_), st(st_), idx(-1) {
+        if (!s->prof_on) return;
+        hipEvent_t a, b;
+        if (s->ev_pool.size() >= 2) {
+            a = s->ev_pool.back(); s->ev_pool.pop_back();
+            b = s->ev_pool.back(); s->ev_pool.pop_back();
+        } else {
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        }
+        s->spans.push_back(ProfSpan{a, b, cls});
+        idx = static_cast<int>(s->spans.size()) - 1;
+        (void)hipEventRecord(a, st);
+    }
+    ~ProfScope() {
+        if (idx >= 0) (void)hipEventRecord(s->spans[idx].b, st);
+    }
+};
+
+extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B, const eaz_search_opts* opts, eaz_search** out) {
+    ARG_OK(ctx && env && net && opts && out && B > 0);
+    ARG_OK(opts->num_simulations >= 1 && opts->num_simulations <= 4096);
+    if (net->dev.in_dim != env->dev.obs_dim) return fail("network input %d != observation size %d", net->dev.in_dim, env->dev.obs_dim);
+    if (net->dev.A != env->dev.A) return fail("network actions %d != env actions %d", net->dev.A, env->dev.A);
+    ARG_OK(opts->max_num_considered_actions >= 1 && opts->max_num_considered_actions <= 256);
+    HIP_OK(hipSetDevice(ctx->device));
+    eaz_search* s = new eaz_search();
+    s->ctx = ctx; s->env = env; s->net = net; s->opts = *opts;
+    s->B = B; s->S = opts->num_simulations; s->N = s->S + 1; s->A = env->dev.A;
+    s->prof_on = 0; s->step_graph = nullptr; s->step_graph_valid = false; s->pending_expand = -1;
+    const int A = s->A;
+    int p2 = 2;
+    while (p2 < A) p2 <<= 1;
+    if (p2 <= 64) { s->lpt = p2; s->apl = 1; }
+    else { s->lpt = 64; s->apl = p2 / 64; }
+    TreeDev& t = s->tree;
+    std::memset(&t, 0, sizeof t);
+    t.B = B; t.N = s->N; t.A = A; t.S = s->S;
+    const size_t bn = static_cast<size_t>(B) * s->N, bna = bn * A;
+    DALLOC(t.node_visits, bn); DALLOC(t.parents, bn); DALLOC(t.action_from_parent, bn);
+    DALLOC(t.raw_values, bn); DALLOC(t.node_values, bn); DALLOC(t.raw_var, bn); DALLOC(t.node_var, bn);
+    DALLOC(t.children_index, bna); DALLOC(t.children_visits, bna);
+    DALLOC(t.children_prior_logits, bna); DALLOC(t.children_values, bna); DALLOC(t.children_rewards, bna);
+    DALLOC(t.children_discounts, bna); DALLOC(t.children_var, bna); DALLOC(t.children_reward_var, bna);
+    DALLOC(t.beta, B); DALLOC(t.root_invalid, static_cast<size_t>(B) * A); DALLOC(t.root_gumbel, static_cast<size_t>(B) * A);
+    t.state_bytes = env->dev.state_bytes;
+    DALLOC(t.embeddings, bn * t.state_bytes);
+    DALLOC(t.sim_parent, B); DALLOC(t.sim_action, B); DALLOC(t.sim_next, B);
+    // sequential-halving table
+    const int mc = opts->max_num_considered_actions;
+    std::vector<int32_t> table(static_cast<size_t>(mc + 1) * s->S);
+    for (int m = 0; m <= mc; ++m) considered_visits(m, s->S, table.data() + static_cast<size_t>(m) * s->S);
+    DALLOC(s->d_table, table.size());
+    HIP_OK(hipMemcpy(s->d_table, table.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    t.table = s->d_table;
+    t.rescale = opts->rescale_values; t.use_mixed = opts->use_mixed_value; t.max_considered = mc;
+    t.max_depth = opts->max_depth > 0 ? opts->max_depth : s->S;
+    t.value_scale = opts->value_scale; t.maxvisit_init = opts->maxvisit_init;
+    t.discount = opts->discount; t.two_player = opts->two_players_game;
+    // per-simulation workspace
+    DALLOC(s->d_obs, static_cast<size_t>(B) * env->dev.obs_dim + 16);
+    DALLOC(s->d_novelty, B); DALLOC(s->d_exploit, static_cast<size_t>(B) * A); DALLOC(s->d_explore, static_cast<size_t>(B) * A);
+    DALLOC(s->d_v, B); DALLOC(s->d_u, B); DALLOC(s->d_next_reward, B); DALLOC(s->d_next_term, B);
+    DALLOC(s->d_next_legal, static_cast<size_t>(B) * A);
+    DALLOC(s->d_root_logits, static_cast<size_t>(B) * A); DALLOC(s->d_root_beta, B); DALLOC(s->d_root_gumbel, static_cast<size_t>(B) * A);
+    DALLOC(s->d_aw, static_cast<size_t>(B) * A); DALLOC(s->d_vprobs, static_cast<size_t>(B) * A);
+    DALLOC(s->d_root_invalid, static_cast<size_t>(B) * A); DALLOC(s->d_legal, static_cast<size_t>(B) * A); DALLOC(s->d_action, B);
+    t.net_logits = opts->exploration ? s->d_explore : s->d_exploit;  // context.py:132
+    t.net_value = s->d_v; t.net_ube = s->d_u;
+    t.next_reward = s->d_next_reward; t.next_term = s->d_next_term; t.next_legal = s->d_next_legal;
+    *out = s;
+    return 0;
+}
+
+extern "C" int eaz_search_destroy(eaz_search* s) {
+    if (!s) return 0;
+    for (void* p : s->allocs) (void)hipFree(p);
+    for (auto& sp : s->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (auto& e : s->ev_pool) (void)hipEventDestroy(e);
+    if (s->step_graph) (void)hipGraphExecDestroy(s->step_graph);
+    delete s;
+    return 0;
+}
+
+static int tree_grid(const eaz_search* s) { return cdiv(static_cast<long>(s->B) * s->lpt, 256); }
+
+extern "C" int eaz_search_begin(eaz_search* s, const float* d_prior_logits, const float* d_value, const float* d_value_var,
+                                const void* d_root_states, const float* d_beta, const uint8_t* d_invalid, const float* d_gumbel,
+                                void* stream) {
+    ARG_OK(s && d_prior_logits && d_value && d_value_var && d_root_states && d_beta && d_gumbel);
+    hipStream_t st = S(stream);
+    {
+        ProfScope ps(s, EAZ_K_MISC, st);
+        const long bna = static_cast<long>(s->B) * s->N * s->A;
+        tree_clear_kernel<<<cdiv(bna, 256) < 4096 ? cdiv(bna, 256) : 4096, 256, 0, st>>>(s->tree);
+        LAUNCH_OK();
+#define CALL_ROOT(L, P)                                                                                              \
+    tree_root_kernel<L, P><<<tree_grid(s), 256, 0, st>>>(s->tree, d_prior_logits, d_value, d_value_var,                \
+                                                         static_cast<const char*>(d_root_states), d_beta, d_invalid, d_gumbel)
+        TREE_DISPATCH(s, CALL_ROOT);
+#undef CALL_ROOT
+        LAUNCH_OK();
+    }
+    s->pending_expand = -1;
+    return 0;
+}
+
+static int tree_step_launch(eaz_search* s, int sim, int mode, hipStream_t st) {
+    ProfScope ps(s, EAZ_K_TREE, st);
+#define CALL_STEP(L, P) tree_step_kernel<L, P><<<tree_grid(s), 256, 0, st>>>(s->tree, sim, mode)
+    TREE_DISPATCH(s, CALL_STEP);
+#undef CALL_STEP
+    LAUNCH_OK();
+    return 0;
+}
+
+// leaf gather + env.step + observation (context.py:125-127), novelty lookup, network forward (context.py:129-131)
+static int recurrent_launch(eaz_search* s, hipStream_t st) {
+    eaz_env* env = s->env;
+    const int B = s->B;
+    {
+        ProfScope ps(s, EAZ_K_GATHER, st);
+        if (env->dev.kind == EAZ_ENV_DEEPSEA) {
+            leaf_gather_deepsea_kernel<<<cdiv(static_cast<long>(B) * 64, 256), 256, 0, st>>>(
+                env->dev, s->tree, s->d_obs, s->d_next_reward, s->d_next_term, s->d_next_legal);
+            LAUNCH_OK();
+        } else {
+            StateRef src{s->tree.embeddings, s->tree.sim_parent, s->N};
+            StateRef dst{s->tree.embeddings, s->tree.sim_next, s->N};
+            subleq_step_kernel<<<cdiv(B, 64), 192, 192 * env->dev.W, st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0},
+                                                                             nullptr, s->d_next_reward, s->d_next_term, s->d_next_legal);
+            LAUNCH_OK();
+            obs_emit_kernel<<<cdiv(static_cast<long>(B) * 64, 256), 256, 0, st>>>(env->dev, dst, B, s->d_obs);
+            LAUNCH_OK();
+        }
+    }
+    {
+        ProfScope ps(s, EAZ_K_HASH, st);
+        int rc = hash_launch(s->net, B, s->d_obs, s->d_novelty, nullptr, nullptr, 0, st);
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(s, EAZ_K_NET, st);
+        HeadList hl{3, {0, 1, s->opts.exploration ? 3 : 2, 0}};
+        NetOut o{s->opts.exploration ? nullptr : s->d_exploit, s->opts.exploration ? s->d_explore : nullptr, s->d_v, s->d_u, s->d_novelty};
+        int rc = fc_launch(s->net, B, s->d_obs, o, hl, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int eaz_search_simulate(eaz_search* s, int sim, void* stream) {
+    ARG_OK(s && sim >= 0 && sim < s->S);
+    hipStream_t st = S(stream);
+    s->tree.fused_rf = 1;
+    int mode = kTreeSelect | (s->pending_expand >= 0 ? kTreeExpand : 0);
+    int rc = tree_step_launch(s, sim, mode, st);
+    if (rc) return rc;
+    rc = recurrent_launch(s, st);
+    if (rc) return rc;
+    s->pending_expand = sim;
+    return 0;
+}
+
+static int flush_expand(eaz_search* s, hipStream_t st) {
+    if (s->pending_expand < 0) return 0;
+    int rc = tree_step_launch(s, s->pending_expand + 1, kTreeExpand, st);
+    s->pending_expand = -1;
+    return rc;
+}
+
+extern "C" int eaz_search_run(eaz_search* s, void* stream) {
+    ARG_OK(s != nullptr);
+    for (int sim = 0; sim < s->S; ++sim) {
+        int rc = eaz_search_simulate(s, sim, stream);
+        if (rc) return rc;
+    }
+    return flush_expand(s, S(stream));
+}
+
+extern "C" int eaz_search_finish(eaz_search* s, int32_t* d_action, float* d_action_weights, void* stream) {
+    ARG_OK(s != nullptr);
+    hipStream_t st = S(stream);
+    int rc = flush_expand(s, st);
+    if (rc) return rc;
+    ProfScope ps(s, EAZ_K_MISC, st);
+#define CALL_FIN(L, P) tree_finish_kernel<L, P><<<tree_grid(s), 256, 0, st>>>(s->tree, d_action, d_action_weights)
+    TREE_DISPATCH(s, CALL_FIN);
+#undef CALL_FIN
+    LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int eaz_search_summary(eaz_search* s, float* d_value, float* d_value_std, float* d_qvalues, float* d_qvalues_var,
+                                  float* d_visit_counts, float* d_visit_probs, void* stream) {
+    ARG_OK(s != nullptr);
+    hipStream_t st = S(stream);
+    int rc = flush_expand(s, st);
+    if (rc) return rc;
+    ProfScope ps(s, EAZ_K_MISC, st);
+    tree_summary_kernel<<<cdiv(static_cast<long>(s->B) * s->A, 256), 256, 0, st>>>(s->tree, d_value, d_value_std, d_qvalues,
+                                                                                   d_qvalues_var, d_visit_counts, d_visit_probs);
+    LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int eaz_search_select(eaz_search* s, int sim, int32_t* d_parent, int32_t* d_action, int32_t* d_next, void* stream) {
+    ARG_OK(s && sim >= 0 && sim < s->S);
+    hipStream_t st = S(stream);
+    if (s->pending_expand >= 0) return fail("eaz_search_select: simulation %d has not been expanded yet", s->pending_expand);
+    int rc = tree_step_launch(s, sim, kTreeSelect, st);
+    if (rc) return rc;
+    const size_t n = sizeof(int32_t) * s->B;
+    if (d_parent) HIP_OK(hipMemcpyAsync(d_parent, s->tree.sim_parent, n, hipMemcpyDeviceToDevice, st));
+    if (d_action) HIP_OK(hipMemcpyAsync(d_action, s->tree.sim_action, n, hipMemcpyDeviceToDevice, st));
+    if (d_next) HIP_OK(hipMemcpyAsync(d_next, s->tree.sim_next, n, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+extern "C" int eaz_search_expand(eaz_search* s, int sim, const float* d_reward, const float* d_reward_var, const float* d_discount,
+                                 const float* d_prior_logits, const float* d_value, const float* d_value_var, void* stream) {
+    ARG_OK(s && d_reward && d_reward_var && d_discount && d_prior_logits && d_value && d_value_var);
+    TreeDev& t = s->tree;
+    t.fused_rf = 0;
+    t.rf_reward = d_reward; t.rf_reward_var = d_reward_var; t.rf_discount = d_discount;
+    t.rf_logits = d_prior_logits; t.rf_value = d_value; t.rf_value_var = d_value_var;
+    int rc = tree_step_launch(s, sim + 1, kTreeExpand, S(stream));
+    t.fused_rf = 1;
+    return rc;
+}
+
+extern "C" int eaz_search_tree_view(eaz_search* s, int id, void** d_ptr, int64_t shape[3], int* elem_bytes) {
+    ARG_OK(s && d_ptr && shape && elem_bytes);
+    TreeDev& t = s->tree;
+    const int64_t B = s->B, N = s->N, A = s->A;
+    void* p = nullptr;
+    int64_t sh[3] = {B, N, 0};
+    int eb = 4;
+    switch (id) {
+        case EAZ_F_NODE_VISITS: p = t.node_visits; break;
+        case EAZ_F_RAW_VALUES: p = t.raw_values; break;
+        case EAZ_F_NODE_VALUES: p = t.node_values; break;
+        case EAZ_F_PARENTS: p = t.parents; break;
+        case EAZ_F_ACTION_FROM_PARENT: p = t.action_from_parent; break;
+        case EAZ_F_RAW_VALUES_VAR: p = t.raw_var; break;
+        case EAZ_F_NODE_VALUES_VAR: p = t.node_var; break;
+        case EAZ_F_CHILDREN_INDEX: p = t.children_index; sh[2] = A; break;
+        case EAZ_F_CHILDREN_PRIOR_LOGITS: p = t.children_prior_logits; sh[2] = A; break;
+        case EAZ_F_CHILDREN_VALUES: p = t.children_values; sh[2] = A; break;
+        case EAZ_F_CHILDREN_VISITS: p = t.children_visits; sh[2] = A; break;
+        case EAZ_F_CHILDREN_REWARDS: p = t.children_rewards; sh[2] = A; break;
+        case EAZ_F_CHILDREN_DISCOUNTS: p = t.children_discounts; sh[2] = A; break;
+        case EAZ_F_CHILDREN_VALUES_VAR: p = t.children_var; sh[2] = A; break;
+        case EAZ_F_CHILDREN_REWARDS_VAR: p = t.children_reward_var; sh[2] = A; break;
+        case EAZ_F_EMBEDDINGS: p = t.embeddings; sh[2] = t.state_bytes; eb = 1; break;
+        case EAZ_F_ROOT_GUMBEL: p = t.root_gumbel; sh[1] = A; break;
+        case EAZ_F_BETA: p = t.beta; sh[1] = 0; break;
+        default: return fail("unknown tree field id %d", id);
+    }
+    *d_ptr = p;
+    shape[0] = sh[0]; shape[1] = sh[1]; shape[2] = sh[2];
+    *elem_bytes = eb;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// self-play driver (src/selfplay.py:78-149)
+// ------------------------------------------------------------------------------------------------------------------
+static int selfplay_step(eaz_search* s, const eaz_selfplay_cfg* cfg, Key kt, int step, void* d_states, const float* d_gumbel,
+                         void* d_out_states, float* d_out_root_value, float* d_out_root_std, float* d_out_value_pred,
+                         float* d_out_ube_pred, float* d_out_qvar, int32_t* d_out_action, hipStream_t st) {
+    eaz_env* env = s->env;
+    const int B = s->B, A = s->A;
+    const long tb = static_cast<long>(step) * B;
+    int rc;
+    // root inference (selfplay.py:89-91): observation -> novelty -> value / ube / policy head
+    {
+        ProfScope ps(s, EAZ_K_MISC, st);
+        rc = obs_launch(env, B, d_states, s->d_obs, st);
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(s, EAZ_K_HASH, st);
+        rc = hash_launch(s->net, B, s->d_obs, s->d_novelty, nullptr, nullptr, 0, st);
+        if (rc) return rc;
+    }
+    const bool explore = cfg->directed_exploration != 0;  // selfplay.py:93-95
+    {
+        ProfScope ps(s, EAZ_K_NET, st);
+        HeadList hl{3, {0, 1, explore ? 3 : 2, 0}};
+        // root outputs go to dedicated buffers: d_v/d_u are overwritten by the simulations
+        NetOut o{explore ? nullptr : s->d_root_logits, explore ? s->d_root_logits : nullptr,
+                 d_out_value_pred ? d_out_value_pred + tb : s->d_v, d_out_ube_pred ? d_out_ube_pred + tb : s->d_u, s->d_novelty};
+        rc = fc_launch(s->net, B, s->d_obs, o, hl, st);
+        if (rc) return rc;
+    }
+    const float* root_v = d_out_value_pred ? d_out_value_pred + tb : s->d_v;
+    const float* root_u = d_out_ube_pred ? d_out_ube_pred + tb : s->d_u;
+    {
+        ProfScope ps(s, EAZ_K_MISC, st);
+        env_fields_kernel<<<cdiv(B, 256), 256, 0, st>>>(env->dev, static_cast<const char*>(d_states), B, nullptr, nullptr, nullptr,
+                                                       nullptr, s->d_legal);
+        LAUNCH_OK();
+        const float sbeta = explore ? cfg->exploration_beta : 0.0f;  // selfplay.py:92
+        root_prep_kernel<<<cdiv(static_cast<long>(B) * A, 256), 256, 0, st>>>(
+            B, A, s->d_root_logits, cfg->uniform_search_policy, sbeta, s->d_legal,
+            d_gumbel ? d_gumbel + tb * A : nullptr, fold(kt, kTagGumbel), s->opts.gumbel_scale, s->d_root_logits, s->d_root_beta,
+            s->d_root_invalid, s->d_root_gumbel);
+        LAUNCH_OK();
+    }
+    rc = eaz_search_begin(s, s->d_root_logits, root_v, root_u, d_states, s->d_root_beta, s->d_root_invalid, s->d_root_gumbel, st);
+    if (rc) return rc;
+    rc = eaz_search_run(s, st);
+    if (rc) return rc;
+    rc = eaz_search_finish(s, s->d_action, s->d_aw, st);
+    if (rc) return rc;
+    rc = eaz_search_summary(s, d_out_root_value ? d_out_root_value + tb : nullptr, d_out_root_std ? d_out_root_std + tb : nullptr,
+                            nullptr, d_out_qvar ? d_out_qvar + tb * A : nullptr, nullptr, s->d_vprobs, st);
+    if (rc) return rc;
+    {
+        ProfScope ps(s, EAZ_K_MISC, st);
+        if (cfg->sample_actions || cfg->sample_from_improved_policy) {
+            choose_action_kernel<<<cdiv(B, 256), 256, 0, st>>>(B, A, s->d_action, s->d_vprobs, s->d_aw, cfg->sample_actions,
+                                                              cfg->sample_from_improved_policy, fold(kt, kTagSampleVisits),
+                                                              fold(kt, kTagSampleImproved));
+            LAUNCH_OK();
+        }
+        if (d_out_action) HIP_OK(hipMemcpyAsync(d_out_action + tb, s->d_action, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, st));
+        // real env step with auto-reset (selfplay.py:135); the new states are also the SelfplayOutput.state of this step
+        char* copy = d_out_states ? static_cast<char*>(d_out_states) + tb * env->dev.state_bytes : nullptr;
+        rc = env_step_launch(env, B, d_states, s->d_action, fold(kt, kTagEnv), 1, d_states, copy, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int eaz_selfplay_run(eaz_search* s, const eaz_selfplay_cfg* cfg, uint64_t key, void* d_states, const float* d_gumbel,
+                                void* d_out_states, float* d_out_root_value, float* d_out_root_std, float* d_out_value_pred,
+                                float* d_out_ube_pred, float* d_out_qvar, int32_t* d_out_action, void* stream) {
+    ARG_OK(s && cfg && d_states && cfg->selfplay_steps >= 0);
+    if ((cfg->directed_exploration != 0) != (s->opts.exploration != 0))
+        return fail("selfplay: directed_exploration (%d) must match the search's recurrent-fn `exploration` flag (%d), main.py:262",
+                    cfg->directed_exploration, s->opts.exploration);
+    HIP_OK(hipSetDevice(s->ctx->device));
+    const Key k = key_from_u64(key);
+    for (int step = 0; step < cfg->selfplay_steps; ++step) {
+        int rc = selfplay_step(s, cfg, fold(k, kTagStep + static_cast<uint32_t>(step)), step, d_states, d_gumbel, d_out_states,
+                               d_out_root_value, d_out_root_std, d_out_value_pred, d_out_ube_pred, d_out_qvar, d_out_action, S(stream));
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int eaz_random_play(eaz_env* env, int B, int T, uint64_t key, void* d_states, void* d_traj, void* stream) {
+    ARG_OK(env && d_states && B > 0 && T >= 0);
+    hipStream_t st = S(stream);
+    const Key k = key_from_u64(key);
+    int rc = env_step_launch(env, B, nullptr, nullptr, fold(k, kTagInit), 2, d_states, nullptr, st);
+    if (rc) return rc;
+    int32_t* d_act = nullptr;
+    HIP_OK(hipMallocAsync(reinterpret_cast<void**>(&d_act), sizeof(int32_t) * B, st));
+    const size_t sb = static_cast<size_t>(env->dev.state_bytes) * B;
+    for (int step = 0; step < T; ++step) {
+        const Key kt = fold(k, kTagStep + static_cast<uint32_t>(step));
+        random_action_kernel<<<cdiv(B, 256), 256, 0, st>>>(B, env->dev.A, fold(kt, kTagRandomAction), d_act);
+        LAUNCH_OK();
+        if (d_traj) HIP_OK(hipMemcpyAsync(static_cast<char*>(d_traj) + sb * step, d_states, sb, hipMemcpyDeviceToDevice, st));
+        rc = env_step_launch(env, B, d_states, d_act, fold(kt, kTagEnv), 1, d_states, nullptr, st);
+        if (rc) return rc;
+    }
+    HIP_OK(hipFreeAsync(d_act, st));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// instrumentation
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int eaz_profile_enable(eaz_search* s, int on) {
+    ARG_OK(s != nullptr);
+    s->prof_on = on;
+    return 0;
+}
+
+extern "C" int eaz_profile_read(eaz_search* s, double ms[EAZ_K_COUNT], int64_t launches[EAZ_K_COUNT], int reset) {
+    ARG_OK(s && ms && launches);
+    HIP_OK(hipDeviceSynchronize());
+    for (int i = 0; i < EAZ_K_COUNT; ++i) { ms[i] = 0.0; launches[i] = 0; }
+    for (auto& sp : s->spans) {
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess) { ms[sp.cls] += t; launches[sp.cls] += 1; }
+    }
+    if (reset) {
+        for (auto& sp : s->spans) { s->ev_pool.push_back(sp.a); s->ev_pool.push_back(sp.b); }
+        s->spans.clear();
+    }
+    return 0;
+}

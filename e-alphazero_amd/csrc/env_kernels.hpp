@@ -1,0 +1,239 @@
+// env_kernels.hpp -- batched environment kernels: init / step / auto-reset / observe / field export, and the
+// leaf-gather kernel of the search (T4 "expand: gather embedding[b, parent] -> env.step -> new embedding + observation row").
+//
+// Leaf gather data flow (DeepSea, per tree and simulation): read the parent's 16-byte compact state, step it
+// (pgx wrapper + deep_sea.py:59-81), write the child's 16-byte state into the tree's embedding slab, and emit the
+// child's observation as ONE coalesced 16-byte-per-lane row store into the contiguous [B, obs_dim] uint8 inference
+// batch.  The reference moves the whole pgx.State (observation included) on both sides (src/selfplay.py:104); the
+// algorithmic bytes of DESIGN.md are counted on the engine's compact layout.
+#pragma once
+#include "envs.hpp"
+#include "tree.hpp"
+
+namespace eaz {
+
+// ---- observation rows -------------------------------------------------------------------------------------------
+// one wavefront per state; 16 bytes per lane per pass
+__device__ __forceinline__ void emit_obs_row(const EnvDev& e, const char* sp, uint8_t* row, int lane) {
+    const int D = e.obs_dim;
+    const int hot = e.kind == EAZ_ENV_DEEPSEA ? ds_hot_index(e, ds_load(sp)) : 0;
+    const bool vec = (D % 16 == 0) && ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
+    if (vec) {
+        for (int base = lane * 16; base < D; base += 64 * 16) {
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            if (e.kind == EAZ_ENV_DEEPSEA) {
+                const int o = hot - base;
+                if (o >= 0 && o < 16) w[o >> 2] = 1u << (8 * (o & 3));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) w[i >> 2] |= static_cast<uint32_t>(obs_byte(e, sp, hot, base + i)) << (8 * (i & 3));
+            }
+            *reinterpret_cast<uint4*>(row + base) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    } else {
+        for (int i = lane; i < D; i += 64) row[i] = obs_byte(e, sp, hot, i);
+    }
+}
+
+__global__ void __launch_bounds__(256) obs_emit_kernel(EnvDev e, StateRef src, int B, uint8_t* obs) {
+    const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (b >= B) return;
+    emit_obs_row(e, state_ptr(src, b, e.state_bytes), obs + static_cast<long>(b) * e.obs_dim, lane);
+}
+
+// ---- DeepSea ----------------------------------------------------------------------------------------------------
+// mode: 0 = env.step, 1 = auto_reset(env.step, env.init) (selfplay.py:26-75), 2 = env.init
+__global__ void __launch_bounds__(256) deepsea_step_kernel(EnvDev e, const char* in, const int32_t* action, int B, int mode,
+                                                           char* out, char* out_copy) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    eaz_deepsea_state s;
+    if (mode == 2) {
+        s = ds_init();
+    } else {
+        s = ds_load(in + static_cast<long>(b) * sizeof(eaz_deepsea_state));
+        if (mode == 1 && (s.terminated | s.truncated)) s = ds_init();
+        else s = ds_step(e, s, action[b]);
+    }
+    ds_store(out + static_cast<long>(b) * sizeof(eaz_deepsea_state), s);
+    if (out_copy) ds_store(out_copy + static_cast<long>(b) * sizeof(eaz_deepsea_state), s);
+}
+
+// leaf gather + env.step + observation emit: one wavefront per tree
+__global__ void __launch_bounds__(256) leaf_gather_deepsea_kernel(EnvDev e, TreeDev t, uint8_t* obs, float* next_reward,
+                                                                  uint8_t* next_term, uint8_t* next_legal) {
+    const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (b >= t.B) return;
+    const int parent = t.sim_parent[b], action = t.sim_action[b], nxt = t.sim_next[b];
+    char* base = t.embeddings + static_cast<long>(b) * t.N * sizeof(eaz_deepsea_state);
+    const eaz_deepsea_state s = ds_step(e, ds_load(base + static_cast<long>(parent) * sizeof(eaz_deepsea_state)), action);
+    if (lane == 0) {
+        ds_store(base + static_cast<long>(nxt) * sizeof(eaz_deepsea_state), s);
+        next_reward[b] = s.reward;          // rewards[b, current_player], single player (deep_sea.py:100-102)
+        next_term[b] = s.terminated;
+    }
+    if (lane < e.A) next_legal[static_cast<long>(b) * e.A + lane] = 1;  // legal_action_mask all true (deep_sea.py:19)
+    // observation row (deep_sea.py:66-70) -> contiguous inference batch
+    const int D = e.obs_dim;
+    uint8_t* row = obs + static_cast<long>(b) * D;
+    const int hot = ds_hot_index(e, s);
+    if (D % 16 == 0) {
+        for (int o0 = lane * 16; o0 < D; o0 += 64 * 16) {
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            const int o = hot - o0;
+            if (o >= 0 && o < 16) w[o >> 2] = 1u << (8 * (o & 3));
+            *reinterpret_cast<uint4*>(row + o0) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    } else {
+        for (int i = lane; i < D; i += 64) row[i] = static_cast<uint8_t>(i == hot);
+    }
+}
+
+// ---- Subleq -----------------------------------------------------------------------------------------------------
+// One thread per (environment, test case): 64 environments x 3 test cases per 192-thread workgroup.  Each thread
+// interprets the program on a private copy of the memory in LDS (W bytes), <= 200 cycles (subleq.py:19,297-299).
+// mode as deepsea_step_kernel.  src/dst may alias (in-place real step) or be tree embedding slots (leaf gather).
+__global__ void __launch_bounds__(192) subleq_step_kernel(EnvDev e, StateRef src, StateRef dst, const int32_t* action, int B,
+                                                          int mode, Key key, char* out_copy, float* next_reward,
+                                                          uint8_t* next_term, uint8_t* next_legal) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lmem[];  // 192 * W
+    __shared__ uint8_t s_correct[192];
+    __shared__ uint16_t s_in_after[64][8], s_out_after[64][8];
+    const int W = e.W;
+    const int el = threadIdx.x / 3, c = threadIdx.x - el * 3;
+    const int b = blockIdx.x * 64 + el;
+    const bool live = b < B;
+    const eaz_subleq_state* sp = live ? reinterpret_cast<const eaz_subleq_state*>(state_ptr(src, b, e.state_bytes)) : nullptr;
+    eaz_subleq_state* dp = live ? reinterpret_cast<eaz_subleq_state*>(state_ptr(dst, b, e.state_bytes)) : nullptr;
+
+    // ---- decide what this environment does (pgx wrapper A.1, auto_reset selfplay.py:66-71, _step subleq.py:671-677)
+    bool do_init = false, noop = false, finish = false, run = false;
+    int step_count = 0, task = 0, act = 0;
+    if (live) {
+        const bool done = mode != 2 && (sp->terminated | sp->truncated);
+        do_init = mode == 2 || (mode == 1 && done);
+        if (do_init) {
+            const Key kb = fold(key, static_cast<uint32_t>(b));
+            const Key ki = mode == 2 ? kb : fold(kb, 1u);
+            const int idx = e.n_tasks > 1 ? static_cast<int>(rbits(ki, 0) % static_cast<uint32_t>(e.n_tasks)) : 0;  // subleq.py:624
+            task = e.tasks[idx];
+            step_count = 0;
+            run = true;
+        } else if (done) {
+            noop = true;  // same state, zero rewards
+            task = sp->task; step_count = sp->step_count;
+        } else {
+            task = sp->task;
+            step_count = sp->step_count + 1;
+            act = action[b];
+            if (step_count >= W - 3 || sp->solved) finish = true;  // subleq.py:671-673
+            else run = true;
+        }
+    }
+    uint8_t* mem = lmem + static_cast<long>(threadIdx.x) * W;
+    uint16_t tin[8], tout[8], outv[8];
+    bool correct = false;
+    if (run) {
+        if (do_init) { for (int i = 0; i < W; ++i) mem[i] = 0; }
+        else {
+            for (int i = 0; i < W; i += 4) *reinterpret_cast<uint32_t*>(mem + i) = *reinterpret_cast<const uint32_t*>(sp->memory + i);
+            const int idx = step_count - 1;  // subleq.py:654
+            if (idx >= 0 && idx < W) mem[idx] = static_cast<uint8_t>(act);
+        }
+        subleq_test_case(task, c, W, tin, tout);
+        uint16_t ex_in[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ex_in[i] = tin[i];
+        correct = subleq_simulate(W, mem, tin, tout, outv);
+        if (c == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s_in_after[el][i] = tin[i]; s_out_after[el][i] = outv[i]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { tin[i] = ex_in[i]; }  // keep example_input for the state write below
+        }
+    }
+    s_correct[threadIdx.x] = correct ? 1 : 0;
+    __syncthreads();
+    if (!live || c != 0) return;
+
+    // ---- assemble the new state (thread c == 0 of each environment) -------------------------------------------
+    const bool copy_mem = reinterpret_cast<const void*>(sp) != reinterpret_cast<const void*>(dp);
+    float reward;
+    uint8_t terminated, solved;
+    if (run) {
+        solved = s_correct[threadIdx.x] & s_correct[threadIdx.x + 1] & s_correct[threadIdx.x + 2];  // subleq.py:525
+        reward = solved ? 1.0f : 0.0f;                                                                // :535-537
+        terminated = do_init ? 0 : sp->terminated;  // _step never sets terminated on this branch (:661-669)
+        if (do_init) {
+            for (int i = 0; i < 256; i += 16) *reinterpret_cast<uint4*>(dp->memory + i) = make_uint4(0, 0, 0, 0);
+        } else {
+            if (copy_mem)
+                for (int i = 0; i < 256; i += 16) *reinterpret_cast<uint4*>(dp->memory + i) = *reinterpret_cast<const uint4*>(sp->memory + i);
+            const int idx = step_count - 1;
+            if (idx >= 0 && idx < W) dp->memory[idx] = static_cast<uint8_t>(act);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            dp->ex_in[i] = tin[i];
+            dp->ex_out[i] = tout[i];
+            dp->ex_in_after[i] = s_in_after[el][i];
+            dp->ex_out_after[i] = s_out_after[el][i];
+        }
+    } else {
+        solved = sp->solved;
+        reward = 0.0f;                       // terminal no-op (A.1) or subleq.py:673
+        terminated = finish ? 1 : sp->terminated;
+        if (copy_mem) {
+            for (int i = 0; i < 256; i += 16) *reinterpret_cast<uint4*>(dp->memory + i) = *reinterpret_cast<const uint4*>(sp->memory + i);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                dp->ex_in[i] = sp->ex_in[i]; dp->ex_out[i] = sp->ex_out[i];
+                dp->ex_in_after[i] = sp->ex_in_after[i]; dp->ex_out_after[i] = sp->ex_out_after[i];
+            }
+        }
+    }
+    const uint8_t truncated = (do_init || !sp) ? 0 : sp->truncated;
+    dp->step_count = step_count;
+    dp->task = task;
+    dp->reward = reward;
+    dp->terminated = terminated;
+    dp->truncated = truncated;
+    dp->solved = solved;
+    dp->pad = 0;
+    (void)noop;
+    if (out_copy) {
+        uint4* o = reinterpret_cast<uint4*>(out_copy + static_cast<long>(b) * sizeof(eaz_subleq_state));
+        const uint4* i4 = reinterpret_cast<const uint4*>(dp);
+        for (int i = 0; i < static_cast<int>(sizeof(eaz_subleq_state) / 16); ++i) o[i] = i4[i];
+    }
+    if (next_reward) next_reward[b] = reward;
+    if (next_term) next_term[b] = terminated;
+    if (next_legal)
+        for (int a = 0; a < e.A; ++a) next_legal[static_cast<long>(b) * e.A + a] = 1;  // all legal (subleq.py:626)
+}
+
+// ---- state field export (pgx.State-visible fields) -----------------------------------------------------------------
+__global__ void __launch_bounds__(256) env_fields_kernel(EnvDev e, const char* states, int B, uint8_t* terminated,
+                                                         uint8_t* truncated, float* reward, int32_t* step_count, uint8_t* legal) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const char* sp = states + static_cast<long>(b) * e.state_bytes;
+    uint8_t term, trunc;
+    float rew;
+    int sc;
+    if (e.kind == EAZ_ENV_DEEPSEA) {
+        const eaz_deepsea_state s = ds_load(sp);
+        term = s.terminated; trunc = s.truncated; rew = s.reward; sc = s.step_count;
+    } else {
+        const eaz_subleq_state* s = reinterpret_cast<const eaz_subleq_state*>(sp);
+        term = s->terminated; trunc = s->truncated; rew = s->reward; sc = s->step_count;
+    }
+    if (terminated) terminated[b] = term;
+    if (truncated) truncated[b] = trunc;
+    if (reward) reward[b] = rew;
+    if (step_count) step_count[b] = sc;
+    if (legal)
+        for (int a = 0; a < e.A; ++a) legal[static_cast<long>(b) * e.A + a] = 1;
+}
+
+}  // namespace eaz

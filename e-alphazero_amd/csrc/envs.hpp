@@ -1,0 +1,231 @@
+// envs.hpp -- device-side environments: pgx.Env wrapper semantics + DeepSea + Subleq.
+//
+// Reference: pgx.Env.step/init/observe [EXT] (called at src/context.py:127, src/selfplay.py:135,166),
+//            src/envs/deep_sea.py:54-85, src/envs/subleq.py:26-98,156-532,623-707, auto_reset src/selfplay.py:26-75.
+// States are the compact blobs of include/eaz.h; the observation is regenerated from them on demand.
+#pragma once
+#include "../../include/eaz.h"
+#include "rng.hpp"
+
+namespace eaz {
+
+struct EnvDev {
+    int kind;
+    int A;
+    int obs_rows, obs_cols, obs_dim;
+    int state_bytes;
+    // DeepSea
+    int G;
+    const uint8_t* action_map;  // device [G*G]
+    // Subleq
+    int W;
+    int n_tasks;
+    int tasks[16];
+    int binary;
+};
+
+// A batch of states addressed as base + (b * nodes_per_tree + idx[b]) * state_bytes  (idx == nullptr -> 0).
+struct StateRef {
+    char* base;
+    const int32_t* idx;
+    int nodes_per_tree;
+};
+__device__ __forceinline__ char* state_ptr(const StateRef& r, int b, int state_bytes) {
+    const long n = r.idx ? r.idx[b] : 0;
+    return r.base + (static_cast<long>(b) * r.nodes_per_tree + n) * state_bytes;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// DeepSea
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ eaz_deepsea_state ds_load(const char* p) {
+    const int4 v = *reinterpret_cast<const int4*>(p);
+    eaz_deepsea_state s;
+    s.step_count = v.x;
+    s.pos = v.y;
+    s.reward = __builtin_bit_cast(float, v.z);
+    s.terminated = static_cast<uint8_t>(v.w & 0xFF);
+    s.truncated = static_cast<uint8_t>((v.w >> 8) & 0xFF);
+    s.pad[0] = s.pad[1] = 0;
+    return s;
+}
+__device__ __forceinline__ void ds_store(char* p, const eaz_deepsea_state& s) {
+    int4 v;
+    v.x = s.step_count;
+    v.y = s.pos;
+    v.z = __builtin_bit_cast(int, s.reward);
+    v.w = static_cast<int>(s.terminated) | (static_cast<int>(s.truncated) << 8);
+    *reinterpret_cast<int4*>(p) = v;
+}
+
+// deep_sea.py:54-57
+__device__ __forceinline__ eaz_deepsea_state ds_init() {
+    eaz_deepsea_state s;
+    s.step_count = 0; s.pos = 0; s.reward = 0.0f; s.terminated = 0; s.truncated = 0; s.pad[0] = s.pad[1] = 0;
+    return s;
+}
+
+// pgx.Env.step wrapper (A.1) around deep_sea.py:59-81.  All actions are legal (deep_sea.py:19).
+__device__ __forceinline__ eaz_deepsea_state ds_step(const EnvDev& e, eaz_deepsea_state s, int action) {
+    if (s.terminated | s.truncated) {  // terminal no-op with zero rewards
+        s.reward = 0.0f;
+        return s;
+    }
+    const int G = e.G;
+    s.step_count += 1;
+    int r = s.step_count - 1;
+    r = r < 0 ? 0 : (r > G - 1 ? G - 1 : r);
+    const int flip = e.action_map[r * G + s.pos] != 0;          // :62
+    const int shift = ((action == 0) ^ flip) ? -1 : 1;          // :63
+    int pos = s.pos + shift;
+    pos = pos < 0 ? 0 : (pos > G - 1 ? G - 1 : pos);            // :64
+    const int term = s.step_count >= G - 1;                     // :72
+    s.pos = pos;
+    s.terminated = static_cast<uint8_t>(term);
+    s.reward = (term && pos == G - 1) ? 1.0f : 0.0f;            // :74-78
+    return s;
+}
+
+// flat index of the single True cell, deep_sea.py:66-70
+__device__ __forceinline__ int ds_hot_index(const EnvDev& e, const eaz_deepsea_state& s) {
+    const int r = s.step_count < e.G - 1 ? s.step_count : e.G - 1;
+    return r * e.G + s.pos;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Subleq
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pymod(int x, int m) {
+    const int r = x % m;
+    return r < 0 ? r + m : r;
+}
+
+// subleq.py:398-501 get_test_cases: test case `c` of `task`, already modulo'd and padded (:101-107,:402-404).
+// lax.switch clamps the branch index, so task ids >= 6 all select the multiplication table.
+__device__ __forceinline__ void subleq_test_case(int task, int c, int W, uint16_t tin[8], uint16_t tout[8]) {
+    int branch = task - 1;
+    branch = branch < 0 ? 0 : (branch > 5 ? 5 : branch);
+    int in[8], out[8];
+    int nin = 0, nout = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { in[i] = 0; out[i] = 0; }
+    if (branch == 0) {  // NEGATION_POSITIVE :406-411
+        const int t1[8] = {5, 4, 4, 5, 1, 2, 3, 1}, t2[8] = {1, 1, 6, 2, 4, 4, 5, 3};
+        if (c == 0) { nin = 7; for (int i = 0; i < 7; ++i) in[i] = i + 1; }
+        else { nin = 8; for (int i = 0; i < 8; ++i) in[i] = c == 1 ? t1[i] : t2[i]; }
+        nout = nin;
+        for (int i = 0; i < 8; ++i) out[i] = -in[i];
+    } else if (branch == 1 || branch == 2) {  // NEGATION :413-418 / IDENTITY :420-421
+        const int t2[5] = {0, -1, 2, -3, 4};
+        if (c == 0) { nin = 8; for (int i = 0; i < 8; ++i) in[i] = -4 + i; }
+        else if (c == 1) { nin = 7; for (int i = 0; i < 7; ++i) in[i] = i + 1; }
+        else { nin = 5; for (int i = 0; i < 5; ++i) in[i] = t2[i]; }
+        nout = nin;
+        for (int i = 0; i < 8; ++i) out[i] = branch == 1 ? -in[i] : in[i];
+    } else if (branch == 3 || branch == 4) {  // SUBTRACTION :423-432 / ADDITION :434-443
+        const int a0[6] = {1, 1, 5, 4, 0, -3}, a1[6] = {2, 3, 0, 0, -1, -2}, a2[8] = {1, 2, 3, 4, 4, 3, 2, 1};
+        const int s0[3] = {0, 1, 3}, s1[3] = {-1, 0, 1}, s2[4] = {-1, -1, 1, 1};
+        const int p0[3] = {2, 9, -3}, p1[3] = {5, 0, -3}, p2[4] = {3, 7, 7, 3};
+        if (c == 0) { nin = 6; nout = 3; for (int i = 0; i < 6; ++i) in[i] = a0[i]; for (int i = 0; i < 3; ++i) out[i] = branch == 3 ? s0[i] : p0[i]; }
+        else if (c == 1) { nin = 6; nout = 3; for (int i = 0; i < 6; ++i) in[i] = a1[i]; for (int i = 0; i < 3; ++i) out[i] = branch == 3 ? s1[i] : p1[i]; }
+        else { nin = 8; nout = 4; for (int i = 0; i < 8; ++i) in[i] = a2[i]; for (int i = 0; i < 4; ++i) out[i] = branch == 3 ? s2[i] : p2[i]; }
+    } else {  // MULTIPLICATION :445-454
+        const int m0[6] = {1, 2, 2, 3, -7, 4}, m1[6] = {-1, -5, 5, 2, 0, 1}, m2[6] = {0, 0, 1, 1, -3, 3};
+        const int o0[3] = {2, 6, -28}, o1[3] = {5, 10, 0}, o2[3] = {0, 1, -9};
+        nin = 6; nout = 3;
+        for (int i = 0; i < 6; ++i) in[i] = c == 0 ? m0[i] : (c == 1 ? m1[i] : m2[i]);
+        for (int i = 0; i < 3; ++i) out[i] = c == 0 ? o0[i] : (c == 1 ? o1[i] : o2[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        tin[i] = static_cast<uint16_t>(i < nin ? pymod(in[i], W) : W);
+        tout[i] = static_cast<uint16_t>(i < nout ? pymod(out[i], W) : W);
+    }
+}
+
+// subleq.py:156-395 simulate.  `mem` is a private, mutable copy of the program (W bytes, LDS or scratch).
+// Returns correct (:394); in/out hold input_after / output_after on return.
+__device__ __forceinline__ bool subleq_simulate(int W, uint8_t* mem, uint16_t in[8], const uint16_t tout[8], uint16_t out[8]) {
+    const int AMAX = W - 4, AIN = W - 3, AOUT = W - 2;  // :162-165
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = static_cast<uint16_t>(W);  // :382
+    int out_cursor = 0, cur = 0, cycles = 0;
+    bool halt = false, error = false;
+    while (!error && !halt && cycles < 200) {  // :297-299, MAX_CYCLE_COUNT :19
+        cycles += 1;
+        if (cur + 2 >= W) { error = true; continue; }  // :364-370
+        const int a = mem[cur], b = mem[cur + 1], c = mem[cur + 2];
+        // read_memory :187-232 (both reads see the pre-advance input state)
+        int ra = 0, rb = 0;
+        bool acc = false, err = false;
+        if (a <= AMAX) ra = mem[a];
+        else if (a == AIN) { if (in[0] >= W) err = true; else { ra = in[0]; acc = true; } }
+        if (b <= AMAX) rb = mem[b];
+        else if (b == AIN) { if (in[0] >= W) err = true; else { rb = in[0]; acc = true; } }
+        const int value = pymod(ra - rb, W);  // :322
+        // write_memory :243-295
+        bool modified = false;
+        if (a <= AMAX) mem[a] = static_cast<uint8_t>(value);
+        else if (a == AOUT) {
+            if (out_cursor >= 8) err = true;
+            else { out[out_cursor] = static_cast<uint16_t>(value); out_cursor += 1; modified = true; }
+        }
+        const bool jump = (value == 0) || (2 * value >= W);  // :329
+        cur = jump ? c : cur + 3;                            // :330
+        if (acc) {                                           // :333-338
+#pragma unroll
+            for (int i = 0; i < 7; ++i) in[i] = in[i + 1];
+            in[7] = static_cast<uint16_t>(W);
+        }
+        bool all_eq = true;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) all_eq = all_eq && (out[i] == tout[i]);
+        // :340-345 `(execute_jump & c > ADDRESS_MAX)` == `(execute_jump & c) > ADDRESS_MAX` (Python precedence): {0,1} > W-4
+        halt = (((jump ? 1 : 0) & c) > AMAX) || all_eq;
+        const int oc = (out_cursor - 1) & 7;  // -1 wraps to the last element (jnp negative index); masked by `modified`
+        error = err || (modified && (out[oc] != tout[oc]));  // :346-350
+    }
+    bool all_eq = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) all_eq = all_eq && (out[i] == tout[i]);
+    return !error && all_eq;
+}
+
+// subleq.py:26-56 / :63-98 encoders: byte (row-word v, column j) of the observation
+__device__ __forceinline__ uint8_t subleq_enc(const EnvDev& e, int v, int j) {
+    if (e.binary) {
+        if (j == e.obs_cols - 1) return static_cast<uint8_t>(v == e.W);               // :96
+        const unsigned m = static_cast<unsigned>(pymod(v, e.W)) & 0xFFu;              // :90
+        return j < 8 ? static_cast<uint8_t>((m >> j) & 1u) : static_cast<uint8_t>(0);  // :91
+    }
+    const int idx = v == e.W ? e.W : pymod(v, e.W);  // :52
+    return static_cast<uint8_t>(j == idx);
+}
+
+// subleq.py:679-707 _observe: rows = memory | example_input | input_after | example_output | output_after
+__device__ __forceinline__ int subleq_row_word(const EnvDev& e, const eaz_subleq_state* s, int row) {
+    const int W = e.W;
+    if (row < W) return s->memory[row];
+    const int r = row - W;
+    const int blk = r >> 3, i = r & 7;
+    return blk == 0 ? s->ex_in[i] : (blk == 1 ? s->ex_in_after[i] : (blk == 2 ? s->ex_out[i] : s->ex_out_after[i]));
+}
+
+// generic observation byte i of the flattened observation
+__device__ __forceinline__ uint8_t obs_byte(const EnvDev& e, const char* sp, int hot, int i) {
+    if (e.kind == EAZ_ENV_DEEPSEA) return static_cast<uint8_t>(i == hot);
+    const eaz_subleq_state* s = reinterpret_cast<const eaz_subleq_state*>(sp);
+    const int row = i / e.obs_cols, col = i - row * e.obs_cols;
+    return subleq_enc(e, subleq_row_word(e, s, row), col);
+}
+
+__device__ __forceinline__ bool state_is_done(const EnvDev& e, const char* sp) {
+    if (e.kind == EAZ_ENV_DEEPSEA) {
+        const eaz_deepsea_state* s = reinterpret_cast<const eaz_deepsea_state*>(sp);
+        return (s->terminated | s->truncated) != 0;
+    }
+    const eaz_subleq_state* s = reinterpret_cast<const eaz_subleq_state*>(sp);
+    return (s->terminated | s->truncated) != 0;
+}
+
+}  // namespace eaz

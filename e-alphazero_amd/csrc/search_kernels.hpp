@@ -1,0 +1,188 @@
+// search_kernels.hpp -- the kernels around the per-simulation tree kernel: tree instantiation, root preparation,
+// final action / action_weights, epistemic_summary, action choice of the self-play driver.
+//
+// Reference: mctx instantiate_tree_from_root / gumbel_muzero_policy tail / Tree.summary [EXT]
+// and src/selfplay.py:92-134.
+#pragma once
+#include "rng.hpp"
+#include "tree.hpp"
+
+namespace eaz {
+
+// mctx instantiate_tree_from_root (A.3): ints -1 / 0, floats 0.  Grid-stride over B*N*A.
+__global__ void __launch_bounds__(256) tree_clear_kernel(TreeDev t) {
+    const long bn = static_cast<long>(t.B) * t.N, bna = bn * t.A;
+    const long stride = static_cast<long>(gridDim.x) * blockDim.x;
+    for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < bna; i += stride) {
+        t.children_index[i] = -1;
+        t.children_visits[i] = 0;
+        t.children_prior_logits[i] = 0.0f;
+        t.children_values[i] = 0.0f;
+        t.children_rewards[i] = 0.0f;
+        t.children_discounts[i] = 0.0f;
+        t.children_var[i] = 0.0f;
+        t.children_reward_var[i] = 0.0f;
+        if (i < bn) {
+            t.node_visits[i] = 0;
+            t.parents[i] = -1;
+            t.action_from_parent[i] = -1;
+            t.raw_values[i] = 0.0f;
+            t.node_values[i] = 0.0f;
+            t.raw_var[i] = 0.0f;
+            t.node_var[i] = 0.0f;
+        }
+    }
+}
+
+// Root write: mask_invalid_actions(prior_logits) (A.2), update_tree_node(ROOT) (A.3), embedding[ROOT] = root state.
+template <int LPT, int APL>
+__global__ void __launch_bounds__(256) tree_root_kernel(TreeDev t, const float* prior_logits, const float* value,
+                                                        const float* value_var, const char* root_states, const float* beta,
+                                                        const uint8_t* invalid, const float* gumbel) {
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = gtid / LPT;
+    const bool live = b < t.B;
+    const Group<LPT, APL> g = make_group<LPT, APL>(live ? b : 0, gtid % LPT, t.A);
+    const int A = t.A;
+    const long nb = static_cast<long>(g.b) * t.N;
+    float lg[APL];
+    bool inv[APL];
+#pragma unroll
+    for (int j = 0; j < APL; ++j) {
+        const long o = static_cast<long>(g.b) * A + g.act[j];
+        lg[j] = g.ok[j] ? prior_logits[o] : 0.0f;
+        inv[j] = g.ok[j] && invalid && invalid[o];
+    }
+    const float m = g.vmax(lg);
+#pragma unroll
+    for (int j = 0; j < APL; ++j) {
+        if (!(live && g.ok[j])) continue;
+        const long o = static_cast<long>(g.b) * A + g.act[j];
+        t.children_prior_logits[nb * A + g.act[j]] = inv[j] ? kF32Min : lg[j] - m;
+        t.root_invalid[o] = inv[j] ? 1 : 0;
+        t.root_gumbel[o] = gumbel[o];
+    }
+    if (live && g.gl == 0) {
+        t.beta[g.b] = beta[g.b];
+        t.raw_values[nb] = value[g.b];
+        t.node_values[nb] = value[g.b];
+        t.raw_var[nb] = value_var[g.b];
+        t.node_var[nb] = value_var[g.b];
+        t.node_visits[nb] = 1;
+    }
+    // embedding copy: state_bytes is a multiple of 16
+    if (live) {
+        const uint4* src = reinterpret_cast<const uint4*>(root_states + static_cast<long>(g.b) * t.state_bytes);
+        uint4* dst = reinterpret_cast<uint4*>(t.embeddings + nb * t.state_bytes);
+        for (int i = g.gl; i < t.state_bytes / 16; i += LPT) dst[i] = src[i];
+    }
+}
+
+// Tail of gumbel_muzero_policy (A.2): action = masked_argmax(score_considered(max visit, ...)),
+// action_weights = softmax(mask(root_logits + completed_q)).
+template <int LPT, int APL>
+__global__ void __launch_bounds__(256) tree_finish_kernel(TreeDev t, int32_t* action_out, float* action_weights) {
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = gtid / LPT;
+    const bool live = b < t.B;
+    const Group<LPT, APL> g = make_group<LPT, APL>(live ? b : 0, gtid % LPT, t.A);
+    const int A = t.A;
+    const long nb = static_cast<long>(g.b) * t.N;
+    const float beta = t.beta[g.b];
+    NodeRows<APL> r;
+    load_rows<LPT, APL>(t, g, 0, beta != 0.0f, r);
+    float cq[APL];
+    qtransform<LPT, APL>(t, g, r, t.raw_values[nb], t.raw_var[nb], beta, cq);
+    int lmax = 0;
+#pragma unroll
+    for (int j = 0; j < APL; ++j) lmax = r.visits[j] > lmax ? r.visits[j] : lmax;
+    const int maxN = gmaxi<LPT>(lmax);
+    const int action = root_pick<LPT, APL>(t, g, r, cq, static_cast<float>(maxN));
+    float x[APL], p[APL];
+#pragma unroll
+    for (int j = 0; j < APL; ++j) x[j] = r.logits[j] + cq[j];
+    const float m = g.vmax(x);
+#pragma unroll
+    for (int j = 0; j < APL; ++j)
+        if (g.ok[j]) x[j] = t.root_invalid[static_cast<long>(g.b) * A + g.act[j]] ? kF32Min : x[j] - m;
+    g.softmax(x, p);
+    if (!live) return;
+    if (g.gl == 0 && action_out) action_out[g.b] = action;
+#pragma unroll
+    for (int j = 0; j < APL; ++j)
+        if (g.ok[j] && action_weights) action_weights[static_cast<long>(g.b) * A + g.act[j]] = p[j];
+}
+
+// emctx Tree.epistemic_summary() (A.7): one thread per (b, a); visit totals are exact small integers.
+__global__ void __launch_bounds__(256) tree_summary_kernel(TreeDev t, float* value, float* value_std, float* qvalues,
+                                                           float* qvalues_var, float* visit_counts, float* visit_probs) {
+    const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= static_cast<long>(t.B) * t.A) return;
+    const int b = static_cast<int>(i / t.A), a = static_cast<int>(i - static_cast<long>(b) * t.A);
+    const long nb = static_cast<long>(b) * t.N, o = nb * t.A;
+    if (a == 0) {
+        if (value) value[b] = t.node_values[nb];
+        if (value_std) value_std[b] = __builtin_sqrtf(t.node_var[nb]);
+    }
+    int tot = 0;
+    for (int k = 0; k < t.A; ++k) tot += t.children_visits[o + k];
+    const float d = t.children_discounts[o + a];
+    if (qvalues) qvalues[i] = t.children_rewards[o + a] + d * t.children_values[o + a];
+    if (qvalues_var) qvalues_var[i] = t.children_reward_var[o + a] + (d * d) * t.children_var[o + a];
+    const float vc = static_cast<float>(t.children_visits[o + a]);
+    const float ftot = static_cast<float>(tot);
+    if (visit_counts) visit_counts[i] = vc;
+    if (visit_probs) visit_probs[i] = tot > 0 ? vc / (ftot > 1.0f ? ftot : 1.0f) : 1.0f / static_cast<float>(t.A);
+}
+
+// Root preparation of selfplay's step_fn (src/selfplay.py:92-106,113): policy logits (uniform option), per-env beta
+// schedule beta * linspace(0, 1, B), invalid = ~legal_action_mask, root Gumbel noise (explicit or generated).
+__global__ void __launch_bounds__(256) root_prep_kernel(int B, int A, const float* logits_in, int uniform_policy, float sbeta,
+                                                        const uint8_t* legal, const float* gumbel_in, Key gkey,
+                                                        float gumbel_scale, float* logits_out, float* beta, uint8_t* invalid,
+                                                        float* gumbel_out) {
+    const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= static_cast<long>(B) * A) return;
+    const int b = static_cast<int>(i / A);
+    logits_out[i] = uniform_policy ? 1.0f : logits_in[i];                                   // :96-98
+    invalid[i] = legal ? (legal[i] ? 0 : 1) : 0;                                            // :113
+    const float g = gumbel_in ? gumbel_in[i] : gumbel(gkey, static_cast<uint32_t>(i));
+    gumbel_out[i] = gumbel_scale * g;
+    if (i == static_cast<long>(b) * A)
+        beta[b] = sbeta * (B > 1 ? static_cast<float>(b) / static_cast<float>(B - 1) : 0.0f);  // :105
+}
+
+// Action choice (src/selfplay.py:118-134): search action, or categorical over visit PROBABILITIES / action weights
+// used as logits (reproduced literally), categorical(key, logits) = argmax(logits + Gumbel).
+__global__ void __launch_bounds__(256) choose_action_kernel(int B, int A, int32_t* action, const float* visit_probs,
+                                                            const float* action_weights, int sample_actions,
+                                                            int sample_improved, Key kvis, Key kimp) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int act = action[b];
+    if (sample_actions) {
+        float best = -kInf; int bi = 0;
+        for (int a = 0; a < A; ++a) {
+            const float v = visit_probs[static_cast<long>(b) * A + a] + gumbel(kvis, static_cast<uint32_t>(b * A + a));
+            if (v > best) { best = v; bi = a; }
+        }
+        act = bi;
+    }
+    if (sample_improved) {
+        float best = -kInf; int bi = 0;
+        for (int a = 0; a < A; ++a) {
+            const float v = action_weights[static_cast<long>(b) * A + a] + gumbel(kimp, static_cast<uint32_t>(b * A + a));
+            if (v > best) { best = v; bi = a; }
+        }
+        act = bi;
+    }
+    action[b] = act;
+}
+
+// uniformrandomplay's actions (src/selfplay.py:160): randint(0, num_actions)
+__global__ void __launch_bounds__(256) random_action_kernel(int B, int A, Key k, int32_t* action) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) action[b] = static_cast<int32_t>(rbits(k, static_cast<uint32_t>(b)) % static_cast<uint32_t>(A));
+}
+
+}  // namespace eaz

@@ -1,0 +1,398 @@
+// tree.hpp -- Gumbel-MuZero search tree with epistemic fields: device layout and the per-simulation tree kernel.
+//
+// Reference: emctx [EXT] (fork of google-deepmind/mctx, un-vendored) as called from
+// src/selfplay.py:100-121, with the recurrent fn of src/context.py:117-155 applied in the expand step.
+//
+// Execution model: a group of LPT (2..64, power of two) consecutive lanes of one wavefront walks ONE tree; each lane
+// owns APL consecutive actions (LPT*APL >= A).  Small action sets therefore pack 64/LPT trees per wavefront
+// (DeepSea: 32 trees per wave); A = 256 uses a full wave with 4 actions per lane.  All per-node vectors
+// ([A]-sized rows of the [B,N,A] arrays) are read coalesced by the group; float reductions use the fixed
+// butterfly order (lane ^ 1, ^ 2, ...) that the CPU oracle mirrors, so selections are bit-reproducible.
+#pragma once
+#include "dmath.hpp"
+
+namespace eaz {
+
+struct TreeDev {
+    int B, N, A, S;
+    int32_t *node_visits, *parents, *action_from_parent;                                     // [B,N]
+    float *raw_values, *node_values, *raw_var, *node_var;                                    // [B,N]
+    int32_t *children_index, *children_visits;                                               // [B,N,A]
+    float *children_prior_logits, *children_values, *children_rewards, *children_discounts;  // [B,N,A]
+    float *children_var, *children_reward_var;                                               // [B,N,A]
+    float* beta;            // [B]
+    uint8_t* root_invalid;  // [B,A]
+    float* root_gumbel;     // [B,A]
+    char* embeddings;       // [B,N,state_bytes]
+    int state_bytes;
+    int32_t *sim_parent, *sim_action, *sim_next;  // [B] result of the last select
+    const int32_t* table;                         // [(max_considered+1), S]
+    // outputs of a caller-evaluated recurrent fn for the simulation being expanded (generic path, fused_rf == 0)
+    const float *rf_reward, *rf_reward_var, *rf_discount, *rf_logits, *rf_value, *rf_value_var;  // [B], [B,A]
+    // fused native recurrent fn (src/context.py:117-155): raw network outputs + fields of the stepped state
+    int fused_rf;
+    const float *net_logits, *net_value, *net_ube;  // [B,A] (head chosen by `exploration`), [B], [B]
+    const float* next_reward;                        // [B]   rewards[b, current_player]   context.py:139
+    const uint8_t* next_term;                        // [B]   state.terminated             context.py:140-144
+    const uint8_t* next_legal;                       // [B,A] state.legal_action_mask      context.py:137
+    float discount;
+    int two_player;
+    // options
+    int rescale, use_mixed, max_considered, max_depth;
+    float value_scale, maxvisit_init;
+};
+
+// ---- group reductions ---------------------------------------------------------------------------------------
+template <int LPT>
+__device__ __forceinline__ float gsum(float v) {
+#pragma unroll
+    for (int s = 1; s < LPT; s <<= 1) v = v + __shfl_xor(v, s);
+    return v;
+}
+template <int LPT>
+__device__ __forceinline__ int gsumi(int v) {
+#pragma unroll
+    for (int s = 1; s < LPT; s <<= 1) v = v + __shfl_xor(v, s);
+    return v;
+}
+template <int LPT>
+__device__ __forceinline__ float gmax(float v) {
+#pragma unroll
+    for (int s = 1; s < LPT; s <<= 1) { const float o = __shfl_xor(v, s); v = o > v ? o : v; }
+    return v;
+}
+template <int LPT>
+__device__ __forceinline__ float gmin(float v) {
+#pragma unroll
+    for (int s = 1; s < LPT; s <<= 1) { const float o = __shfl_xor(v, s); v = o < v ? o : v; }
+    return v;
+}
+template <int LPT>
+__device__ __forceinline__ int gmaxi(int v) {
+#pragma unroll
+    for (int s = 1; s < LPT; s <<= 1) { const int o = __shfl_xor(v, s); v = o > v ? o : v; }
+    return v;
+}
+// argmax with ties -> lowest index (jnp.argmax)
+template <int LPT>
+__device__ __forceinline__ int gargmax(float v, int i) {
+#pragma unroll
+    for (int s = 1; s < LPT; s <<= 1) {
+        const float ov = __shfl_xor(v, s);
+        const int oi = __shfl_xor(i, s);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+    return i;
+}
+// in-lane pairwise sum of APL slots (levels below the cross-lane butterfly)
+template <int APL>
+__device__ __forceinline__ float lsum(const float (&x)[APL]) {
+    if constexpr (APL == 1) return x[0];
+    else if constexpr (APL == 2) return x[0] + x[1];
+    else return (x[0] + x[1]) + (x[2] + x[3]);
+}
+
+template <int LPT, int APL>
+struct Group {
+    int b;      // tree index
+    int gl;     // lane within the group
+    int A;
+    bool ok[APL];  // slot holds a real action
+    int act[APL];
+
+    __device__ __forceinline__ float sum(const float (&x)[APL]) const { return gsum<LPT>(lsum<APL>(x)); }
+    __device__ __forceinline__ float vmax(const float (&x)[APL]) const {
+        float m = -kInf;
+#pragma unroll
+        for (int j = 0; j < APL; ++j) if (ok[j]) m = x[j] > m ? x[j] : m;
+        return gmax<LPT>(m);
+    }
+    __device__ __forceinline__ float vmin(const float (&x)[APL]) const {
+        float m = kInf;
+#pragma unroll
+        for (int j = 0; j < APL; ++j) if (ok[j]) m = x[j] < m ? x[j] : m;
+        return gmin<LPT>(m);
+    }
+    __device__ __forceinline__ int argmax(const float (&x)[APL]) const {
+        float bv = -kInf;
+        int bi = 0x7FFFFFFF;
+#pragma unroll
+        for (int j = 0; j < APL; ++j)
+            if (ok[j] && (bi == 0x7FFFFFFF || x[j] > bv)) { bv = x[j]; bi = act[j]; }
+        if (bi == 0x7FFFFFFF) bv = -kInf;
+        // an all -inf row must return 0: a lane without real actions keeps index INT_MAX and value -inf
+        return gargmax<LPT>(bv, bi);
+    }
+    // jax.nn.softmax over the real actions
+    __device__ __forceinline__ void softmax(const float (&x)[APL], float (&p)[APL]) const {
+        const float m = vmax(x);
+        float e[APL];
+#pragma unroll
+        for (int j = 0; j < APL; ++j) e[j] = ok[j] ? det_exp(x[j] - m) : 0.0f;
+        const float s = sum(e);
+#pragma unroll
+        for (int j = 0; j < APL; ++j) p[j] = e[j] / s;
+    }
+};
+
+// mctx qtransforms._compute_mixed_value [EXT] (A.5)
+template <int LPT, int APL>
+__device__ __forceinline__ float mixed_value(const Group<LPT, APL>& g, float raw, const float (&q)[APL],
+                                             const int (&visits)[APL], const float (&probs)[APL], int sumN) {
+    float t0[APL], t1[APL], p2[APL];
+#pragma unroll
+    for (int j = 0; j < APL; ++j) {
+        p2[j] = probs[j] > kF32Tiny ? probs[j] : kF32Tiny;
+        t0[j] = (g.ok[j] && visits[j] > 0) ? p2[j] : 0.0f;
+    }
+    const float sum_probs = g.sum(t0);
+#pragma unroll
+    for (int j = 0; j < APL; ++j) t1[j] = (g.ok[j] && visits[j] > 0) ? (p2[j] * q[j]) / sum_probs : 0.0f;
+    const float wq = g.sum(t1);
+    return (raw + static_cast<float>(sumN) * wq) / (static_cast<float>(sumN) + 1.0f);
+}
+
+// per-node child rows held by a group
+template <int APL>
+struct NodeRows {
+    float logits[APL], values[APL], rewards[APL], discounts[APL], var[APL], rvar[APL];
+    int visits[APL];
+};
+
+template <int LPT, int APL>
+__device__ __forceinline__ void load_rows(const TreeDev& t, const Group<LPT, APL>& g, int node, bool need_var,
+                                          NodeRows<APL>& r) {
+    const long base = (static_cast<long>(g.b) * t.N + node) * t.A;
+#pragma unroll
+    for (int j = 0; j < APL; ++j) {
+        if (g.ok[j]) {
+            const long o = base + g.act[j];
+            r.logits[j] = t.children_prior_logits[o];
+            r.values[j] = t.children_values[o];
+            r.rewards[j] = t.children_rewards[o];
+            r.discounts[j] = t.children_discounts[o];
+            r.visits[j] = t.children_visits[o];
+            r.var[j] = need_var ? t.children_var[o] : 0.0f;
+            r.rvar[j] = need_var ? t.children_reward_var[o] : 0.0f;
+        } else {
+            r.logits[j] = 0.0f; r.values[j] = 0.0f; r.rewards[j] = 0.0f; r.discounts[j] = 0.0f;
+            r.visits[j] = 0; r.var[j] = 0.0f; r.rvar[j] = 0.0f;
+        }
+    }
+}
+
+// emctx epistemic_qtransform_completed_by_mix_value [EXT] (selfplay.py:114-116; A.5).  beta == 0 -> plain mctx.
+template <int LPT, int APL>
+__device__ __forceinline__ void qtransform(const TreeDev& t, const Group<LPT, APL>& g, const NodeRows<APL>& r,
+                                           float raw_value, float raw_var, float beta, float (&out)[APL]) {
+    float q[APL], probs[APL];
+#pragma unroll
+    for (int j = 0; j < APL; ++j) q[j] = r.rewards[j] + r.discounts[j] * r.values[j];
+    g.softmax(r.logits, probs);
+    int ln = 0, lmax = 0;
+#pragma unroll
+    for (int j = 0; j < APL; ++j) { ln += r.visits[j]; lmax = r.visits[j] > lmax ? r.visits[j] : lmax; }
+    const int sumN = gsumi<LPT>(ln);
+    const int maxN = gmaxi<LPT>(lmax);
+    float value = raw_value;
+    if (t.use_mixed) value = mixed_value<LPT, APL>(g, raw_value, q, r.visits, probs, sumN);
+#pragma unroll
+    for (int j = 0; j < APL; ++j) out[j] = r.visits[j] > 0 ? q[j] : value;
+    if (beta != 0.0f) {  // x + 0*sqrt(v) == x for finite v >= 0, so the twin is only evaluated when it matters
+        float qv[APL];
+#pragma unroll
+        for (int j = 0; j < APL; ++j) qv[j] = r.rvar[j] + (r.discounts[j] * r.discounts[j]) * r.var[j];
+        float vvar = raw_var;
+        if (t.use_mixed) vvar = mixed_value<LPT, APL>(g, raw_var, qv, r.visits, probs, sumN);
+#pragma unroll
+        for (int j = 0; j < APL; ++j) {
+            const float cvar = r.visits[j] > 0 ? qv[j] : vvar;
+            out[j] = out[j] + beta * __builtin_sqrtf(cvar);
+        }
+    }
+    if (t.rescale) {
+        const float mn = g.vmin(out), mx = g.vmax(out);
+        float den = mx - mn;
+        den = den > 1e-8f ? den : 1e-8f;
+#pragma unroll
+        for (int j = 0; j < APL; ++j) out[j] = (out[j] - mn) / den;
+    }
+    const float scale = (t.maxvisit_init + static_cast<float>(maxN)) * t.value_scale;
+#pragma unroll
+    for (int j = 0; j < APL; ++j) out[j] = scale * out[j];
+}
+
+// mctx seq_halving.score_considered + masked_argmax [EXT] (A.2)
+template <int LPT, int APL>
+__device__ __forceinline__ int root_pick(const TreeDev& t, const Group<LPT, APL>& g, const NodeRows<APL>& r,
+                                         const float (&cq)[APL], float considered_visit) {
+    const float m = g.vmax(r.logits);
+    float sc[APL];
+#pragma unroll
+    for (int j = 0; j < APL; ++j) {
+        if (g.ok[j]) {
+            const long o = static_cast<long>(g.b) * t.A + g.act[j];
+            float s = (t.root_gumbel[o] + (r.logits[j] - m)) + cq[j];
+            s = s > -1e9f ? s : -1e9f;
+            s = s + (static_cast<float>(r.visits[j]) == considered_visit ? 0.0f : -kInf);
+            sc[j] = t.root_invalid[o] ? -kInf : s;
+        } else {
+            sc[j] = -kInf;
+        }
+    }
+    return g.argmax(sc);
+}
+
+template <int LPT, int APL>
+__device__ __forceinline__ Group<LPT, APL> make_group(int b, int gl, int A) {
+    Group<LPT, APL> g;
+    g.b = b; g.gl = gl; g.A = A;
+#pragma unroll
+    for (int j = 0; j < APL; ++j) { g.act[j] = gl * APL + j; g.ok[j] = g.act[j] < A; }
+    return g;
+}
+
+enum : int { kTreeExpand = 1, kTreeSelect = 2 };
+
+// One launch per simulation: [expand + backward of simulation sim-1] then [select of simulation sim].
+template <int LPT, int APL>
+__global__ void __launch_bounds__(256) tree_step_kernel(TreeDev t, int sim, int mode) {
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = gtid / LPT;
+    const bool live = b < t.B;  // dead groups keep executing (shuffles need every lane) on tree 0 without storing
+    const Group<LPT, APL> g = make_group<LPT, APL>(live ? b : 0, gtid % LPT, t.A);
+    const int N = t.N, A = t.A;
+    const long nb = static_cast<long>(g.b) * N;
+    const float beta = t.beta[g.b];
+    const bool lead = live && g.gl == 0;
+
+    if (mode & kTreeExpand) {
+        // ---- expand: mctx update_tree_node + topology (A.3) -------------------------------------------------
+        const int parent = t.sim_parent[g.b], action = t.sim_action[g.b], nxt = t.sim_next[g.b];
+        float value, var, reward, rvar, disc, lg[APL];
+        if (t.fused_rf) {
+            // epistemic_recurrent_fn, src/context.py:132-153, on the outputs of the leaf-gather and network kernels
+#pragma unroll
+            for (int j = 0; j < APL; ++j) lg[j] = g.ok[j] ? t.net_logits[static_cast<long>(g.b) * A + g.act[j]] : 0.0f;
+            const float m = g.vmax(lg);                                                        // :135
+#pragma unroll
+            for (int j = 0; j < APL; ++j)
+                if (g.ok[j]) lg[j] = t.next_legal[static_cast<long>(g.b) * A + g.act[j]] ? lg[j] - m : kF32Min;  // :137
+            const bool term = t.next_term[g.b] != 0;
+            reward = t.next_reward[g.b];                                                       // :139
+            value = term ? 0.0f : t.net_value[g.b];                                            // :140
+            var = term ? 0.0f : t.net_ube[g.b];                                                // :141
+            disc = 1.0f * t.discount;                                                          // :142
+            if (t.two_player) disc = disc * -1.0f;                                             // :143
+            if (term) disc = 0.0f;                                                             // :144
+            rvar = 0.0f;                                                                       // :149
+        } else {
+            value = t.rf_value[g.b]; var = t.rf_value_var[g.b];
+            reward = t.rf_reward[g.b]; rvar = t.rf_reward_var[g.b]; disc = t.rf_discount[g.b];
+#pragma unroll
+            for (int j = 0; j < APL; ++j) lg[j] = g.ok[j] ? t.rf_logits[static_cast<long>(g.b) * A + g.act[j]] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < APL; ++j)
+            if (live && g.ok[j]) t.children_prior_logits[(nb + nxt) * A + g.act[j]] = lg[j];
+        const long ca0 = (nb + parent) * A + action;
+        if (lead) {
+            t.raw_values[nb + nxt] = value;
+            t.raw_var[nb + nxt] = var;
+            t.node_visits[nb + nxt] += 1;
+            t.children_index[ca0] = nxt;
+            t.children_rewards[ca0] = reward;
+            t.children_reward_var[ca0] = rvar;
+            t.children_discounts[ca0] = disc;
+            t.parents[nb + nxt] = parent;
+            t.action_from_parent[nb + nxt] = action;
+        }
+        // ---- backward (A.6): values carried in registers, every lane computes, the lead lane stores ----------
+        float G = value, U = var;            // leaf_value / leaf variance
+        float child_value = value, child_var = var;  // node_values[idx] after its own update
+        int idx = nxt, p = parent, a = action;
+        float r = reward, rv = rvar, d = disc;
+        if (lead) { t.node_values[nb + nxt] = value; t.node_var[nb + nxt] = var; }
+        while (true) {
+            const long ca = (nb + p) * A + a;
+            const int cnt_i = t.node_visits[nb + p];
+            const float cnt = static_cast<float>(cnt_i);
+            G = r + d * G;
+            U = rv + (d * d) * U;
+            const float pv = (t.node_values[nb + p] * cnt + G) / (cnt + 1.0f);
+            const float pvar = (t.node_var[nb + p] * cnt + U) / (cnt + 1.0f);
+            const int cvis = t.children_visits[ca];
+            // the reads above must complete before the lead lane's stores below (same addresses, other lanes)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            if (lead) {
+                t.node_values[nb + p] = pv;
+                t.node_var[nb + p] = pvar;
+                t.node_visits[nb + p] = cnt_i + 1;
+                t.children_values[ca] = child_value;
+                t.children_var[ca] = child_var;
+                t.children_visits[ca] = cvis + 1;
+            }
+            child_value = pv;
+            child_var = pvar;
+            idx = p;
+            if (idx == 0) break;
+            p = t.parents[nb + idx];
+            a = t.action_from_parent[nb + idx];
+            const long cb = (nb + p) * A + a;
+            r = t.children_rewards[cb];
+            rv = t.children_reward_var[cb];
+            d = t.children_discounts[cb];
+        }
+        // make the lead lane's stores visible to the other lanes of the group before select re-reads the rows
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+
+    if (mode & kTreeSelect) {
+        // ---- simulate (A.4) ----------------------------------------------------------------------------------
+        int node = 0, depth = 0, action = 0, nxt = 0;
+        const bool need_var = beta != 0.0f;
+        while (true) {
+            NodeRows<APL> r;
+            load_rows<LPT, APL>(t, g, node, need_var, r);
+            float cq[APL];
+            qtransform<LPT, APL>(t, g, r, t.raw_values[nb + node], need_var ? t.raw_var[nb + node] : 0.0f, beta, cq);
+            if (depth == 0) {
+                // gumbel_muzero_root_action_selection
+                int lvalid = 0, lsumN = 0;
+#pragma unroll
+                for (int j = 0; j < APL; ++j)
+                    if (g.ok[j]) { lvalid += 1 - static_cast<int>(t.root_invalid[static_cast<long>(g.b) * A + g.act[j]]); lsumN += r.visits[j]; }
+                const int nvalid = gsumi<LPT>(lvalid);
+                int simidx = gsumi<LPT>(lsumN);
+                const int nc = nvalid < t.max_considered ? nvalid : t.max_considered;
+                simidx = simidx > t.S - 1 ? t.S - 1 : simidx;
+                const float cvis = static_cast<float>(t.table[static_cast<long>(nc) * t.S + simidx]);
+                action = root_pick<LPT, APL>(t, g, r, cq, cvis);
+            } else {
+                // gumbel_muzero_interior_action_selection
+                float x[APL], pr[APL];
+                int lsumN = 0;
+#pragma unroll
+                for (int j = 0; j < APL; ++j) { x[j] = r.logits[j] + cq[j]; lsumN += r.visits[j]; }
+                const int sumN = gsumi<LPT>(lsumN);
+                g.softmax(x, pr);
+                const float den = static_cast<float>(1 + sumN);
+#pragma unroll
+                for (int j = 0; j < APL; ++j) x[j] = pr[j] - static_cast<float>(r.visits[j]) / den;
+                action = g.argmax(x);
+            }
+            nxt = t.children_index[(nb + node) * A + action];
+            depth += 1;
+            // group-uniform exit: every lane of the group computed the same action / nxt
+            if (nxt == -1 || depth >= t.max_depth) break;
+            node = nxt;
+        }
+        if (lead) {
+            t.sim_parent[g.b] = node;
+            t.sim_action[g.b] = action;
+            t.sim_next[g.b] = nxt == -1 ? sim + 1 : nxt;
+        }
+    }
+}
+
+}  // namespace eaz

@@ -1,0 +1,329 @@
+"""Thin object layer over libeaz.so: device context, environments, FC network, search, self-play.
+
+PyTorch (ROCm) is used for device memory and streams only; every computation below is a HIP kernel of libeaz.so
+reached through the C ABI of include/eaz.h.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import EazError, SearchOpts, SelfplayCfg, check
+from .params import fc_weight_list, HASH_MODULE
+
+_contexts: dict[int, "Context"] = {}
+
+TREE_FIELDS = {
+    "node_visits": (0, torch.int32), "raw_values": (1, torch.float32), "node_values": (2, torch.float32),
+    "parents": (3, torch.int32), "action_from_parent": (4, torch.int32), "children_index": (5, torch.int32),
+    "children_prior_logits": (6, torch.float32), "children_values": (7, torch.float32),
+    "children_visits": (8, torch.int32), "children_rewards": (9, torch.float32),
+    "children_discounts": (10, torch.float32), "raw_values_epistemic_variance": (11, torch.float32),
+    "node_values_epistemic_variance": (12, torch.float32), "children_values_epistemic_variance": (13, torch.float32),
+    "children_rewards_epistemic_variance": (14, torch.float32), "embeddings": (15, torch.uint8),
+    "root_gumbel": (16, torch.float32), "beta": (17, torch.float32),
+}
+
+
+def _stream() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "libeaz needs contiguous device tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def as_key(key) -> int:
+    """Keys are 64-bit integers; (k0, k1) pairs and 2-element arrays are accepted."""
+    if isinstance(key, (tuple, list, np.ndarray)) or (isinstance(key, torch.Tensor) and key.numel() == 2):
+        k = [int(x) for x in (key.tolist() if hasattr(key, "tolist") else key)]
+        return (k[0] & 0xFFFFFFFF) | ((k[1] & 0xFFFFFFFF) << 32)
+    return int(key) & 0xFFFFFFFFFFFFFFFF
+
+
+def key_pair(key) -> tuple[int, int]:
+    k = as_key(key)
+    return k & 0xFFFFFFFF, k >> 32
+
+
+def fold(key, tag: int) -> int:
+    out = C.c_uint64()
+    check(_lib.load().eaz_key_fold(as_key(key), tag & 0xFFFFFFFF, C.byref(out)))
+    return int(out.value)
+
+
+class Context:
+    """One per device (eaz_ctx)."""
+
+    def __init__(self, device: int):
+        if not torch.cuda.is_available():
+            raise EazError("no ROCm device visible: the engine has no CPU fallback")
+        self.device = device
+        self.torch_device = torch.device("cuda", device)
+        h = C.c_void_p()
+        check(_lib.load().eaz_ctx_create(device, C.byref(h)))
+        self.h = h
+
+    @staticmethod
+    def get(device: Optional[int] = None) -> "Context":
+        device = torch.cuda.current_device() if device is None else device
+        if device not in _contexts:
+            _contexts[device] = Context(device)
+        return _contexts[device]
+
+
+class EnvHandle:
+    """eaz_env + batched operations on compact state blobs (uint8 [B, state_bytes] device tensors)."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx, self.h = ctx, handle
+        v = [C.c_int() for _ in range(5)]
+        check(_lib.load().eaz_env_info(handle, *[C.byref(x) for x in v]))
+        self.kind, self.num_actions, rows, cols, self.state_bytes = [x.value for x in v]
+        self.obs_shape = (rows, cols)
+        self.obs_dim = rows * cols
+
+    @classmethod
+    def deepsea(cls, size_of_grid: int, action_map: Optional[np.ndarray] = None, device=None):
+        ctx = Context.get(device)
+        am = None if action_map is None else np.ascontiguousarray(action_map, np.uint8).reshape(-1)
+        assert am is None or am.size == size_of_grid * size_of_grid
+        h = C.c_void_p()
+        check(_lib.load().eaz_env_create_deepsea(ctx.h, size_of_grid, None if am is None else am.ctypes.data_as(C.c_void_p), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def subleq(cls, word_size: int, tasks: Sequence[int], use_binary_encoding: bool, device=None):
+        ctx = Context.get(device)
+        t = np.ascontiguousarray(tasks, np.int32)
+        h = C.c_void_p()
+        check(_lib.load().eaz_env_create_subleq(ctx.h, word_size, t.ctypes.data_as(C.c_void_p), len(t), int(use_binary_encoding), C.byref(h)))
+        return cls(ctx, h)
+
+    def new_states(self, *lead) -> torch.Tensor:
+        return torch.zeros(*lead, self.state_bytes, dtype=torch.uint8, device=self.ctx.torch_device)
+
+    def init(self, B: int, key=0) -> torch.Tensor:
+        s = self.new_states(B)
+        check(_lib.load().eaz_env_init(self.h, B, as_key(key), _ptr(s), _stream()))
+        return s
+
+    def step(self, states: torch.Tensor, action: torch.Tensor, key=0, autoreset: bool = False) -> torch.Tensor:
+        B = states.shape[0]
+        out = torch.empty_like(states)
+        a = action.to(torch.int32).contiguous()
+        check(_lib.load().eaz_env_step(self.h, B, _ptr(states), _ptr(a), as_key(key), int(autoreset), _ptr(out), _stream()))
+        return out
+
+    def observe(self, states: torch.Tensor) -> torch.Tensor:
+        flat = states.reshape(-1, self.state_bytes)
+        obs = torch.empty(flat.shape[0], self.obs_dim, dtype=torch.uint8, device=states.device)
+        check(_lib.load().eaz_env_observe(self.h, flat.shape[0], _ptr(flat), _ptr(obs), _stream()))
+        return obs.reshape(*states.shape[:-1], self.obs_dim)
+
+    def fields(self, states: torch.Tensor) -> dict:
+        flat = states.reshape(-1, self.state_bytes)
+        n, dev = flat.shape[0], states.device
+        term = torch.empty(n, dtype=torch.uint8, device=dev)
+        trunc = torch.empty(n, dtype=torch.uint8, device=dev)
+        rew = torch.empty(n, dtype=torch.float32, device=dev)
+        sc = torch.empty(n, dtype=torch.int32, device=dev)
+        legal = torch.empty(n, self.num_actions, dtype=torch.uint8, device=dev)
+        check(_lib.load().eaz_env_fields(self.h, n, _ptr(flat), _ptr(term), _ptr(trunc), _ptr(rew), _ptr(sc), _ptr(legal), _stream()))
+        lead = states.shape[:-1]
+        return dict(terminated=term.bool().reshape(lead), truncated=trunc.bool().reshape(lead), rewards=rew.reshape(*lead, 1),
+                    step_count=sc.reshape(lead), legal_action_mask=legal.bool().reshape(*lead, self.num_actions))
+
+    def random_play(self, B: int, T: int, key=0, want_traj: bool = False):
+        states = self.new_states(B)
+        traj = self.new_states(T, B) if want_traj else None
+        check(_lib.load().eaz_random_play(self.h, B, T, as_key(key), _ptr(states), _ptr(traj), _stream()))
+        return states, traj
+
+
+class FCNet:
+    """eaz_net for EpistemicFullyConnectedAZNet (src/network/fully_connected.py)."""
+
+    def __init__(self, ctx: Context, in_dim: int, hidden: int, num_actions: int, params, state=None, max_ube: float = 1.0,
+                 max_epistemic_variance_reward: float = 1.0, hash_off: int = 0, hash_len: Optional[int] = None, hash_bits: int = 24):
+        self.ctx, self.in_dim, self.hidden, self.num_actions = ctx, in_dim, hidden, num_actions
+        self.hash_bits = hash_bits
+        hash_len = in_dim - hash_off if hash_len is None else hash_len
+        wl = fc_weight_list(params)
+        self._keep = wl
+        wp = (C.c_void_p * 12)(*[w.ctypes.data for w, _ in wl])
+        bp = (C.c_void_p * 12)(*[b.ctypes.data for _, b in wl])
+        h = C.c_void_p()
+        check(_lib.load().eaz_net_create_fc(ctx.h, in_dim, hidden, num_actions, wp, bp, max_ube, max_epistemic_variance_reward,
+                                            hash_off, hash_len, hash_bits, C.byref(h)))
+        self.h = h
+        if state is not None:
+            self.set_state(state)
+
+    def set_params(self, params):
+        wl = fc_weight_list(params)
+        self._keep = wl
+        wp = (C.c_void_p * 12)(*[w.ctypes.data for w, _ in wl])
+        bp = (C.c_void_p * 12)(*[b.ctypes.data for _, b in wl])
+        check(_lib.load().eaz_net_set_weights(self.h, wp, bp, _stream()))
+        torch.cuda.current_stream().synchronize()
+
+    def set_state(self, state):
+        bs = np.ascontiguousarray(state[HASH_MODULE]["binary_set"], np.uint8)
+        assert bs.size == 1 << (self.hash_bits - 3)
+        check(_lib.load().eaz_net_set_bitset(self.h, bs.ctypes.data_as(C.c_void_p), _stream()))
+        torch.cuda.current_stream().synchronize()
+
+    def get_state(self):
+        bs = np.empty(1 << (self.hash_bits - 3), np.uint8)
+        check(_lib.load().eaz_net_get_bitset(self.h, bs.ctypes.data_as(C.c_void_p), _stream()))
+        return {HASH_MODULE: {"binary_set": bs}}
+
+    def forward(self, obs: torch.Tensor):
+        """-> (exploitation_logits, exploration_logits, value, value_epistemic_variance, reward_epistemic_variance)"""
+        o = obs.reshape(-1, self.in_dim)
+        if o.dtype != torch.uint8:
+            o = o.to(torch.uint8)
+        o = o.contiguous()
+        B, dev, A = o.shape[0], o.device, self.num_actions
+        ex = torch.empty(B, A, dtype=torch.float32, device=dev)
+        xp = torch.empty(B, A, dtype=torch.float32, device=dev)
+        v = torch.empty(B, dtype=torch.float32, device=dev)
+        u = torch.empty(B, dtype=torch.float32, device=dev)
+        nov = torch.empty(B, dtype=torch.float32, device=dev)
+        check(_lib.load().eaz_net_forward(self.h, B, _ptr(o), _ptr(ex), _ptr(xp), _ptr(v), _ptr(u), _ptr(nov), _stream()))
+        return ex, xp, v, u, nov
+
+    def hash_lookup(self, obs: torch.Tensor):
+        o = obs.reshape(-1, self.in_dim).to(torch.uint8).contiguous()
+        seen = torch.empty(o.shape[0], dtype=torch.uint8, device=o.device)
+        idx = torch.empty(o.shape[0], dtype=torch.int32, device=o.device)
+        check(_lib.load().eaz_hash_lookup(self.h, o.shape[0], _ptr(o), _ptr(seen), _ptr(idx), _stream()))
+        return seen.bool(), idx
+
+    def hash_update(self, obs: torch.Tensor):
+        o = obs.reshape(-1, self.in_dim).to(torch.uint8).contiguous()
+        check(_lib.load().eaz_hash_update(self.h, o.shape[0], _ptr(o), _stream()))
+
+
+class Search:
+    """eaz_search: Gumbel-MuZero search with epistemic fields over B trees of num_simulations + 1 nodes."""
+
+    def __init__(self, env: EnvHandle, net: FCNet, B: int, num_simulations: int, discount: float = 0.997,
+                 two_players_game: bool = False, exploration: bool = False, rescale_values: bool = True,
+                 use_mixed_value: bool = True, value_scale: float = 0.1, maxvisit_init: float = 50.0,
+                 max_num_considered_actions: int = 16, gumbel_scale: float = 1.0, max_depth: Optional[int] = None):
+        self.env, self.net, self.B, self.S, self.N, self.A = env, net, B, num_simulations, num_simulations + 1, env.num_actions
+        self.opts = SearchOpts(num_simulations, max_depth or 0, max_num_considered_actions, gumbel_scale, int(rescale_values),
+                               int(use_mixed_value), value_scale, maxvisit_init, discount, int(two_players_game), int(exploration))
+        h = C.c_void_p()
+        check(_lib.load().eaz_search_create(env.ctx.h, env.h, net.h, B, C.byref(self.opts), C.byref(h)))
+        self.h = h
+        self.device = env.ctx.torch_device
+
+    def __del__(self):
+        try:
+            _lib.load().eaz_search_destroy(self.h)
+        except Exception:
+            pass
+
+    # -- step-wise API ------------------------------------------------------------------------------------------
+    def begin(self, prior_logits, value, value_var, root_states, beta, invalid, gumbel):
+        f = lambda t: t.to(torch.float32).contiguous()
+        self._keep = [f(prior_logits), f(value), f(value_var), root_states.contiguous(), f(beta),
+                      None if invalid is None else invalid.to(torch.uint8).contiguous(), f(gumbel)]
+        k = self._keep
+        check(_lib.load().eaz_search_begin(self.h, _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(k[3]), _ptr(k[4]), _ptr(k[5]), _ptr(k[6]), _stream()))
+
+    def simulate(self, sim: int):
+        check(_lib.load().eaz_search_simulate(self.h, sim, _stream()))
+
+    def run(self):
+        check(_lib.load().eaz_search_run(self.h, _stream()))
+
+    def finish(self):
+        act = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        aw = torch.empty(self.B, self.A, dtype=torch.float32, device=self.device)
+        check(_lib.load().eaz_search_finish(self.h, _ptr(act), _ptr(aw), _stream()))
+        return act, aw
+
+    def summary(self) -> dict:
+        B, A, dev = self.B, self.A, self.device
+        o = dict(value=torch.empty(B, device=dev), value_epistemic_std=torch.empty(B, device=dev),
+                 qvalues=torch.empty(B, A, device=dev), qvalues_epistemic_variance=torch.empty(B, A, device=dev),
+                 visit_counts=torch.empty(B, A, device=dev), visit_probs=torch.empty(B, A, device=dev))
+        check(_lib.load().eaz_search_summary(self.h, _ptr(o["value"]), _ptr(o["value_epistemic_std"]), _ptr(o["qvalues"]),
+                                             _ptr(o["qvalues_epistemic_variance"]), _ptr(o["visit_counts"]), _ptr(o["visit_probs"]), _stream()))
+        return o
+
+    def select(self, sim: int):
+        p = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        a = torch.empty_like(p)
+        n = torch.empty_like(p)
+        check(_lib.load().eaz_search_select(self.h, sim, _ptr(p), _ptr(a), _ptr(n), _stream()))
+        return p, a, n
+
+    def expand(self, sim: int, reward, reward_var, discount, prior_logits, value, value_var):
+        f = lambda t: t.to(torch.float32).contiguous()
+        keep = [f(reward), f(reward_var), f(discount), f(prior_logits), f(value), f(value_var)]
+        check(_lib.load().eaz_search_expand(self.h, sim, *[_ptr(t) for t in keep], _stream()))
+        torch.cuda.current_stream().synchronize()  # keep the temporaries alive until the kernel has consumed them
+
+    def field(self, name: str) -> torch.Tensor:
+        """Copy of one tree array (mctx Tree / emctx EpistemicTree field names)."""
+        fid, dt = TREE_FIELDS[name]
+        ptr, shape, eb = C.c_void_p(), (C.c_int64 * 3)(), C.c_int()
+        check(_lib.load().eaz_search_tree_view(self.h, fid, C.byref(ptr), shape, C.byref(eb)))
+        dims = tuple(int(d) for d in shape if d > 0)
+        typestr = {torch.int32: "<i4", torch.float32: "<f4", torch.uint8: "|u1"}[dt]
+
+        class _View:  # zero-copy view of library-owned device memory
+            __cuda_array_interface__ = {"shape": dims, "typestr": typestr, "data": (int(ptr.value), False), "version": 2}
+
+        return torch.as_tensor(_View(), device=self.device).clone()
+
+    def dump(self) -> dict:
+        return {k: self.field(k).cpu().numpy() for k in TREE_FIELDS if k != "embeddings"}
+
+    # -- fused self-play driver ---------------------------------------------------------------------------------
+    def selfplay(self, states: torch.Tensor, T: int, key=0, gumbel: Optional[torch.Tensor] = None,
+                 directed_exploration: bool = False, exploration_beta: float = 0.0, uniform_search_policy: bool = False,
+                 sample_actions: bool = False, sample_from_improved_policy: bool = False, outputs: Optional[dict] = None,
+                 use_graph: bool = False) -> dict:
+        """src/selfplay.py:78-149.  `states` ([B, state_bytes]) is advanced in place; returns SelfplayOutput fields [T,B,..]."""
+        B, A, dev = self.B, self.A, self.device
+        assert states.shape == (B, self.env.state_bytes) and states.is_contiguous()
+        if outputs is None:
+            outputs = dict(
+                state=torch.empty(T, B, self.env.state_bytes, dtype=torch.uint8, device=dev),
+                root_value=torch.empty(T, B, device=dev), root_epistemic_std=torch.empty(T, B, device=dev),
+                value_prediction=torch.empty(T, B, device=dev), ube_prediction=torch.empty(T, B, device=dev),
+                q_values_epistemic_variance=torch.empty(T, B, A, device=dev),
+                action=torch.empty(T, B, dtype=torch.int32, device=dev),
+            )
+        cfg = SelfplayCfg(T, int(directed_exploration), exploration_beta, int(uniform_search_policy), int(sample_actions),
+                          int(sample_from_improved_policy), int(use_graph))
+        g = None if gumbel is None else gumbel.to(torch.float32).contiguous()
+        o = outputs
+        check(_lib.load().eaz_selfplay_run(self.h, C.byref(cfg), as_key(key), _ptr(states), _ptr(g), _ptr(o["state"]),
+                                           _ptr(o["root_value"]), _ptr(o["root_epistemic_std"]), _ptr(o["value_prediction"]),
+                                           _ptr(o["ube_prediction"]), _ptr(o["q_values_epistemic_variance"]), _ptr(o.get("action")),
+                                           _stream()))
+        return outputs
+
+    # -- instrumentation ----------------------------------------------------------------------------------------
+    def profile(self, on: bool):
+        check(_lib.load().eaz_profile_enable(self.h, int(on)))
+
+    def profile_read(self, reset: bool = True) -> dict:
+        ms = (C.c_double * 5)()
+        n = (C.c_int64 * 5)()
+        check(_lib.load().eaz_profile_read(self.h, ms, n, int(reset)))
+        return {name: dict(ms=ms[i], launches=int(n[i])) for i, name in enumerate(_lib.K_NAMES)}

@@ -1,0 +1,199 @@
+/*
+ * include/eaz.h -- C ABI of libeaz.so, the MI355X-native Epistemic-AlphaZero self-play engine.
+ *
+ * The reference (emcts/e-alphazero) is pure Python/JAX and has no FFI layer; its de-facto operator boundary for
+ * the self-play hot path is three Python call shapes:
+ *   (i)   pgx.Env.init / step / observe + State fields      src/selfplay.py:84,135,166 ; src/context.py:125-139
+ *   (ii)  forward.apply(params, state, obs, is_training=False) -> (exploit_logits, explore_logits, v, u, nov)
+ *                                                            src/selfplay.py:89-91 ; src/context.py:86-106
+ *   (iii) emctx.epistemic_gumbel_muzero_policy(...) + search_tree.epistemic_summary(), with the recurrent fn of
+ *         src/context.py:117-155                            src/selfplay.py:100-121
+ * plus the fused driver selfplay() itself                    src/selfplay.py:78-149
+ * Each entry point below names the call shape it replaces.  The Python facade in e-alphazero_amd/ binds these
+ * with ctypes and re-exposes the reference's names; INTEGRATION.md shows the stub a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; eaz_last_error() returns a thread-local message.
+ *   - "d_" pointers are DEVICE pointers owned by the caller (e.g. torch ROCm tensors); "h_" pointers are host.
+ *   - all kernels are enqueued on the caller-supplied hipStream_t (passed as void*; NULL = default stream);
+ *     calls are asynchronous unless stated otherwise.
+ *   - one context per device; a context and the objects created from it are not thread-safe.
+ *   - keys are 64-bit (k0 | k1 << 32) seeds of the build's Threefry-2x32 stream (see csrc/rng.hpp).
+ *   - floats are IEEE binary32 everywhere ("dtype f32"); observations are uint8 (the reference's bool).
+ */
+#ifndef EAZ_H
+#define EAZ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EAZ_API __attribute__((visibility("default")))
+
+typedef struct eaz_ctx eaz_ctx;
+typedef struct eaz_env eaz_env;
+typedef struct eaz_net eaz_net;
+typedef struct eaz_search eaz_search;
+
+#define EAZ_ENV_DEEPSEA 0
+#define EAZ_ENV_SUBLEQ 1
+
+/* ---- compact env state blobs (AoS, one per environment instance) --------------------------------------------
+ * The reference keeps the whole pgx.State (incl. the observation) per tree node (src/selfplay.py:104); the
+ * observation is a pure function of these fields (deep_sea.py:66-70, subleq.py:697-705) and is regenerated
+ * by the leaf-gather kernel instead of being stored. */
+typedef struct {
+    int32_t step_count; /* _step_count           deep_sea.py:22 */
+    int32_t pos;        /* _horizontal_position  deep_sea.py:23 */
+    float reward;       /* rewards[0]            deep_sea.py:16 */
+    uint8_t terminated, truncated, pad[2];
+} eaz_deepsea_state; /* 16 bytes */
+
+#define EAZ_SUBLEQ_IO 8 /* MAXIMUM_INPUT_LENGTH = MAXIMUM_OUTPUT_LENGTH, subleq.py:15-17 */
+typedef struct {
+    int32_t step_count; /* _step_count subleq.py:554 */
+    int32_t task;       /* _task :555 */
+    float reward;       /* rewards[0] :549 */
+    uint8_t terminated, truncated, solved, pad;
+    uint16_t ex_in[EAZ_SUBLEQ_IO], ex_in_after[EAZ_SUBLEQ_IO], ex_out[EAZ_SUBLEQ_IO], ex_out_after[EAZ_SUBLEQ_IO]; /* :559-562 */
+    uint8_t memory[256]; /* _memory_state :558 (only the first W bytes are meaningful; words are < W <= 256) */
+} eaz_subleq_state; /* 336 bytes */
+
+/* ---- context ------------------------------------------------------------------------------------------------ */
+EAZ_API const char* eaz_last_error(void);
+EAZ_API int eaz_version(void);
+EAZ_API int eaz_ctx_create(int device, eaz_ctx** out);
+EAZ_API int eaz_ctx_destroy(eaz_ctx* ctx);
+/* child key = fold(key, tag) of the engine's Threefry-2x32 key derivation (csrc/rng.hpp); the counterpart of
+ * jax.random.split / fold_in at src/selfplay.py:87,145-147 */
+EAZ_API int eaz_key_fold(uint64_t key, uint32_t tag, uint64_t* out);
+
+/* ---- (i) environments: pgx.Env surface -------------------------------------------------------------------- */
+/* DeepSea(size_of_grid, action_map_key) deep_sea.py:37-52; the caller supplies the Bernoulli(0.5) map itself. */
+EAZ_API int eaz_env_create_deepsea(eaz_ctx* ctx, int size_of_grid, const uint8_t* h_action_map /* [G*G] or NULL */, eaz_env** out);
+/* Subleq(tasks, word_size, use_binary_encoding) subleq.py:599-621 */
+EAZ_API int eaz_env_create_subleq(eaz_ctx* ctx, int word_size, const int32_t* h_tasks, int n_tasks, int use_binary_encoding, eaz_env** out);
+EAZ_API int eaz_env_destroy(eaz_env* env);
+/* num_actions, observation shape [rows, cols] and the byte size of one compact state */
+EAZ_API int eaz_env_info(const eaz_env* env, int* kind, int* num_actions, int* obs_rows, int* obs_cols, int* state_bytes);
+/* vmap(env.init)(keys)   selfplay.py:166 */
+EAZ_API int eaz_env_init(eaz_env* env, int B, uint64_t key, void* d_states, void* stream);
+/* vmap(env.step)(state, action, keys) context.py:127 ; autoreset != 0: vmap(auto_reset(env.step, env.init)) selfplay.py:26-75,135 */
+EAZ_API int eaz_env_step(eaz_env* env, int B, const void* d_states_in, const int32_t* d_action, uint64_t key, int autoreset,
+                 void* d_states_out, void* stream);
+/* state.observation -> uint8 [B, rows*cols] */
+EAZ_API int eaz_env_observe(eaz_env* env, int B, const void* d_states, uint8_t* d_obs, void* stream);
+/* state.terminated / truncated / rewards[:,0] / _step_count / legal_action_mask[B,A] (any pointer may be NULL) */
+EAZ_API int eaz_env_fields(eaz_env* env, int B, const void* d_states, uint8_t* d_terminated, uint8_t* d_truncated,
+                   float* d_reward, int32_t* d_step_count, uint8_t* d_legal_mask, void* stream);
+
+/* ---- (ii) network: forward.apply(params, state, obs, is_training=False) ------------------------------------ */
+/* EpistemicFullyConnectedAZNet fully_connected.py:14-39.  h_w[i] is [in,out] row-major, h_b[i] is [out], i in haiku
+ * creation order: value 0-2, ube 3-5, exploitation 6-8, exploration 9-11 (fully_connected.py:50-81).
+ * hash_off/hash_len select the flattened slice that is hashed (hash_io: rows word_size.. , fully_connected.py:85-87). */
+EAZ_API int eaz_net_create_fc(eaz_ctx* ctx, int in_dim, int hidden, int num_actions, const float* const* h_w, const float* const* h_b,
+                      float max_ube, float max_reward_variance, int hash_off, int hash_len, int hash_bits, eaz_net** out);
+EAZ_API int eaz_net_destroy(eaz_net* net);
+/* replace weights (after a learner update) -- same layout as eaz_net_create_fc */
+EAZ_API int eaz_net_set_weights(eaz_net* net, const float* const* h_w, const float* const* h_b, void* stream);
+/* haiku state "fc_az_net/xxhash32/binary_set": uint8[2^(bits-3)] (hashes.py:40-43); host copy in/out */
+EAZ_API int eaz_net_set_bitset(eaz_net* net, const uint8_t* h_bitset, void* stream);
+EAZ_API int eaz_net_get_bitset(eaz_net* net, uint8_t* h_bitset, void* stream); /* synchronous */
+/* outputs in the CODE's order (fully_connected.py:101): exploit[B,A], explore[B,A], v[B], u[B], novelty[B] (NULL = skip) */
+EAZ_API int eaz_net_forward(eaz_net* net, int B, const uint8_t* d_obs, float* d_exploit, float* d_explore, float* d_value,
+                    float* d_ube, float* d_novelty, void* stream);
+/* BaseHash.__call__ / get_indices / update  hashes.py:23-50,162-229 on d_obs[:, hash_off:hash_off+hash_len] */
+EAZ_API int eaz_hash_lookup(eaz_net* net, int B, const uint8_t* d_obs, uint8_t* d_seen, uint32_t* d_indices, void* stream);
+EAZ_API int eaz_hash_update(eaz_net* net, int B, const uint8_t* d_obs, void* stream);
+
+/* ---- (iii) search: emctx.epistemic_gumbel_muzero_policy --------------------------------------------------- */
+typedef struct {
+    int num_simulations;            /* selfplay.py:111 */
+    int max_depth;                  /* emctx default None -> num_simulations (pass 0) */
+    int max_num_considered_actions; /* emctx default 16 */
+    float gumbel_scale;             /* emctx default 1.0 ; evaluate.py:44 passes 0.0 */
+    /* qtransform = partial(epistemic_qtransform_completed_by_mix_value, rescale_values=...) selfplay.py:114-116 */
+    int rescale_values;
+    int use_mixed_value; /* 1 */
+    float value_scale;   /* 0.1 */
+    float maxvisit_init; /* 50 */
+    /* recurrent fn factory arguments, context.py:109-115 */
+    float discount;
+    int two_players_game;
+    int exploration; /* use exploration logits inside the tree (context.py:132) */
+} eaz_search_opts;
+
+EAZ_API int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B, const eaz_search_opts* opts, eaz_search** out);
+EAZ_API int eaz_search_destroy(eaz_search* s);
+
+/* EpistemicRootFnOutput(prior_logits, value, value_epistemic_variance, embedding, beta) selfplay.py:100-106,
+ * invalid_actions (uint8 [B,A] or NULL), explicit root Gumbel noise (already multiplied by gumbel_scale). */
+EAZ_API int eaz_search_begin(eaz_search* s, const float* d_prior_logits, const float* d_value, const float* d_value_var,
+                     const void* d_root_states, const float* d_beta, const uint8_t* d_invalid, const float* d_gumbel,
+                     void* stream);
+/* one simulation = select -> leaf gather + env.step -> forward -> expand -> backward (fused native recurrent fn) */
+EAZ_API int eaz_search_simulate(eaz_search* s, int sim, void* stream);
+/* all simulations (sim = 0..S-1) */
+EAZ_API int eaz_search_run(eaz_search* s, void* stream);
+/* PolicyOutput.action [B] int32, action_weights [B,A] */
+EAZ_API int eaz_search_finish(eaz_search* s, int32_t* d_action, float* d_action_weights, void* stream);
+/* search_tree.epistemic_summary(): value[B], value_epistemic_std[B], qvalues[B,A], qvalues_epistemic_variance[B,A],
+ * visit_counts[B,A] (f32), visit_probs[B,A]; any pointer may be NULL.  selfplay.py:119-121,125,142 ; reanalyze.py:86-116 */
+EAZ_API int eaz_search_summary(eaz_search* s, float* d_value, float* d_value_std, float* d_qvalues, float* d_qvalues_var,
+                       float* d_visit_counts, float* d_visit_probs, void* stream);
+
+/* generic-recurrent-fn path: the caller evaluates recurrent_fn itself between the two halves.
+ * select: writes parent_index[B], action[B], next_node_index[B]. */
+EAZ_API int eaz_search_select(eaz_search* s, int sim, int32_t* d_parent, int32_t* d_action, int32_t* d_next, void* stream);
+/* expand + backward with EpistemicRecurrentFnOutput(reward, reward_epistemic_variance, discount, prior_logits, value,
+ * value_epistemic_variance) context.py:146-153 (prior_logits already masked by the caller's recurrent fn). */
+EAZ_API int eaz_search_expand(eaz_search* s, int sim, const float* d_reward, const float* d_reward_var, const float* d_discount,
+                      const float* d_prior_logits, const float* d_value, const float* d_value_var, void* stream);
+
+/* tree field ids for eaz_search_tree_view (mctx Tree / emctx EpistemicTree field names) */
+enum {
+    EAZ_F_NODE_VISITS = 0, EAZ_F_RAW_VALUES = 1, EAZ_F_NODE_VALUES = 2, EAZ_F_PARENTS = 3, EAZ_F_ACTION_FROM_PARENT = 4,
+    EAZ_F_CHILDREN_INDEX = 5, EAZ_F_CHILDREN_PRIOR_LOGITS = 6, EAZ_F_CHILDREN_VALUES = 7, EAZ_F_CHILDREN_VISITS = 8,
+    EAZ_F_CHILDREN_REWARDS = 9, EAZ_F_CHILDREN_DISCOUNTS = 10, EAZ_F_RAW_VALUES_VAR = 11, EAZ_F_NODE_VALUES_VAR = 12,
+    EAZ_F_CHILDREN_VALUES_VAR = 13, EAZ_F_CHILDREN_REWARDS_VAR = 14, EAZ_F_EMBEDDINGS = 15, EAZ_F_ROOT_GUMBEL = 16,
+    EAZ_F_BETA = 17, EAZ_F_COUNT = 18
+};
+/* device pointer + shape ([B,N], [B,N,A], [B,N,state_bytes], [B,A] or [B]; unused dims = 0) + element size */
+EAZ_API int eaz_search_tree_view(eaz_search* s, int field_id, void** d_ptr, int64_t shape[3], int* elem_bytes);
+
+/* ---- fused driver: selfplay()  src/selfplay.py:78-149 ------------------------------------------------------ */
+typedef struct {
+    int selfplay_steps;               /* T, config.py:37 */
+    int directed_exploration;         /* config.py:38 */
+    float exploration_beta;           /* config.py:69 */
+    int uniform_search_policy;        /* config.py:42 */
+    int sample_actions;               /* config.py:39 */
+    int sample_from_improved_policy;  /* config.py:40 */
+    int use_graph;                    /* capture each real step into a hipGraph and replay it */
+} eaz_selfplay_cfg;
+
+/* d_states [B] compact states: in = last_states, out = new last_states.  d_gumbel: optional explicit unscaled root
+ * noise [T,B,A] (NULL = generated from key).  Outputs are SelfplayOutput fields (selfplay.py:17-23), [T,B(,A)]:
+ * state (compact blobs), root_value, root_epistemic_std, value_prediction, ube_prediction,
+ * q_values_epistemic_variance; d_out_action [T,B] is an extra (the chosen actions).  Any output may be NULL. */
+EAZ_API int eaz_selfplay_run(eaz_search* s, const eaz_selfplay_cfg* cfg, uint64_t key, void* d_states, const float* d_gumbel,
+                     void* d_out_states, float* d_out_root_value, float* d_out_root_std, float* d_out_value_pred,
+                     float* d_out_ube_pred, float* d_out_qvar, int32_t* d_out_action, void* stream);
+
+/* uniformrandomplay() src/selfplay.py:152-170: init + T uniformly random auto-reset steps; d_states [B] out (last states),
+ * d_traj optional [T,B] states before each step. */
+EAZ_API int eaz_random_play(eaz_env* env, int B, int T, uint64_t key, void* d_states, void* d_traj, void* stream);
+
+/* ---- instrumentation -------------------------------------------------------------------------------------- */
+/* per-kernel-class device time accumulated with hipEvents on the launch stream while profiling is enabled */
+enum { EAZ_K_TREE = 0, EAZ_K_GATHER = 1, EAZ_K_HASH = 2, EAZ_K_NET = 3, EAZ_K_MISC = 4, EAZ_K_COUNT = 5 };
+EAZ_API int eaz_profile_enable(eaz_search* s, int on);
+/* synchronises the stream; returns total ms and launch count per class since the last reset */
+EAZ_API int eaz_profile_read(eaz_search* s, double ms[EAZ_K_COUNT], int64_t launches[EAZ_K_COUNT], int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EAZ_H */
