@@ -26,7 +26,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import e_alphazero_amd as eaz  # noqa: E402
-from e_alphazero_amd import engine  # noqa: E402
+from e_alphazero_amd import engine, pool  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBPS = 8000.0        # MI355X_MICROARCH.md "HBM3E peak BW"
@@ -87,16 +87,8 @@ def main():
         nonlocal outputs, gathered
         outputs = search.selfplay(states, T, key=(1000 * rank + i), outputs=outputs)
         if dist is not None:
-            # pool trajectories of all ranks (replay-buffer landing zone): one all-gather of the packed block
-            block = torch.cat([outputs["state"].reshape(T, B, -1),
-                               outputs["root_value"].view(torch.uint8).reshape(T, B, 4),
-                               outputs["root_epistemic_std"].view(torch.uint8).reshape(T, B, 4),
-                               outputs["value_prediction"].view(torch.uint8).reshape(T, B, 4),
-                               outputs["ube_prediction"].view(torch.uint8).reshape(T, B, 4),
-                               outputs["q_values_epistemic_variance"].view(torch.uint8).reshape(T, B, 4 * A)], dim=2)
-            if gathered is None:
-                gathered = torch.empty((world,) + tuple(block.shape), dtype=torch.uint8, device=dev)
-            dist.all_gather_into_tensor(gathered, block.contiguous())
+            # pool the trajectories of all ranks (replay-buffer landing zone): ONE all-gather of the packed block
+            gathered = pool.all_gather_trajectories(pool.pack(outputs), out=gathered)
 
     def sync():
         if dist is not None:
@@ -163,6 +155,8 @@ def main():
         import eaz_oracle as O
 
         cb, ct = args.cpu_sample_batch, args.cpu_sample_steps
+        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        O.lib().eazo_set_num_threads(ncores)
         oenv = O.OracleEnv.deepsea(G, am)
         onet = O.OracleNet(G * G, H, A, eaz.params.fc_weight_list(params), bitset=hstate[eaz.params.HASH_MODULE]["binary_set"])
         ost = oenv.init(cb)

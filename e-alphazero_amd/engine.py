@@ -73,6 +73,8 @@ class Context:
 
     @staticmethod
     def get(device: Optional[int] = None) -> "Context":
+        if not torch.cuda.is_available():
+            raise EazError("no ROCm device visible: the engine has no CPU fallback")
         device = torch.cuda.current_device() if device is None else device
         if device not in _contexts:
             _contexts[device] = Context(device)

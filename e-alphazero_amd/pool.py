@@ -1,0 +1,63 @@
+"""Trajectory pooling across ranks: the counterpart of the reference's host-side concat of per-device self-play output
+(src/main.py:383-385) before `buffer_fn.add`.
+
+Self-play shards embarrassingly (one process per GPU, no collective inside the search); after each selfplay() call
+every rank contributes its [T, B_local, ...] block and receives the pooled [T, world * B_local, ...] block with ONE
+all-gather (RCCL over xGMI on MI355X, gloo in the CPU tests).  All SelfplayOutput fields are packed into a single
+uint8 record per (t, b) so that it is one collective, not six.
+"""
+from __future__ import annotations
+
+import torch
+
+FLOAT_FIELDS = ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction")
+
+
+def record_bytes(state_bytes: int, num_actions: int) -> int:
+    return state_bytes + 4 * len(FLOAT_FIELDS) + 4 * num_actions + 4
+
+
+def pack(out: dict) -> torch.Tensor:
+    """SelfplayOutput dict ([T,B,...] tensors) -> uint8 [T, B, record_bytes]."""
+    T, B = out["root_value"].shape
+    parts = [out["state"].reshape(T, B, -1)]
+    parts += [out[k].contiguous().view(torch.uint8).reshape(T, B, 4) for k in FLOAT_FIELDS]
+    parts.append(out["q_values_epistemic_variance"].contiguous().view(torch.uint8).reshape(T, B, -1))
+    parts.append(out["action"].contiguous().view(torch.uint8).reshape(T, B, 4))
+    return torch.cat(parts, dim=2).contiguous()
+
+
+def unpack(block: torch.Tensor, state_bytes: int, num_actions: int) -> dict:
+    """uint8 [T, B, record_bytes] -> SelfplayOutput dict."""
+    T, B, R = block.shape
+    assert R == record_bytes(state_bytes, num_actions)
+    out, o = {}, 0
+    out["state"] = block[:, :, o:o + state_bytes].contiguous()
+    o += state_bytes
+    for k in FLOAT_FIELDS:
+        out[k] = block[:, :, o:o + 4].contiguous().view(torch.float32).reshape(T, B)
+        o += 4
+    out["q_values_epistemic_variance"] = block[:, :, o:o + 4 * num_actions].contiguous().view(torch.float32).reshape(T, B, num_actions)
+    o += 4 * num_actions
+    out["action"] = block[:, :, o:o + 4].contiguous().view(torch.int32).reshape(T, B)
+    return out
+
+
+def all_gather_trajectories(block: torch.Tensor, out: torch.Tensor | None = None, group=None) -> torch.Tensor:
+    """block: uint8 [T, B, R] of this rank -> pooled uint8 [T, world*B, R] (rank-major along the batch axis, like the
+    reference's `states.reshape(B_total, T, ...)` over devices)."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    T, B, R = block.shape
+    if out is None:
+        out = torch.empty(world, T, B, R, dtype=torch.uint8, device=block.device)
+    # concatenation-along-dim-0 form: accepted by both the RCCL and the gloo backend
+    dist.all_gather_into_tensor(out.view(world * T, B, R), block, group=group)
+    return out
+
+
+def pooled_view(gathered: torch.Tensor) -> torch.Tensor:
+    """[world, T, B, R] -> [T, world*B, R]"""
+    W, T, B, R = gathered.shape
+    return gathered.permute(1, 0, 2, 3).reshape(T, W * B, R)

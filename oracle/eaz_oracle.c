@@ -471,6 +471,17 @@ EXPORT void eazo_subleq_simulate(int W, const int32_t* mem, const int32_t* tin, 
 EXPORT void eazo_subleq_encode(const OEnv* e, const int32_t* words, int n, uint8_t* rows) {
     for (int i = 0; i < n; ++i) o_subleq_encode_row(e, words[i], rows + (size_t)i * e->obs_cols);
 }
+/* encoders for ANY word size (the docstring example at subleq.py:30-41 uses word_size = 8, below the env's minimum) */
+EXPORT int eazo_subleq_encode_raw(int W, int binary, const int32_t* words, int n, uint8_t* rows) {
+    OEnv e;
+    memset(&e, 0, sizeof e);
+    e.W = W; e.binary = binary;
+    int bl = 0;
+    for (int v = W - 1; v > 0; v >>= 1) bl++;
+    e.obs_cols = binary ? bl + 1 : W + 1;
+    for (int i = 0; i < n; ++i) o_subleq_encode_row(&e, words[i], rows + (size_t)i * e.obs_cols);
+    return e.obs_cols;
+}
 
 /* ===================================================================================================== *
  *  Hash novelty set  (src/network/hashes.py)                                                            *

@@ -61,6 +61,7 @@ def lib():
             "eazo_subleq_test_cases": (None, [i32, i32, vp, vp]),
             "eazo_subleq_simulate": (None, [i32, vp, vp, vp, vp, vp, vp]),
             "eazo_subleq_encode": (None, [vp, vp, i32, vp]),
+            "eazo_subleq_encode_raw": (i32, [i32, i32, vp, i32, vp]),
             "eazo_xxhash_indices": (None, [vp, i32, i32, i32, vp]),
             "eazo_hash_update": (None, [vp, vp, i32]),
             "eazo_hash_seen": (None, [vp, vp, i32, vp]),

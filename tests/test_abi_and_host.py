@@ -1,0 +1,81 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol include/eaz.h declares, the ctypes
+binding covers the same set, host-only helpers behave, and the product never routes through the oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "eaz.h")).read()
+    return sorted(set(re.findall(r"EAZ_API\s+(?:const\s+char\*|int)\s+(eaz_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(eaz):
+    names = _declared()
+    assert len(names) >= 30
+    lib = C.CDLL(eaz.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"libeaz.so does not export {n}"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", eaz.LIB_PATH], text=True)
+    exported = sorted(set(re.findall(r" T (eaz_\w+)", out)))
+    assert exported == names, "exported symbols and include/eaz.h differ"
+
+
+def test_ctypes_binding_matches_header(eaz):
+    assert sorted(list(eaz.SIGNATURES) + ["eaz_last_error"]) == _declared()
+    assert eaz.load_library().eaz_version() >= 100
+
+
+def test_state_struct_sizes_match_header():
+    from helpers import DEVICE_SUBLEQ
+
+    text = open(os.path.join(ROOT, "include", "eaz.h")).read()
+    assert "eaz_deepsea_state; /* 16 bytes */" in text and "eaz_subleq_state; /* 336 bytes */" in text
+    assert DEVICE_SUBLEQ.itemsize == 336
+
+
+def test_no_gpu_means_loud_failure(eaz):
+    """No CPU fallback: without a ROCm device the engine refuses to create a context."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from e_alphazero_amd import engine
+
+    with pytest.raises(eaz.EazError):
+        engine.EnvHandle.deepsea(8, None)
+    out = C.c_void_p()
+    assert eaz.load_library().eaz_ctx_create(0, C.byref(out)) != 0
+    assert b"hip" in eaz.load_library().eaz_last_error().lower()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "e-alphazero_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "eaz_oracle" not in text and "oracle/" not in text and "eazo_" not in text, f
+
+
+def test_params_layout_and_npz_roundtrip(eaz, tmp_path):
+    p = eaz.params.init_fc_params(64, 256, 2, seed=0)
+    assert list(p)[0] == "fc_az_net/linear" and list(p)[-1] == "fc_az_net/linear_11"
+    assert p["fc_az_net/linear"]["w"].shape == (64, 256) and p["fc_az_net/linear_2"]["w"].shape == (256, 1)
+    assert p["fc_az_net/linear_8"]["w"].shape == (256, 2) and p["fc_az_net/linear_11"]["b"].shape == (2,)
+    w = p["fc_az_net/linear"]["w"]
+    assert np.abs(w).max() <= 2 / 8 + 1e-6 and abs(w.std() - 0.88 / 8) < 0.01  # trunc-normal(2 sigma), sigma = 1/sqrt(64)
+    s = eaz.params.init_hash_state(fill=0.5, seed=1)
+    bs = s["fc_az_net/xxhash32"]["binary_set"]
+    assert bs.shape == (1 << 21,) and abs(np.unpackbits(bs[:4096]).mean() - 0.5) < 0.05
+    path = str(tmp_path / "ckpt.npz")
+    eaz.params.save_npz(path, p, s)
+    p2, s2 = eaz.params.load_npz(path)
+    assert all(np.array_equal(p[k]["w"], p2[k]["w"]) and np.array_equal(p[k]["b"], p2[k]["b"]) for k in p)
+    assert np.array_equal(s2["fc_az_net/xxhash32"]["binary_set"], bs)

@@ -1,0 +1,136 @@
+"""GPU parity against the committed golden vectors (tests/golden/*.npz) and Subleq parity against the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import subleq_device_to_oracle, subleq_oracle_to_device, subleq_setup, deepsea_setup
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-5
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as MG  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+
+    assert t.cuda.is_available()
+    return t
+
+
+def _build_engine(eaz, kind, size, seed, fill):
+    from e_alphazero_amd import engine
+
+    if kind == "deepsea":
+        am, params, state = deepsea_setup(eaz, size, seed=seed, fill=fill)
+        env = engine.EnvHandle.deepsea(size, am, device=0)
+        net = engine.FCNet(env.ctx, size * size, 256, 2, params, state)
+        return engine, env, net, 0.997
+    dims, params, state = subleq_setup(eaz, size, seed=seed, fill=fill)
+    env = engine.EnvHandle.subleq(size, (1,), True, device=0)
+    net = engine.FCNet(env.ctx, dims["in_dim"], 256, size, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
+    return engine, env, net, 0.97
+
+
+def _to_oracle_states(kind, size, dev_states):
+    a = dev_states.cpu().numpy()
+    return a if kind == "deepsea" else subleq_device_to_oracle(a, size)
+
+
+@pytest.mark.parametrize("name", sorted(MG.CASES))
+def test_selfplay_and_tree_match_golden(eaz, torch, name):
+    kind, size, B, S, T, seed, fill, flags = MG.CASES[name]
+    z = np.load(os.path.join(HERE, "golden", f"{name}.npz"))
+    engine, env, net, discount = _build_engine(eaz, kind, size, seed, fill)
+    explore = bool(flags.get("directed_exploration", False))
+    search = engine.Search(env, net, B, S, discount=discount, exploration=explore)
+    st = env.init(B, key=seed)
+    out = search.selfplay(st, T, key=1000 + seed, **flags)
+    assert np.array_equal(out["action"].cpu().numpy(), z["sp_action"])
+    assert np.array_equal(_to_oracle_states(kind, size, out["state"]), z["sp_state"])
+    assert np.array_equal(_to_oracle_states(kind, size, st), z["last_states"])
+    for k in ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction", "q_values_epistemic_variance"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), z[f"sp_{k}"], rtol=0, atol=ATOL, err_msg=k)
+    # standalone search from the final states with the golden root outputs / noise injected: full tree comparison
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    search.begin(cu(z["root_logits"]), cu(z["root_value"]), cu(z["root_var"]), st, cu(z["beta"]), None, cu(z["gumbel"]))
+    search.run()
+    act, aw = search.finish()
+    assert np.array_equal(act.cpu().numpy(), z["search_action"])
+    np.testing.assert_allclose(aw.cpu().numpy(), z["search_action_weights"], rtol=0, atol=ATOL)
+    d = search.dump()
+    for k in MG.TREE_INT:
+        assert np.array_equal(d[k], z[f"tree_{k}"]), k
+    for k in MG.TREE_F32:
+        np.testing.assert_allclose(d[k], z[f"tree_{k}"], rtol=0, atol=ATOL, err_msg=k)
+    s = search.summary()
+    for k in ("value", "value_epistemic_std", "qvalues", "qvalues_epistemic_variance", "visit_counts", "visit_probs"):
+        np.testing.assert_allclose(s[k].cpu().numpy(), z[f"sum_{k}"], rtol=0, atol=ATOL, err_msg=k)
+
+
+@pytest.mark.parametrize("W,binary,tasks", [(16, True, (1,)), (16, False, (3,)), (32, True, (2, 5, 9)), (256, True, (1,))])
+def test_subleq_env_matches_oracle(oracle, eaz, torch, W, binary, tasks):
+    from e_alphazero_amd import engine
+
+    env = engine.EnvHandle.subleq(W, tasks, binary, device=0)
+    oenv = oracle.OracleEnv.subleq(W, tasks, binary)
+    assert env.obs_shape == oenv.obs_shape and env.num_actions == W
+    B = 130
+    st = env.init(B, key=5)
+    ost = oenv.init(B, key=(5, 0))
+    assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost)
+    rng = np.random.default_rng(W)
+    for t in range(W - 1 if W <= 32 else 14):
+        a = rng.integers(0, W, B).astype(np.int32)
+        a[: B // 4] = [W - 2, W - 3][t] if t < 2 else a[: B // 4]  # a quarter of the batch solves NEGATION_POSITIVE-style tasks
+        auto = t % 3 == 2
+        st = env.step(st, torch.from_numpy(a).cuda(), key=100 + t, autoreset=auto)
+        ost = oenv.step(ost, a, key=(100 + t, 0), autoreset=auto)
+        assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost), f"t={t}"
+        assert np.array_equal(env.observe(st).cpu().numpy(), oenv.observe(ost)), f"obs t={t}"
+        f, of = env.fields(st), oenv.fields(ost)
+        assert np.array_equal(f["rewards"].cpu().numpy()[:, 0], of["rewards"])
+        assert np.array_equal(f["terminated"].cpu().numpy(), of["terminated"])
+    # round trip of the layout converters themselves
+    assert np.array_equal(subleq_oracle_to_device(ost), st.cpu().numpy())
+
+
+def test_random_play_matches_oracle(oracle, eaz, torch):
+    """uniformrandomplay (selfplay.py:152-170): same keys -> same trajectories."""
+    from e_alphazero_amd import engine
+
+    am, _, _ = deepsea_setup(eaz, 8, seed=9)
+    env = engine.EnvHandle.deepsea(8, am, device=0)
+    oenv = oracle.OracleEnv.deepsea(8, am)
+    last, traj = env.random_play(64, 20, key=77, want_traj=True)
+    olast, otraj = oracle.random_play(oenv, 64, 20, key=(77, 0), want_traj=True)
+    assert np.array_equal(last.cpu().numpy(), olast) and np.array_equal(traj.cpu().numpy(), otraj)
+    senv = engine.EnvHandle.subleq(16, (1, 2, 3), True, device=0)
+    osenv = oracle.OracleEnv.subleq(16, (1, 2, 3), True)
+    last, _ = senv.random_play(96, 30, key=78)
+    olast, _ = oracle.random_play(osenv, 96, 30, key=(78, 0))
+    assert np.array_equal(subleq_device_to_oracle(last.cpu().numpy(), 16), olast)
+
+
+def test_hash_update_matches_oracle(oracle, eaz, torch):
+    """BaseHash.update (hashes.py:45-50) as a scatter-OR kernel."""
+    G, B = 8, 500
+    am, params, state = deepsea_setup(eaz, G, seed=1, fill=0.0)
+    from e_alphazero_amd import engine
+
+    env = engine.EnvHandle.deepsea(G, am, device=0)
+    net = engine.FCNet(env.ctx, G * G, 256, 2, params, state)
+    obs = (np.random.default_rng(0).random((B, G * G)) < 0.1).astype(np.uint8)
+    net.hash_update(torch.from_numpy(obs).cuda())
+    bs = net.get_state()[eaz.params.HASH_MODULE]["binary_set"]
+    idx = np.empty(B, np.uint32)
+    oracle.lib().eazo_xxhash_indices(obs.ctypes.data, B, G * G, 24, idx.ctypes.data)
+    ref = np.zeros(1 << 21, np.uint8)
+    oracle.lib().eazo_hash_update(ref.ctypes.data, idx.ctypes.data, B)
+    assert np.array_equal(bs, ref)
+    seen, _ = net.hash_lookup(torch.from_numpy(obs).cuda())
+    assert seen.all()

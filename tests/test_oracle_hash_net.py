@@ -1,0 +1,142 @@
+"""Pins for the XXHash-variant novelty set (src/network/hashes.py) and the FC forward (src/network/fully_connected.py)."""
+import struct
+
+import numpy as np
+import pytest
+import xxhash
+
+M32 = 0xFFFFFFFF
+P1, P2, P3, P4, P5 = 0x9E3779B1, 0x85EBCA77, 0xC2B2AE3D, 0x27D4EB2F, 0x165667B1
+
+
+def test_xxh32_primitives_against_xxhash_package(oracle):
+    """hashes.py:164-197 constants/rotations: rebuild REAL xxh32 (seed 1, inputs of 16*L bytes so there is no tail) from the
+    oracle's round/converge/avalanche primitives and compare with the installed `xxhash` package."""
+    L = oracle.lib()
+    rng = np.random.default_rng(0)
+    for nstripes in (1, 2, 7, 64):
+        data = rng.integers(0, 256, 16 * nstripes, dtype=np.uint8).tobytes()
+        seed = 1
+        acc = [(seed + P1 + P2) & M32, (seed + P2) & M32, seed, (seed - P1) & M32]
+        words = struct.unpack(f"<{4 * nstripes}I", data)
+        for s in range(nstripes):  # real xxh32 interleaves: stripe s feeds words 4s..4s+3 to lanes 0..3
+            for i in range(4):
+                acc[i] = L.eazo_xxh_round(acc[i], words[4 * s + i])
+        h = L.eazo_xxh_converge(*acc)
+        h = (h + 16 * nstripes) & M32  # real xxh32 adds the BYTE length
+        h = L.eazo_xxh_avalanche(h)
+        assert h == xxhash.xxh32(data, seed=1).intdigest()
+
+
+def _variant_py(x_bytes, bits=24):
+    """Independent pure-Python restatement of XXHash.get_indices (hashes.py:162-229) on one observation row."""
+    rotl = lambda v, n: ((v << n) | (v >> (32 - n))) & M32
+    lanes = np.frombuffer(np.asarray(x_bytes, np.uint8).astype(np.float32).tobytes(), dtype=np.uint32)  # :45 astype, :207 bitcast
+    x = lanes.reshape(4, -1)  # :211  [4, L]: lane i = i-th contiguous quarter
+    Ls = x.shape[1]
+    acc = [(1 + P1 + P2) & M32, (1 + P2) & M32, 1, (1 - P1) & M32]  # :217-220
+    for l in range(Ls):
+        for i in range(4):
+            a = (acc[i] + int(x[i, l]) * P2) & M32  # :176-181
+            acc[i] = (rotl(a, 13) * P1) & M32
+    h = (rotl(acc[0], 1) + rotl(acc[1], 7) + rotl(acc[2], 12) + rotl(acc[3], 18)) & M32  # :184-187
+    h = (h + Ls) & M32  # :226
+    h ^= h >> 15; h = (h * P2) & M32; h ^= h >> 13; h = (h * P3) & M32; h ^= h >> 16  # :190-197
+    return h >> (32 - bits)  # :229
+
+
+@pytest.mark.parametrize("n", [16, 40, 64, 240, 1024])
+def test_xxhash_variant_matches_python_restatement(oracle, n):
+    rng = np.random.default_rng(n)
+    x = (rng.random((9, n)) < 0.3).astype(np.uint8)
+    x[0] = 0
+    x[1, :] = 0
+    x[1, n // 3] = 1
+    idx = np.empty(9, np.uint32)
+    oracle.lib().eazo_xxhash_indices(x.ctypes.data, 9, n, 24, idx.ctypes.data)
+    assert [int(i) for i in idx] == [_variant_py(r) for r in x]
+    assert int(idx.max()) < 1 << 24
+
+
+def test_bitset_lookup_and_update(oracle):
+    """hashes.py:23-50: seen = set[idx // 8] & (1 << idx % 8); update ORs the bit in."""
+    bs = np.zeros(1 << 21, np.uint8)
+    idx = np.array([0, 7, 8, 12345678, (1 << 24) - 1], np.uint32)
+    seen = np.empty(5, np.uint8)
+    oracle.lib().eazo_hash_seen(bs.ctypes.data, idx.ctypes.data, 5, seen.ctypes.data)
+    assert not seen.any()
+    oracle.lib().eazo_hash_update(bs.ctypes.data, idx[:4].ctypes.data, 4)
+    oracle.lib().eazo_hash_seen(bs.ctypes.data, idx.ctypes.data, 5, seen.ctypes.data)
+    assert seen.tolist() == [1, 1, 1, 1, 0]
+    assert bs[0] == 0x81 and bs[1] == 0x01 and bs[12345678 // 8] == 1 << (12345678 % 8)
+    assert int(np.unpackbits(bs).sum()) == 4  # main.py:466-471 popcount log
+
+
+def _fc_numpy(params, obs, A, bitset_seen, max_u=1.0):
+    """float64 restatement of fully_connected.py:41-101 (inference branch)."""
+    import e_alphazero_amd as eaz
+
+    wl = [(w.astype(np.float64), b.astype(np.float64)) for w, b in eaz.params.fc_weight_list(params)]
+    x = obs.astype(np.float64)
+    outs = []
+    for head in range(4):
+        h = x
+        for l in range(3):
+            w, b = wl[head * 3 + l]
+            h = h @ w + b
+            if l < 2:
+                h = np.maximum(h, 0)
+        outs.append(h)
+    v = np.tanh(outs[0][:, 0])
+    u = 0.5 * (np.tanh(outs[1][:, 0]) + 1)
+    nov = (~bitset_seen).astype(np.float64)
+    u = np.clip(np.maximum(nov, u * max_u), 0, max_u)
+    return outs[2], outs[3], v, u, nov
+
+
+def test_fc_forward_against_float64(oracle, eaz):
+    G, B = 8, 37
+    params = eaz.params.init_fc_params(G * G, 256, 2, seed=3)
+    for k in params:  # non-zero biases so the bias path is exercised
+        params[k]["b"] = (np.random.default_rng(1).standard_normal(params[k]["b"].shape) * 0.1).astype(np.float32)
+    st = eaz.params.init_hash_state(fill=0.5, seed=2)
+    bs = st[eaz.params.HASH_MODULE]["binary_set"]
+    net = oracle.OracleNet(G * G, 256, 2, eaz.params.fc_weight_list(params), bitset=bs)
+    obs = (np.random.default_rng(4).random((B, G * G)) < 0.2).astype(np.uint8)
+    ex, xp, v, u, nov = net.forward(obs)
+    idx = np.empty(B, np.uint32)
+    oracle.lib().eazo_xxhash_indices(obs.ctypes.data, B, G * G, 24, idx.ctypes.data)
+    seen = np.empty(B, np.uint8)
+    oracle.lib().eazo_hash_seen(bs.ctypes.data, idx.ctypes.data, B, seen.ctypes.data)
+    assert 0 < seen.sum() < B
+    rex, rxp, rv, ru, rnov = _fc_numpy(params, obs, 2, seen.astype(bool))
+    np.testing.assert_allclose(ex, rex, atol=2e-6)
+    np.testing.assert_allclose(xp, rxp, atol=2e-6)
+    np.testing.assert_allclose(v, rv, atol=1e-6)
+    np.testing.assert_allclose(u, ru, atol=1e-6)
+    assert np.array_equal(nov, rnov)
+    assert (u[~seen.astype(bool)] == 1.0).all()  # unseen state -> novelty 1 -> u = max_u (fully_connected.py:92-96)
+
+
+def test_fc_forward_hash_io_slice(oracle, eaz):
+    """fully_connected.py:85-87: with hash_io only rows word_size.. of the observation are hashed."""
+    from helpers import subleq_setup
+
+    W = 16
+    dims, params, st = subleq_setup(eaz, W)
+    assert dims["hash_len"] == 32 * 5 and dims["hash_len"] % 4 == 0  # L = 40
+    bs = st[eaz.params.HASH_MODULE]["binary_set"].copy()
+    env = oracle.OracleEnv.subleq(W, (1,), True)
+    s0 = env.init(2)
+    s1 = env.step(s0, np.array([0, 1], np.int32))  # different memory, same IO rows (neither program touches IN/OUT)
+    obs = env.observe(s1)
+    assert not np.array_equal(obs[0, : dims["hash_off"]], obs[1, : dims["hash_off"]])
+    idx = np.empty(2, np.uint32)
+    io = np.ascontiguousarray(obs[:, dims["hash_off"]:])
+    oracle.lib().eazo_xxhash_indices(io.ctypes.data, 2, dims["hash_len"], 24, idx.ctypes.data)
+    assert idx[0] == idx[1]
+    oracle.lib().eazo_hash_update(bs.ctypes.data, idx[:1].ctypes.data, 1)
+    net = oracle.OracleNet(dims["in_dim"], 256, W, eaz.params.fc_weight_list(params), hash_off=dims["hash_off"],
+                           hash_len=dims["hash_len"], bitset=bs)
+    nov = net.forward(obs)[4]
+    assert (nov == 0).all()  # both observations share the IO slice that was marked seen
