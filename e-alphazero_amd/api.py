@@ -1,0 +1,571 @@
+"""Host-side mirror of the reference's Python interface for the self-play hot path, backed by libeaz.so.
+
+Names, argument meaning and call shapes follow the reference so that `src/selfplay.py`'s call sites read the same:
+
+    reference (JAX)                                                   this module
+    ---------------------------------------------------------------   ------------------------------------------
+    jax.random.PRNGKey / split                                        random.PRNGKey / random.split
+    jax.vmap(env.init)(keys), jax.vmap(env.step)(s, a, keys)          vmap(env.init)(keys), vmap(env.step)(s, a, keys)
+    auto_reset(env.step, env.init)            selfplay.py:26-75       auto_reset(env.step, env.init)
+    DeepSea(size_of_grid, action_map_key)     envs/deep_sea.py:37     DeepSea(size_of_grid, action_map_key)
+    Subleq(tasks, word_size, use_binary_encoding) envs/subleq.py:599  Subleq(tasks, word_size, use_binary_encoding=...)
+    get_forward_fn(env, config).apply(...)    context.py:86-106       get_forward_fn(env, config).apply(...)
+    get_epistemic_recurrent_fn(...)           context.py:109-157      get_epistemic_recurrent_fn(...)
+    emctx.EpistemicRootFnOutput / EpistemicRecurrentFnOutput          EpistemicRootFnOutput / EpistemicRecurrentFnOutput
+    emctx.epistemic_gumbel_muzero_policy      selfplay.py:107-117     epistemic_gumbel_muzero_policy
+    emctx.epistemic_qtransform_completed_by_mix_value                 epistemic_qtransform_completed_by_mix_value
+    policy_output.search_tree.epistemic_summary()  selfplay.py:119    same
+    selfplay(model, config, context, last_states, rng_key)            same (fused native driver)
+    uniformrandomplay(config, context, rng_key)                       same
+
+Arrays are torch ROCm tensors.  A batch of keys is a `KeyBatch` (parent key + count); per-element keys are derived on
+the device as fold(parent, index), which is what makes `vmap(env.init)(keys)` a single kernel launch.
+"""
+from __future__ import annotations
+
+import dataclasses
+import enum
+import functools
+from typing import Any, Callable, NamedTuple, Optional
+
+import numpy as np
+import torch
+
+from . import engine, params as params_lib
+from ._lib import EazError
+
+# ------------------------------------------------------------------------------------------------------------------
+# random
+# ------------------------------------------------------------------------------------------------------------------
+
+
+class KeyBatch(NamedTuple):
+    parent: int
+    num: int
+
+    def __len__(self):
+        return self.num
+
+
+class random:  # noqa: N801  (namespace mirroring jax.random)
+    @staticmethod
+    def PRNGKey(seed: int) -> int:  # noqa: N802
+        return engine.as_key(int(seed))
+
+    @staticmethod
+    def split(key, num: int = 2):
+        """num <= 8: a tuple of child keys (unpackable like jax.random.split); larger: a KeyBatch for vmapped calls."""
+        k = key.parent if isinstance(key, KeyBatch) else engine.as_key(key)
+        if num <= 8:
+            return tuple(engine.fold(k, 0x5000 + i) for i in range(num))
+        return KeyBatch(engine.fold(k, 0x5FFF), num)
+
+    @staticmethod
+    def fold_in(key, data: int) -> int:
+        return engine.fold(key, 0x6000 + int(data))
+
+
+def _batch_key(keys) -> tuple[int, Optional[int]]:
+    if isinstance(keys, KeyBatch):
+        return keys.parent, keys.num
+    return engine.as_key(keys), None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# environments (pgx.Env / pgx.State surface)
+# ------------------------------------------------------------------------------------------------------------------
+
+
+class State:
+    """pgx.State-shaped view over a batch of compact device states ([..., state_bytes] uint8)."""
+
+    def __init__(self, env: "Env", data: torch.Tensor):
+        self.env, self.data = env, data
+        self._fields = None
+
+    def _f(self):
+        if self._fields is None:
+            self._fields = self.env._h.fields(self.data)
+        return self._fields
+
+    @property
+    def observation(self) -> torch.Tensor:
+        obs = self.env._h.observe(self.data)
+        return obs.reshape(*self.data.shape[:-1], *self.env._h.obs_shape).bool()
+
+    @property
+    def legal_action_mask(self) -> torch.Tensor:
+        return self._f()["legal_action_mask"]
+
+    @property
+    def rewards(self) -> torch.Tensor:
+        return self._f()["rewards"]
+
+    @property
+    def terminated(self) -> torch.Tensor:
+        return self._f()["terminated"]
+
+    @property
+    def truncated(self) -> torch.Tensor:
+        return self._f()["truncated"]
+
+    @property
+    def current_player(self) -> torch.Tensor:
+        return torch.zeros(self.data.shape[:-1], dtype=torch.int32, device=self.data.device)
+
+    @property
+    def _step_count(self) -> torch.Tensor:
+        return self._f()["step_count"]
+
+    @property
+    def env_id(self) -> str:
+        return self.env.id
+
+    def __getitem__(self, idx) -> "State":
+        return State(self.env, self.data[idx])
+
+    @property
+    def shape(self):
+        return tuple(self.data.shape[:-1])
+
+
+class Env:
+    """pgx.Env surface.  `init` / `step` operate on batches; wrap them in `vmap` to keep the reference's call sites."""
+
+    _h: engine.EnvHandle
+    id: str = ""
+    version: str = "0.0.1"
+    num_players: int = 1
+
+    @property
+    def num_actions(self) -> int:
+        return self._h.num_actions
+
+    @property
+    def observation_shape(self):
+        return self._h.obs_shape
+
+    def init(self, key, batch_size: Optional[int] = None) -> State:
+        k, n = _batch_key(key)
+        n = batch_size if batch_size is not None else (n or 1)
+        return State(self, self._h.init(n, k))
+
+    def step(self, state: State, action: torch.Tensor, key=None) -> State:
+        k, _ = _batch_key(0 if key is None else key)
+        return State(self, self._h.step(state.data, action, k, autoreset=False))
+
+    def observe(self, state: State, player_id=None) -> torch.Tensor:
+        return state.observation
+
+
+class DeepSea(Env):
+    """src/envs/deep_sea.py:30-102.  `action_map_key`: None -> identity map; otherwise Bernoulli(0.5) drawn from the key
+    (NumPy generator; the reference draws it with jax.random.bernoulli, deep_sea.py:50-52).  `action_map` may be given explicitly."""
+
+    id = "deep_sea"
+
+    def __init__(self, size_of_grid: int = 4, action_map_key=None, action_map: Optional[np.ndarray] = None, device=None):
+        self.size_of_grid = size_of_grid
+        if action_map is None:
+            action_map = np.zeros((size_of_grid, size_of_grid), np.uint8)
+            if action_map_key is not None:
+                rng = np.random.default_rng(engine.as_key(action_map_key))
+                action_map = (rng.random((size_of_grid, size_of_grid)) < 0.5).astype(np.uint8)
+        self.action_map = np.ascontiguousarray(action_map, np.uint8).reshape(size_of_grid, size_of_grid)
+        self._h = engine.EnvHandle.deepsea(size_of_grid, self.action_map, device=device)
+
+
+class SubleqTask(enum.IntEnum):  # src/envs/subleq.py:110-124
+    NEGATION_POSITIVE = 1
+    NEGATION = 2
+    IDENTITY = 3
+    SUBTRACTION = 4
+    ADDITION = 5
+    MAXIMUM = 6
+    MINIMUM = 7
+    COMPARISON = 8
+    SORT_2 = 9
+    SORT_3 = 10
+    SORT_4 = 11
+    MULTIPLICATION = 12
+    DIVISION = 13
+    SUMMATION = 14
+
+
+class Subleq(Env):
+    """src/envs/subleq.py:571-724 (reward_fn = solved_or_not)."""
+
+    id = "subleq"
+
+    def __init__(self, tasks, word_size: int = 256, use_binary_encoding: bool = False, device=None):
+        if not 16 <= word_size <= 256:
+            raise AssertionError("16 <= word_size <= 256 (subleq.py:606)")
+        self.tasks = [int(t) for t in tasks]
+        self.word_size = word_size
+        self.use_binary_encoding = use_binary_encoding
+        self._h = engine.EnvHandle.subleq(word_size, self.tasks, use_binary_encoding, device=device)
+
+
+class _Vmapped:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, *args):
+        return self.fn(*args)
+
+
+def vmap(fn: Callable) -> Callable:
+    """jax.vmap stand-in for the engine's natively batched callables (env.init, env.step, auto_reset(...))."""
+    return _Vmapped(fn)
+
+
+def auto_reset(step_fn, init_fn):
+    """src/selfplay.py:26-75: reset the environment if the state is ALREADY terminal, otherwise step."""
+    env = step_fn.__self__
+
+    def wrapped_step_fn(state: State, action: torch.Tensor, key=None) -> State:
+        assert key is not None, "auto_reset needs a PRNGKey as third argument (selfplay.py:49-54)"
+        k, _ = _batch_key(key)
+        return State(env, env._h.step(state.data, action, k, autoreset=True))
+
+    return wrapped_step_fn
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# config / network
+# ------------------------------------------------------------------------------------------------------------------
+
+
+@dataclasses.dataclass(eq=False)
+class Config:
+    """The fields of src/config.py:10-99 that the self-play hot path reads, same names and defaults."""
+
+    env_id: str = "deep_sea-32"
+    subleq_tasks: tuple = ("NEGATION_POSITIVE",)
+    use_binary_encoding: bool = True
+    two_players_game: bool = False
+    linear_layer_size: int = 256
+    hash_class: str = "XXHash"
+    max_epistemic_variance_reward: float = 1.0
+    subleq_hash_only_io: bool = True
+    max_ube: float = 1.0
+    selfplay_batch_size: int = 128
+    selfplay_simulations_per_step: int = 32
+    selfplay_steps: int = 32
+    directed_exploration: bool = False
+    sample_actions: bool = False
+    sample_from_improved_policy: bool = False
+    rescale_q_values_in_search: bool = True
+    uniform_search_policy: bool = False
+    discount: float = 0.997
+    exploration_beta: float = 0.0
+
+    def __hash__(self):  # config.py:95-96
+        return 0
+
+
+class ForwardFn:
+    """hk.without_apply_rng(hk.transform_with_state(forward_fn)) of src/context.py:86-106 for the FC network."""
+
+    def __init__(self, env: Env, config: Config):
+        if config.hash_class != "XXHash":
+            raise EazError(f"hash_class {config.hash_class!r}: only XXHash is implemented natively (config.py:27 default)")
+        self.env, self.config = env, config
+        rows, cols = env.observation_shape
+        self.in_dim = rows * cols
+        self.hash_off = 0
+        if isinstance(env, Subleq) and config.subleq_hash_only_io:  # context.py:73, fully_connected.py:85-87
+            self.hash_off = env.word_size * cols
+        self._net: Optional[engine.FCNet] = None
+        self._model_id = None
+
+    def init(self, rng_key, dummy_input=None):
+        """-> (params, state) in the haiku layout (e-alphazero_amd/params.py)."""
+        seed = engine.as_key(rng_key) & 0x7FFFFFFF
+        return (params_lib.init_fc_params(self.in_dim, self.config.linear_layer_size, self.env.num_actions, seed),
+                params_lib.init_hash_state())
+
+    def net(self, model) -> engine.FCNet:
+        model_params, model_state = model
+        mid = (id(model_params), id(model_state))
+        if self._net is None:
+            # get_network does not forward max_ube / max_epistemic_variance_reward to the FC net (context.py:68-75)
+            self._net = engine.FCNet(self.env._h.ctx, self.in_dim, self.config.linear_layer_size, self.env.num_actions,
+                                     model_params, model_state, max_ube=1.0, max_epistemic_variance_reward=1.0,
+                                     hash_off=self.hash_off)
+        elif mid != self._model_id:
+            self._net.set_params(model_params)
+            self._net.set_state(model_state)
+        self._model_id = mid
+        return self._net
+
+    def apply(self, model_params, model_state, x: torch.Tensor, is_training: bool = False, update_hash: bool = False):
+        if is_training:
+            raise EazError("forward.apply(is_training=True) is the learner path and is out of scope for the self-play engine")
+        net = self.net((model_params, model_state))
+        lead = x.shape[: x.dim() - 2] if x.dim() > 2 else x.shape[:1]
+        ex, xp, v, u, nov = net.forward(x)
+        if update_hash:
+            net.hash_update(x)
+            model_state = net.get_state()
+        A = self.env.num_actions
+        return (ex.reshape(*lead, A), xp.reshape(*lead, A), v.reshape(lead), u.reshape(lead), nov.reshape(lead)), model_state
+
+
+def get_forward_fn(env: Env, config: Config) -> ForwardFn:
+    return ForwardFn(env, config)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# emctx surface
+# ------------------------------------------------------------------------------------------------------------------
+
+
+class EpistemicRootFnOutput(NamedTuple):
+    prior_logits: Any
+    value: Any
+    value_epistemic_variance: Any
+    embedding: Any
+    beta: Any
+
+
+class EpistemicRecurrentFnOutput(NamedTuple):
+    reward: Any
+    reward_epistemic_variance: Any
+    discount: Any
+    prior_logits: Any
+    value: Any
+    value_epistemic_variance: Any
+
+
+class EpistemicSearchSummary(NamedTuple):
+    visit_counts: torch.Tensor
+    visit_probs: torch.Tensor
+    value: torch.Tensor
+    value_epistemic_std: torch.Tensor
+    qvalues: torch.Tensor
+    qvalues_epistemic_variance: torch.Tensor
+
+
+class SearchTree:
+    """emctx EpistemicTree view.  Field access copies the device array (mctx field names)."""
+
+    def __init__(self, search: engine.Search):
+        self._search = search
+
+    def epistemic_summary(self) -> EpistemicSearchSummary:
+        s = self._search.summary()
+        return EpistemicSearchSummary(s["visit_counts"], s["visit_probs"], s["value"], s["value_epistemic_std"], s["qvalues"],
+                                      s["qvalues_epistemic_variance"])
+
+    summary = epistemic_summary
+
+    def __getattr__(self, name):
+        if name in engine.TREE_FIELDS:
+            return self._search.field(name)
+        raise AttributeError(name)
+
+
+class PolicyOutput(NamedTuple):
+    action: torch.Tensor
+    action_weights: torch.Tensor
+    search_tree: SearchTree
+
+
+def epistemic_qtransform_completed_by_mix_value(*args, value_scale: float = 0.1, maxvisit_init: float = 50.0,
+                                                rescale_values: bool = True, use_mixed_value: bool = True, **kw):
+    """Marker for the qtransform argument; evaluated inside the tree kernel (csrc/tree.hpp: qtransform)."""
+    raise EazError("the qtransform runs on the device; pass this function (or functools.partial of it) as `qtransform=`")
+
+
+def _qtransform_opts(qtransform) -> dict:
+    opts = dict(value_scale=0.1, maxvisit_init=50.0, rescale_values=True, use_mixed_value=True)
+    fn = qtransform
+    if isinstance(fn, functools.partial):
+        opts.update(fn.keywords)
+        fn = fn.func
+    if fn is not epistemic_qtransform_completed_by_mix_value:
+        raise EazError("only epistemic_qtransform_completed_by_mix_value is implemented (the one src/ uses)")
+    return opts
+
+
+class NativeRecurrentFn:
+    """Product of get_epistemic_recurrent_fn: the fused device implementation of src/context.py:117-155.  Also callable
+    with the reference's signature (model, rng_key, action, state) -> (EpistemicRecurrentFnOutput, state)."""
+
+    def __init__(self, env: Env, forward: ForwardFn, batch_size: int, exploration: bool, discount: float, two_players_game: bool):
+        self.env, self.forward, self.batch_size = env, forward, batch_size
+        self.exploration, self.discount, self.two_players_game = exploration, discount, two_players_game
+
+    def __call__(self, model, rng_key, action: torch.Tensor, state: State):
+        model_params, model_state = model
+        nxt = self.env.step(state, action, rng_key)                                           # context.py:127
+        (ex, xp, value, var, _), _ = self.forward.apply(model_params, model_state, nxt.observation)  # :129-131
+        logits = xp if self.exploration else ex                                               # :132
+        logits = logits - logits.max(dim=-1, keepdim=True).values                             # :135
+        logits = torch.where(nxt.legal_action_mask, logits, torch.finfo(torch.float32).min)   # :137
+        term = nxt.terminated
+        reward = nxt.rewards[:, 0]                                                            # :139 (single player)
+        value = torch.where(term, 0.0, value)                                                 # :140
+        var = torch.where(term, 0.0, var)                                                     # :141
+        disc = torch.full_like(value, self.discount) * (-1.0 if self.two_players_game else 1.0)  # :142-143
+        disc = torch.where(term, 0.0, disc)                                                   # :144
+        return EpistemicRecurrentFnOutput(reward, torch.zeros_like(reward), disc, logits, value, var), nxt
+
+
+def get_epistemic_recurrent_fn(env: Env, forward: ForwardFn, batch_size: int, exploration: bool, discount: float,
+                               two_players_game: bool) -> NativeRecurrentFn:
+    return NativeRecurrentFn(env, forward, batch_size, exploration, discount, two_players_game)
+
+
+_search_cache: dict = {}
+
+
+def _get_search(rf: NativeRecurrentFn, model, B: int, S: int, qopts: dict, max_considered: int, gumbel_scale: float,
+                max_depth) -> engine.Search:
+    net = rf.forward.net(model)
+    key = (id(rf), B, S, tuple(sorted(qopts.items())), max_considered, float(gumbel_scale), max_depth)
+    if key not in _search_cache:
+        _search_cache[key] = engine.Search(rf.env._h, net, B, S, discount=rf.discount, two_players_game=rf.two_players_game,
+                                           exploration=rf.exploration, rescale_values=qopts["rescale_values"],
+                                           use_mixed_value=qopts["use_mixed_value"], value_scale=qopts["value_scale"],
+                                           maxvisit_init=qopts["maxvisit_init"], max_num_considered_actions=max_considered,
+                                           gumbel_scale=gumbel_scale, max_depth=max_depth)
+    return _search_cache[key]
+
+
+def _gumbel_noise(rng_key, B: int, A: int, scale: float, device) -> torch.Tensor:
+    """Root noise from the engine's key stream (same derivation as the fused driver's generated noise is NOT implied;
+    callers that need reproducibility across paths pass `gumbel=` explicitly)."""
+    g = torch.Generator(device="cpu").manual_seed(engine.as_key(rng_key) & 0x7FFFFFFFFFFFFFFF)
+    u = torch.rand(B, A, generator=g, dtype=torch.float64).clamp_min(1e-38)
+    return (scale * -torch.log(-torch.log(u))).to(torch.float32).to(device)
+
+
+def epistemic_gumbel_muzero_policy(params, rng_key, root: EpistemicRootFnOutput, recurrent_fn, num_simulations: int,
+                                   invalid_actions=None, max_depth=None, *,
+                                   qtransform=epistemic_qtransform_completed_by_mix_value, max_num_considered_actions: int = 16,
+                                   gumbel_scale: float = 1.0, gumbel: Optional[torch.Tensor] = None) -> PolicyOutput:
+    """emctx.epistemic_gumbel_muzero_policy (call site src/selfplay.py:107-117).
+
+    `recurrent_fn` produced by get_epistemic_recurrent_fn runs fully fused on the device.  Any other callable with the
+    emctx signature is honoured through the generic path: one select kernel, the Python callback, one expand kernel per
+    simulation.  `gumbel` (already scaled, [B, A]) overrides the generated root noise.
+    """
+    qopts = _qtransform_opts(qtransform)
+    logits = root.prior_logits
+    B, A = logits.shape
+    dev = logits.device
+    g = gumbel if gumbel is not None else _gumbel_noise(rng_key, B, A, gumbel_scale, dev)
+    if isinstance(recurrent_fn, NativeRecurrentFn) and isinstance(root.embedding, State):
+        s = _get_search(recurrent_fn, params, B, num_simulations, qopts, max_num_considered_actions, gumbel_scale, max_depth)
+        s.begin(logits, root.value, root.value_epistemic_variance, root.embedding.data, root.beta, invalid_actions, g)
+        s.run()
+        action, weights = s.finish()
+        return PolicyOutput(action, weights, SearchTree(s))
+    return _generic_policy(params, rng_key, root, recurrent_fn, num_simulations, invalid_actions, max_depth, qopts,
+                           max_num_considered_actions, gumbel_scale, g)
+
+
+class _NullNet:
+    pass
+
+
+def _generic_policy(params, rng_key, root, recurrent_fn, S, invalid_actions, max_depth, qopts, max_considered, gumbel_scale, g):
+    """Arbitrary Python recurrent_fn: tree statistics on the device, embeddings kept as [B, N, ...] torch buffers."""
+    logits = root.prior_logits
+    B, A = logits.shape
+    dev = logits.device
+    emb = root.embedding
+    is_state = isinstance(emb, State)
+    leaves = {"_": emb.data} if is_state else (emb if isinstance(emb, dict) else {"_": emb})
+    store = {k: torch.zeros((B, S + 1) + tuple(v.shape[1:]), dtype=v.dtype, device=dev) for k, v in leaves.items()}
+    for k, v in leaves.items():
+        store[k][:, 0] = v
+    # a Search object needs an env + net for its workspace; the generic path never launches their kernels, so any
+    # env/net of matching action count works -- use a DeepSea-sized dummy when A == 2, otherwise require a native env
+    env_h = emb.env._h if is_state else None
+    if env_h is None:
+        raise EazError("generic recurrent_fn path: embedding must be a State of a native Env (tree workspace is sized from it)")
+    net = _dummy_net(env_h)
+    s = engine.Search(env_h, net, B, S, rescale_values=qopts["rescale_values"], use_mixed_value=qopts["use_mixed_value"],
+                      value_scale=qopts["value_scale"], maxvisit_init=qopts["maxvisit_init"],
+                      max_num_considered_actions=max_considered, gumbel_scale=gumbel_scale, max_depth=max_depth)
+    s.begin(logits, root.value, root.value_epistemic_variance, emb.data, root.beta, invalid_actions, g)
+    ar = torch.arange(B, device=dev)
+    key = engine.as_key(rng_key)
+    for sim in range(S):
+        parent, action, nxt = s.select(sim)
+        gathered = {k: v[ar, parent.long()] for k, v in store.items()}
+        e_in = State(emb.env, gathered["_"]) if is_state else (gathered if isinstance(emb, dict) else gathered["_"])
+        out, e_out = recurrent_fn(params, engine.fold(key, sim), action, e_in)
+        new_leaves = {"_": e_out.data} if is_state else (e_out if isinstance(e_out, dict) else {"_": e_out})
+        for k, v in new_leaves.items():
+            store[k][ar, nxt.long()] = v
+        s.expand(sim, out.reward, out.reward_epistemic_variance, out.discount, out.prior_logits, out.value,
+                 out.value_epistemic_variance)
+    action, weights = s.finish()
+    return PolicyOutput(action, weights, SearchTree(s))
+
+
+_dummy_nets: dict = {}
+
+
+def _dummy_net(env_h: engine.EnvHandle) -> engine.FCNet:
+    k = id(env_h)
+    if k not in _dummy_nets:
+        rows, cols = env_h.obs_shape
+        p = params_lib.init_fc_params(rows * cols, 256, env_h.num_actions, seed=0)
+        hl = (rows * cols) - ((rows * cols) % 4)
+        _dummy_nets[k] = engine.FCNet(env_h.ctx, rows * cols, 256, env_h.num_actions, p, None, hash_len=hl)
+    return _dummy_nets[k]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# selfplay (src/selfplay.py)
+# ------------------------------------------------------------------------------------------------------------------
+
+
+class Context(NamedTuple):
+    """The fields of src/context.py:18-38 the self-play path uses."""
+
+    env: Env
+    devices: list
+    forward: ForwardFn
+    selfplay_recurrent_fn: NativeRecurrentFn
+
+
+class SelfplayOutput(NamedTuple):  # src/selfplay.py:17-23
+    state: State
+    root_value: torch.Tensor
+    root_epistemic_std: torch.Tensor
+    value_prediction: torch.Tensor
+    ube_prediction: torch.Tensor
+    q_values_epistemic_variance: torch.Tensor
+
+
+def selfplay(model, config: Config, context: Context, last_states: State, rng_key,
+             gumbel: Optional[torch.Tensor] = None) -> tuple[State, SelfplayOutput]:
+    """src/selfplay.py:78-149 as ONE native call (eaz_selfplay_run): T = config.selfplay_steps real steps of root inference ->
+    search -> action choice -> auto-reset env step.  Returns (last_states, SelfplayOutput[T, B, ...])."""
+    rf = context.selfplay_recurrent_fn
+    B = last_states.data.shape[0]
+    qopts = dict(value_scale=0.1, maxvisit_init=50.0, rescale_values=config.rescale_q_values_in_search, use_mixed_value=True)
+    s = _get_search(rf, model, B, config.selfplay_simulations_per_step, qopts, 16, 1.0, None)
+    states = last_states.data.clone()
+    out = s.selfplay(states, config.selfplay_steps, key=rng_key, gumbel=gumbel,
+                     directed_exploration=config.directed_exploration,
+                     exploration_beta=config.exploration_beta if config.directed_exploration else 0.0,  # config.py:172
+                     uniform_search_policy=config.uniform_search_policy, sample_actions=config.sample_actions,
+                     sample_from_improved_policy=config.sample_from_improved_policy)
+    env = context.env
+    return State(env, states), SelfplayOutput(State(env, out["state"]), out["root_value"], out["root_epistemic_std"],
+                                              out["value_prediction"], out["ube_prediction"], out["q_values_epistemic_variance"])
+
+
+def uniformrandomplay(config: Config, context: Context, rng_key) -> tuple[State, State]:
+    """src/selfplay.py:152-170: init, then selfplay_steps uniformly random auto-reset steps; returns (last_states, states[T, B])."""
+    env = context.env
+    last, traj = env._h.random_play(config.selfplay_batch_size // max(len(context.devices), 1), config.selfplay_steps,
+                                    key=rng_key, want_traj=True)
+    return State(env, last), State(env, traj)
