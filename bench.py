@@ -97,15 +97,24 @@ def main():
 
     for i in range(args.warmup):
         one_step(-1 - i)
-    # timed region: EXACTLY K steps; HIP events around every FC-forward and leaf-gather launch feed the roofline objects
-    search.profile(True)
-    search.profile_read(reset=True)
+    # ---- timed region: EXACTLY K steps in the production configuration (one captured hipGraph per real step) ----
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
     sync()
     dt = time.perf_counter() - t0
+    # ---- instrumented pass: the same K steps again with HIP events recorded on the launch stream around every kernel
+    # (event records cannot sit between the nodes of a replayed graph, so this pass uses plain stream launches; kernel
+    # durations are unaffected, only the host-side launch gaps differ).  Feeds `roofline`, never `value`. ----
+    search.profile(True)
+    search.profile_read(reset=True)
+    sync()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        outputs = search.selfplay(states, T, key=(1000 * rank + 500 + i), outputs=outputs, use_graph=False)
+    sync()
+    dt_instr = time.perf_counter() - t1
     prof = search.profile_read(reset=True)
     search.profile(False)
     if dist is not None:
@@ -132,14 +141,22 @@ def main():
                    "global_batch": B * n_gpus, "parallelism": f"batch-sharded x{n_gpus}, RCCL all-gather of trajectories" if n_gpus > 1 else "single GPU"},
     }
     # ---- roofline of the dominant kernel (fused FC forward; 3 heads evaluated: value, ube, exploitation) -----------
+    # `achieved` counts the FLOPs the kernel EXECUTED: layers 2-3 are dense; in layer 1 every 64x4 observation block that
+    # is entirely zero is skipped (exact: fma(0,w,acc)=acc), so executed <= dense.  `dense_equiv` prices the same
+    # launches at the dense count of SURVEY.md 8(d) (2 * MACs of every layer).
     heads = (0, 1, 2)
-    flops = fc_flops_per_eval(G * G, H, A, heads) * B
-    net_ms = prof["net"]["ms"] / max(prof["net"]["launches"], 1)
+    n_launch = max(prof["net"]["launches"], 1)
+    dense_flops = fc_flops_per_eval(G * G, H, A, heads) * B
+    l23 = sum(2 * (H * H + H * (1 if h < 2 else A)) for h in heads) * B
+    l1_exec = prof["net"]["layer1_ksteps"] * (64 * H * 4 * 2) / n_launch
+    flops = l23 + l1_exec
+    net_ms = prof["net"]["ms"] / n_launch
     ach = flops / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0
     result["roofline"] = {"kernel": "fc_forward_kernel", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                           "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                           "avg_launch_us": 1e3 * net_ms, "launches": prof["net"]["launches"],
-                          "flops_per_launch": flops}
+                          "flops_per_launch": flops, "dense_flops_per_launch": dense_flops,
+                          "dense_equiv_tflops": dense_flops / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0}
     # leaf gather: algorithmic bytes on the engine's compact layout = parent state + child state + observation row
     gbytes = B * (2 * env.state_bytes + env.obs_dim)
     g_ms = prof["gather"]["ms"] / max(prof["gather"]["launches"], 1)
@@ -147,7 +164,8 @@ def main():
     result["roofline_gather"] = {"kernel": "leaf_gather_deepsea_kernel", "bound": "hbm", "achieved": gach, "peak": PEAK_HBM_GBPS,
                                  "unit": "GB/s", "frac": gach / PEAK_HBM_GBPS, "traffic": None, "avg_launch_us": 1e3 * g_ms,
                                  "launches": prof["gather"]["launches"], "bytes_per_launch": gbytes}
-    result["kernel_ms"] = {k: round(v["ms"], 3) for k, v in prof.items()}
+    result["kernel_ms_instrumented_pass"] = {k: round(v["ms"], 3) for k, v in prof.items()}
+    result["instrumented_pass_env_steps_per_s"] = B * T * args.steps / dt_instr
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload, rank 0 at N = 1 only -------------------
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:

@@ -96,4 +96,11 @@ EAZ_HD float det_tanh(float x) {
     return __builtin_fmaf(p * z, x, x);
 }
 
+// fully_connected.py:92-96 (not is_training): u = clip(max(scaled_state_novelty, u * max_u), 0, max_u); `u_scaled` = u * max_u
+EAZ_HD float ube_combine(float u_scaled, float novelty, float max_u) {
+    float u = novelty > u_scaled ? novelty : u_scaled;
+    u = u < 0.0f ? 0.0f : u;
+    return u > max_u ? max_u : u;
+}
+
 }  // namespace eaz

@@ -66,6 +66,8 @@ struct eaz_net {
     float* d_w[12];
     float* d_b[12];
     size_t bitset_bytes;
+    unsigned long long* d_kstep_counter;  // executed layer-1 k-steps (profiling only; nullptr = off)
+    unsigned long long* d_kstep_storage;
 };
 
 struct ProfSpan {
@@ -95,9 +97,16 @@ struct eaz_search {
     int prof_on;
     std::vector<ProfSpan> spans;
     std::vector<hipEvent_t> ev_pool;
-    // graph replay of one real step
+    // side stream for the novelty lookup (fork/join around every network forward)
+    hipStream_t side, main;
+    hipEvent_t ev_fork, ev_join, ev_in, ev_out;
+    float graph_beta;
+    // per-real-step staging (fixed addresses so that one captured hipGraph serves every step) + the graph itself
+    float *d_root_v, *d_root_u, *d_sum_value, *d_sum_std, *d_sum_qvar, *d_gumbel_stage;
+    Key* d_step_keys;  // [4]: gumbel, env, sample-visits, sample-improved keys of the current real step
     hipGraphExec_t step_graph;
-    bool step_graph_valid;
+    const void* graph_states;  // the captured graph is valid for this d_states pointer / these flags
+    int graph_flags;
     int pending_expand;  // simulation whose expand+backward has not run yet (-1: none)
 };
 
@@ -193,7 +202,7 @@ extern "C" int eaz_env_info(const eaz_env* env, int* kind, int* num_actions, int
 
 // mode: 0 step, 1 auto-reset step, 2 init.  src/dst: plain [B] batches.
 static int env_step_launch(eaz_env* env, int B, const void* in, const int32_t* action, Key key, int mode, void* out,
-                           void* out_copy, hipStream_t st) {
+                           void* out_copy, hipStream_t st, const Key* d_key = nullptr) {
     if (B <= 0) return 0;
     if (env->dev.kind == EAZ_ENV_DEEPSEA) {
         deepsea_step_kernel<<<cdiv(B, 256), 256, 0, st>>>(env->dev, static_cast<const char*>(in), action, B, mode,
@@ -201,7 +210,7 @@ static int env_step_launch(eaz_env* env, int B, const void* in, const int32_t* a
     } else {
         StateRef src{const_cast<char*>(static_cast<const char*>(in ? in : out)), nullptr, 1};
         StateRef dst{static_cast<char*>(out), nullptr, 1};
-        subleq_step_kernel<<<cdiv(B, 64), 192, 192 * env->dev.W, st>>>(env->dev, src, dst, action, B, mode, key,
+        subleq_step_kernel<<<cdiv(B, 64), 192, 192 * env->dev.W, st>>>(env->dev, src, dst, action, B, mode, key, d_key,
                                                                          static_cast<char*>(out_copy), nullptr, nullptr, nullptr);
     }
     LAUNCH_OK();
@@ -279,6 +288,11 @@ extern "C" int eaz_net_create_fc(eaz_ctx* ctx, int in_dim, int hidden, int num_a
     if (n->bitset_bytes < 4) n->bitset_bytes = 4;
     HIP_OK(hipMalloc(&n->dev.bitset, n->bitset_bytes));
     HIP_OK(hipMemset(n->dev.bitset, 0, n->bitset_bytes));
+    if (in_dim > 256 * kFcMaxBlocks) return fail("observation size %d exceeds the FC kernel's limit %d", in_dim, 256 * kFcMaxBlocks);
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kFcLdsBytes));
+    HIP_OK(hipMalloc(&n->d_kstep_storage, sizeof(unsigned long long)));
+    HIP_OK(hipMemset(n->d_kstep_storage, 0, sizeof(unsigned long long)));
+    n->d_kstep_counter = nullptr;
     *out = n;
     return 0;
 }
@@ -287,6 +301,7 @@ extern "C" int eaz_net_destroy(eaz_net* n) {
     if (!n) return 0;
     for (int l = 0; l < 12; ++l) { (void)hipFree(n->d_w[l]); (void)hipFree(n->d_b[l]); }
     (void)hipFree(n->dev.bitset);
+    (void)hipFree(n->d_kstep_storage);
     delete n;
     return 0;
 }
@@ -332,7 +347,7 @@ static int fc_launch(eaz_net* n, int B, const uint8_t* obs, const NetOut& o, con
         cmin = c < cmin ? c : cmin;
     }
     const int grid = 8 * cdiv(n_tiles, cmin);
-    fc_forward_kernel<<<grid, 256, 0, st>>>(n->dev, obs, B, o, heads);
+    fc_forward_kernel<<<grid, 256, kFcLdsBytes, st>>>(n->dev, obs, B, o, heads, n->d_kstep_counter);
     LAUNCH_OK();
     return 0;
 }
@@ -356,10 +371,15 @@ extern "C" int eaz_net_forward(eaz_net* n, int B, const uint8_t* d_obs, float* d
     if (d_ube) hl.id[hl.n++] = 1;
     if (d_exploit) hl.id[hl.n++] = 2;
     if (d_explore) hl.id[hl.n++] = 3;
-    NetOut o{d_exploit, d_explore, d_value, d_ube, nov};
+    NetOut o{d_exploit, d_explore, d_value, d_ube};
     int rc = fc_launch(n, B, d_obs, o, hl, S(stream));
+    if (rc) return rc;
+    if (d_ube) {
+        ube_combine_kernel<<<cdiv(B, 256), 256, 0, S(stream)>>>(d_ube, nov, n->dev.max_u, B);
+        LAUNCH_OK();
+    }
     if (tmp) HIP_OK(hipFreeAsync(tmp, S(stream)));
-    return rc;
+    return 0;
 }
 
 extern "C" int eaz_hash_lookup(eaz_net* n, int B, const uint8_t* d_obs, uint8_t* d_seen, uint32_t* d_indices, void* stream) {
@@ -454,7 +474,14 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     eaz_search* s = new eaz_search();
     s->ctx = ctx; s->env = env; s->net = net; s->opts = *opts;
     s->B = B; s->S = opts->num_simulations; s->N = s->S + 1; s->A = env->dev.A;
-    s->prof_on = 0; s->step_graph = nullptr; s->step_graph_valid = false; s->pending_expand = -1;
+    s->prof_on = 0; s->step_graph = nullptr; s->graph_states = nullptr; s->graph_flags = -1; s->pending_expand = -1;
+    HIP_OK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&s->main, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
+    s->graph_beta = 0.0f;
+    HIP_OK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
     const int A = s->A;
     int p2 = 2;
     while (p2 < A) p2 <<= 1;
@@ -493,7 +520,10 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     DALLOC(s->d_aw, static_cast<size_t>(B) * A); DALLOC(s->d_vprobs, static_cast<size_t>(B) * A);
     DALLOC(s->d_root_invalid, static_cast<size_t>(B) * A); DALLOC(s->d_legal, static_cast<size_t>(B) * A); DALLOC(s->d_action, B);
     t.net_logits = opts->exploration ? s->d_explore : s->d_exploit;  // context.py:132
-    t.net_value = s->d_v; t.net_ube = s->d_u;
+    t.net_value = s->d_v; t.net_ube = s->d_u; t.net_novelty = s->d_novelty; t.max_u = net->dev.max_u;
+    DALLOC(s->d_root_v, B); DALLOC(s->d_root_u, B); DALLOC(s->d_sum_value, B); DALLOC(s->d_sum_std, B);
+    DALLOC(s->d_sum_qvar, static_cast<size_t>(B) * A); DALLOC(s->d_gumbel_stage, static_cast<size_t>(B) * A);
+    DALLOC(s->d_step_keys, 4);
     t.next_reward = s->d_next_reward; t.next_term = s->d_next_term; t.next_legal = s->d_next_legal;
     *out = s;
     return 0;
@@ -505,6 +535,12 @@ extern "C" int eaz_search_destroy(eaz_search* s) {
     for (auto& sp : s->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto& e : s->ev_pool) (void)hipEventDestroy(e);
     if (s->step_graph) (void)hipGraphExecDestroy(s->step_graph);
+    if (s->side) (void)hipStreamDestroy(s->side);
+    if (s->main) (void)hipStreamDestroy(s->main);
+    (void)hipEventDestroy(s->ev_in);
+    (void)hipEventDestroy(s->ev_out);
+    (void)hipEventDestroy(s->ev_fork);
+    (void)hipEventDestroy(s->ev_join);
     delete s;
     return 0;
 }
@@ -541,6 +577,32 @@ static int tree_step_launch(eaz_search* s, int sim, int mode, hipStream_t st) {
     return 0;
 }
 
+// forward.apply on a batch of observations: the novelty lookup (hash_kernel, 4 lanes per sample, ~64 workgroups) and the
+// MFMA forward (192-256 workgroups) are independent, so the lookup is forked onto the search's side stream and joined
+// before the consumer of both (tree expand / root preparation applies ube_combine).
+static int infer_launch(eaz_search* s, const uint8_t* obs, float* novelty, const NetOut& o, const HeadList& hl, hipStream_t st) {
+    const int B = s->B;
+    hipStream_t hs = st;
+    if (s->side) {
+        HIP_OK(hipEventRecord(s->ev_fork, st));
+        HIP_OK(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+        hs = s->side;
+    }
+    {
+        ProfScope ps(s, EAZ_K_HASH, hs);
+        int rc = hash_launch(s->net, B, obs, novelty, nullptr, nullptr, 0, hs);
+        if (rc) return rc;
+    }
+    if (s->side) HIP_OK(hipEventRecord(s->ev_join, s->side));
+    {
+        ProfScope ps(s, EAZ_K_NET, st);
+        int rc = fc_launch(s->net, B, obs, o, hl, st);
+        if (rc) return rc;
+    }
+    if (s->side) HIP_OK(hipStreamWaitEvent(st, s->ev_join, 0));
+    return 0;
+}
+
 // leaf gather + env.step + observation (context.py:125-127), novelty lookup, network forward (context.py:129-131)
 static int recurrent_launch(eaz_search* s, hipStream_t st) {
     eaz_env* env = s->env;
@@ -555,25 +617,16 @@ static int recurrent_launch(eaz_search* s, hipStream_t st) {
             StateRef src{s->tree.embeddings, s->tree.sim_parent, s->N};
             StateRef dst{s->tree.embeddings, s->tree.sim_next, s->N};
             subleq_step_kernel<<<cdiv(B, 64), 192, 192 * env->dev.W, st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0},
-                                                                             nullptr, s->d_next_reward, s->d_next_term, s->d_next_legal);
+                                                                             nullptr, nullptr, s->d_next_reward, s->d_next_term,
+                                                                             s->d_next_legal);
             LAUNCH_OK();
             obs_emit_kernel<<<cdiv(static_cast<long>(B) * 64, 256), 256, 0, st>>>(env->dev, dst, B, s->d_obs);
             LAUNCH_OK();
         }
     }
-    {
-        ProfScope ps(s, EAZ_K_HASH, st);
-        int rc = hash_launch(s->net, B, s->d_obs, s->d_novelty, nullptr, nullptr, 0, st);
-        if (rc) return rc;
-    }
-    {
-        ProfScope ps(s, EAZ_K_NET, st);
-        HeadList hl{3, {0, 1, s->opts.exploration ? 3 : 2, 0}};
-        NetOut o{s->opts.exploration ? nullptr : s->d_exploit, s->opts.exploration ? s->d_explore : nullptr, s->d_v, s->d_u, s->d_novelty};
-        int rc = fc_launch(s->net, B, s->d_obs, o, hl, st);
-        if (rc) return rc;
-    }
-    return 0;
+    HeadList hl{3, {0, 1, s->opts.exploration ? 3 : 2, 0}};
+    NetOut o{s->opts.exploration ? nullptr : s->d_exploit, s->opts.exploration ? s->d_explore : nullptr, s->d_v, s->d_u};
+    return infer_launch(s, s->d_obs, s->d_novelty, o, hl, st);
 }
 
 extern "C" int eaz_search_simulate(eaz_search* s, int sim, void* stream) {
@@ -693,36 +746,32 @@ extern "C" int eaz_search_tree_view(eaz_search* s, int id, void** d_ptr, int64_t
 // ------------------------------------------------------------------------------------------------------------------
 // self-play driver (src/selfplay.py:78-149)
 // ------------------------------------------------------------------------------------------------------------------
-static int selfplay_step(eaz_search* s, const eaz_selfplay_cfg* cfg, Key kt, int step, void* d_states, const float* d_gumbel,
-                         void* d_out_states, float* d_out_root_value, float* d_out_root_std, float* d_out_value_pred,
-                         float* d_out_ube_pred, float* d_out_qvar, int32_t* d_out_action, hipStream_t st) {
+__global__ void set_step_keys_kernel(Key* keys, Key k0, Key k1, Key k2, Key k3) {
+    keys[0] = k0; keys[1] = k1; keys[2] = k2; keys[3] = k3;
+}
+
+enum : int { kFlagUniform = 1, kFlagSampleVisits = 2, kFlagSampleImproved = 4, kFlagExplicitGumbel = 8 };
+
+// One real step of step_fn (selfplay.py:86-143) on fixed addresses: everything that changes from step to step (keys, explicit
+// root noise, output slots) is read from / written to staging buffers, so the launch sequence can be captured ONCE into a
+// hipGraph and replayed (S+1 network forwards, S+1 tree kernels, ... = 4S+12 launches per real step).
+static int selfplay_step_body(eaz_search* s, const eaz_selfplay_cfg* cfg, int flags, void* d_states, hipStream_t st) {
     eaz_env* env = s->env;
     const int B = s->B, A = s->A;
-    const long tb = static_cast<long>(step) * B;
     int rc;
-    // root inference (selfplay.py:89-91): observation -> novelty -> value / ube / policy head
+    // root inference (selfplay.py:89-91): observation -> {novelty lookup || value / ube / policy heads}
     {
         ProfScope ps(s, EAZ_K_MISC, st);
         rc = obs_launch(env, B, d_states, s->d_obs, st);
         if (rc) return rc;
     }
-    {
-        ProfScope ps(s, EAZ_K_HASH, st);
-        rc = hash_launch(s->net, B, s->d_obs, s->d_novelty, nullptr, nullptr, 0, st);
-        if (rc) return rc;
-    }
     const bool explore = cfg->directed_exploration != 0;  // selfplay.py:93-95
     {
-        ProfScope ps(s, EAZ_K_NET, st);
         HeadList hl{3, {0, 1, explore ? 3 : 2, 0}};
-        // root outputs go to dedicated buffers: d_v/d_u are overwritten by the simulations
-        NetOut o{explore ? nullptr : s->d_root_logits, explore ? s->d_root_logits : nullptr,
-                 d_out_value_pred ? d_out_value_pred + tb : s->d_v, d_out_ube_pred ? d_out_ube_pred + tb : s->d_u, s->d_novelty};
-        rc = fc_launch(s->net, B, s->d_obs, o, hl, st);
+        NetOut o{explore ? nullptr : s->d_root_logits, explore ? s->d_root_logits : nullptr, s->d_root_v, s->d_root_u};
+        rc = infer_launch(s, s->d_obs, s->d_novelty, o, hl, st);
         if (rc) return rc;
     }
-    const float* root_v = d_out_value_pred ? d_out_value_pred + tb : s->d_v;
-    const float* root_u = d_out_ube_pred ? d_out_ube_pred + tb : s->d_u;
     {
         ProfScope ps(s, EAZ_K_MISC, st);
         env_fields_kernel<<<cdiv(B, 256), 256, 0, st>>>(env->dev, static_cast<const char*>(d_states), B, nullptr, nullptr, nullptr,
@@ -730,34 +779,47 @@ static int selfplay_step(eaz_search* s, const eaz_selfplay_cfg* cfg, Key kt, int
         LAUNCH_OK();
         const float sbeta = explore ? cfg->exploration_beta : 0.0f;  // selfplay.py:92
         root_prep_kernel<<<cdiv(static_cast<long>(B) * A, 256), 256, 0, st>>>(
-            B, A, s->d_root_logits, cfg->uniform_search_policy, sbeta, s->d_legal,
-            d_gumbel ? d_gumbel + tb * A : nullptr, fold(kt, kTagGumbel), s->opts.gumbel_scale, s->d_root_logits, s->d_root_beta,
-            s->d_root_invalid, s->d_root_gumbel);
+            B, A, s->d_root_logits, (flags & kFlagUniform) != 0, sbeta, s->d_legal,
+            (flags & kFlagExplicitGumbel) ? s->d_gumbel_stage : nullptr, s->d_step_keys, s->opts.gumbel_scale, s->d_root_logits,
+            s->d_root_beta, s->d_root_invalid, s->d_root_gumbel, s->d_root_u, s->d_novelty, s->net->dev.max_u);
         LAUNCH_OK();
     }
-    rc = eaz_search_begin(s, s->d_root_logits, root_v, root_u, d_states, s->d_root_beta, s->d_root_invalid, s->d_root_gumbel, st);
+    rc = eaz_search_begin(s, s->d_root_logits, s->d_root_v, s->d_root_u, d_states, s->d_root_beta, s->d_root_invalid, s->d_root_gumbel, st);
     if (rc) return rc;
     rc = eaz_search_run(s, st);
     if (rc) return rc;
     rc = eaz_search_finish(s, s->d_action, s->d_aw, st);
     if (rc) return rc;
-    rc = eaz_search_summary(s, d_out_root_value ? d_out_root_value + tb : nullptr, d_out_root_std ? d_out_root_std + tb : nullptr,
-                            nullptr, d_out_qvar ? d_out_qvar + tb * A : nullptr, nullptr, s->d_vprobs, st);
+    rc = eaz_search_summary(s, s->d_sum_value, s->d_sum_std, nullptr, s->d_sum_qvar, nullptr, s->d_vprobs, st);
     if (rc) return rc;
     {
         ProfScope ps(s, EAZ_K_MISC, st);
-        if (cfg->sample_actions || cfg->sample_from_improved_policy) {
-            choose_action_kernel<<<cdiv(B, 256), 256, 0, st>>>(B, A, s->d_action, s->d_vprobs, s->d_aw, cfg->sample_actions,
-                                                              cfg->sample_from_improved_policy, fold(kt, kTagSampleVisits),
-                                                              fold(kt, kTagSampleImproved));
+        if (flags & (kFlagSampleVisits | kFlagSampleImproved)) {
+            choose_action_kernel<<<cdiv(B, 256), 256, 0, st>>>(B, A, s->d_action, s->d_vprobs, s->d_aw, (flags & kFlagSampleVisits) != 0,
+                                                              (flags & kFlagSampleImproved) != 0, s->d_step_keys);
             LAUNCH_OK();
         }
-        if (d_out_action) HIP_OK(hipMemcpyAsync(d_out_action + tb, s->d_action, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, st));
-        // real env step with auto-reset (selfplay.py:135); the new states are also the SelfplayOutput.state of this step
-        char* copy = d_out_states ? static_cast<char*>(d_out_states) + tb * env->dev.state_bytes : nullptr;
-        rc = env_step_launch(env, B, d_states, s->d_action, fold(kt, kTagEnv), 1, d_states, copy, st);
+        // real env step with auto-reset (selfplay.py:135), in place
+        rc = env_step_launch(env, B, d_states, s->d_action, Key{0, 0}, 1, d_states, nullptr, st, s->d_step_keys + 1);
         if (rc) return rc;
     }
+    return 0;
+}
+
+static int selfplay_capture(eaz_search* s, const eaz_selfplay_cfg* cfg, int flags, void* d_states, hipStream_t st) {
+    if (s->step_graph && s->graph_states == d_states && s->graph_flags == flags) return 0;
+    if (s->step_graph) { (void)hipGraphExecDestroy(s->step_graph); s->step_graph = nullptr; }
+    hipGraph_t graph = nullptr;
+    HIP_OK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = selfplay_step_body(s, cfg, flags, d_states, st);
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(&s->step_graph, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { s->step_graph = nullptr; return fail("hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+    s->graph_states = d_states;
+    s->graph_flags = flags;
     return 0;
 }
 
@@ -769,11 +831,50 @@ extern "C" int eaz_selfplay_run(eaz_search* s, const eaz_selfplay_cfg* cfg, uint
         return fail("selfplay: directed_exploration (%d) must match the search's recurrent-fn `exploration` flag (%d), main.py:262",
                     cfg->directed_exploration, s->opts.exploration);
     HIP_OK(hipSetDevice(s->ctx->device));
+    const int B = s->B, A = s->A;
+    const size_t sb = static_cast<size_t>(s->env->dev.state_bytes) * B, fb = sizeof(float) * B;
     const Key k = key_from_u64(key);
+    const int flags = (cfg->uniform_search_policy ? kFlagUniform : 0) | (cfg->sample_actions ? kFlagSampleVisits : 0) |
+                      (cfg->sample_from_improved_policy ? kFlagSampleImproved : 0) | (d_gumbel ? kFlagExplicitGumbel : 0) |
+                      (cfg->directed_exploration ? 16 : 0) | (static_cast<int>(cfg->exploration_beta != 0.0f) << 5);
+    // graph replay needs a capturable stream: work runs on the search's own stream, ordered after/before the caller's by events
+    const bool use_graph = cfg->use_graph && !s->prof_on;
+    hipStream_t user = S(stream), st = user;
+    if (use_graph) {
+        st = s->main;
+        HIP_OK(hipEventRecord(s->ev_in, user));
+        HIP_OK(hipStreamWaitEvent(st, s->ev_in, 0));
+        if (s->graph_beta != cfg->exploration_beta) { s->graph_flags = -1; s->graph_beta = cfg->exploration_beta; }
+    }
     for (int step = 0; step < cfg->selfplay_steps; ++step) {
-        int rc = selfplay_step(s, cfg, fold(k, kTagStep + static_cast<uint32_t>(step)), step, d_states, d_gumbel, d_out_states,
-                               d_out_root_value, d_out_root_std, d_out_value_pred, d_out_ube_pred, d_out_qvar, d_out_action, S(stream));
-        if (rc) return rc;
+        const Key kt = fold(k, kTagStep + static_cast<uint32_t>(step));  // key_seq[t], selfplay.py:147
+        const long tb = static_cast<long>(step) * B;
+        set_step_keys_kernel<<<1, 1, 0, st>>>(s->d_step_keys, fold(kt, kTagGumbel), fold(kt, kTagEnv), fold(kt, kTagSampleVisits),
+                                             fold(kt, kTagSampleImproved));
+        LAUNCH_OK();
+        if (d_gumbel) HIP_OK(hipMemcpyAsync(s->d_gumbel_stage, d_gumbel + tb * A, fb * A, hipMemcpyDeviceToDevice, st));
+        int rc;
+        if (use_graph) {
+            rc = selfplay_capture(s, cfg, flags, d_states, st);
+            if (rc) return rc;
+            HIP_OK(hipGraphLaunch(s->step_graph, st));
+        } else {
+            rc = selfplay_step_body(s, cfg, flags, d_states, st);
+            if (rc) return rc;
+        }
+        // SelfplayOutput[t] (selfplay.py:136-143)
+        if (d_out_value_pred) HIP_OK(hipMemcpyAsync(d_out_value_pred + tb, s->d_root_v, fb, hipMemcpyDeviceToDevice, st));
+        if (d_out_ube_pred) HIP_OK(hipMemcpyAsync(d_out_ube_pred + tb, s->d_root_u, fb, hipMemcpyDeviceToDevice, st));
+        if (d_out_root_value) HIP_OK(hipMemcpyAsync(d_out_root_value + tb, s->d_sum_value, fb, hipMemcpyDeviceToDevice, st));
+        if (d_out_root_std) HIP_OK(hipMemcpyAsync(d_out_root_std + tb, s->d_sum_std, fb, hipMemcpyDeviceToDevice, st));
+        if (d_out_qvar) HIP_OK(hipMemcpyAsync(d_out_qvar + tb * A, s->d_sum_qvar, fb * A, hipMemcpyDeviceToDevice, st));
+        if (d_out_action) HIP_OK(hipMemcpyAsync(d_out_action + tb, s->d_action, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, st));
+        if (d_out_states) HIP_OK(hipMemcpyAsync(static_cast<char*>(d_out_states) + tb * s->env->dev.state_bytes, d_states, sb,
+                                                hipMemcpyDeviceToDevice, st));
+    }
+    if (use_graph) {
+        HIP_OK(hipEventRecord(s->ev_out, st));
+        HIP_OK(hipStreamWaitEvent(user, s->ev_out, 0));
     }
     return 0;
 }
@@ -805,6 +906,17 @@ extern "C" int eaz_random_play(eaz_env* env, int B, int T, uint64_t key, void* d
 extern "C" int eaz_profile_enable(eaz_search* s, int on) {
     ARG_OK(s != nullptr);
     s->prof_on = on;
+    s->net->d_kstep_counter = on ? s->net->d_kstep_storage : nullptr;
+    return 0;
+}
+
+extern "C" int eaz_profile_net_ksteps(eaz_search* s, uint64_t* executed, int reset) {
+    ARG_OK(s && executed);
+    HIP_OK(hipDeviceSynchronize());
+    unsigned long long v = 0;
+    HIP_OK(hipMemcpy(&v, s->net->d_kstep_storage, sizeof v, hipMemcpyDeviceToHost));
+    *executed = v;
+    if (reset) HIP_OK(hipMemset(s->net->d_kstep_storage, 0, sizeof v));
     return 0;
 }
 

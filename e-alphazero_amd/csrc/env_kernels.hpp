@@ -94,8 +94,9 @@ __global__ void __launch_bounds__(256) leaf_gather_deepsea_kernel(EnvDev e, Tree
 // interprets the program on a private copy of the memory in LDS (W bytes), <= 200 cycles (subleq.py:19,297-299).
 // mode as deepsea_step_kernel.  src/dst may alias (in-place real step) or be tree embedding slots (leaf gather).
 __global__ void __launch_bounds__(192) subleq_step_kernel(EnvDev e, StateRef src, StateRef dst, const int32_t* action, int B,
-                                                          int mode, Key key, char* out_copy, float* next_reward,
-                                                          uint8_t* next_term, uint8_t* next_legal) {
+                                                          int mode, Key key_arg, const Key* key_ptr, char* out_copy,
+                                                          float* next_reward, uint8_t* next_term, uint8_t* next_legal) {
+    const Key key = key_ptr ? *key_ptr : key_arg;  // device-resident key: lets a captured hipGraph serve every real step
     extern __shared__ __attribute__((aligned(16))) uint8_t lmem[];  // 192 * W
     __shared__ uint8_t s_correct[192];
     __shared__ uint16_t s_in_after[64][8], s_out_after[64][8];

@@ -138,9 +138,10 @@ __global__ void __launch_bounds__(256) tree_summary_kernel(TreeDev t, float* val
 // Root preparation of selfplay's step_fn (src/selfplay.py:92-106,113): policy logits (uniform option), per-env beta
 // schedule beta * linspace(0, 1, B), invalid = ~legal_action_mask, root Gumbel noise (explicit or generated).
 __global__ void __launch_bounds__(256) root_prep_kernel(int B, int A, const float* logits_in, int uniform_policy, float sbeta,
-                                                        const uint8_t* legal, const float* gumbel_in, Key gkey,
+                                                        const uint8_t* legal, const float* gumbel_in, const Key* step_keys,
                                                         float gumbel_scale, float* logits_out, float* beta, uint8_t* invalid,
-                                                        float* gumbel_out) {
+                                                        float* gumbel_out, float* root_ube, const float* novelty, float max_u) {
+    const Key gkey = step_keys[0];
     const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= static_cast<long>(B) * A) return;
     const int b = static_cast<int>(i / A);
@@ -148,15 +149,18 @@ __global__ void __launch_bounds__(256) root_prep_kernel(int B, int A, const floa
     invalid[i] = legal ? (legal[i] ? 0 : 1) : 0;                                            // :113
     const float g = gumbel_in ? gumbel_in[i] : gumbel(gkey, static_cast<uint32_t>(i));
     gumbel_out[i] = gumbel_scale * g;
-    if (i == static_cast<long>(b) * A)
+    if (i == static_cast<long>(b) * A) {
         beta[b] = sbeta * (B > 1 ? static_cast<float>(b) / static_cast<float>(B - 1) : 0.0f);  // :105
+        root_ube[b] = ube_combine(root_ube[b], novelty[b], max_u);  // fully_connected.py:92-96 joined with the novelty lookup
+    }
 }
 
 // Action choice (src/selfplay.py:118-134): search action, or categorical over visit PROBABILITIES / action weights
 // used as logits (reproduced literally), categorical(key, logits) = argmax(logits + Gumbel).
 __global__ void __launch_bounds__(256) choose_action_kernel(int B, int A, int32_t* action, const float* visit_probs,
                                                             const float* action_weights, int sample_actions,
-                                                            int sample_improved, Key kvis, Key kimp) {
+                                                            int sample_improved, const Key* step_keys) {
+    const Key kvis = step_keys[2], kimp = step_keys[3];
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     int act = action[b];

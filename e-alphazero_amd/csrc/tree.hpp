@@ -31,7 +31,9 @@ struct TreeDev {
     const float *rf_reward, *rf_reward_var, *rf_discount, *rf_logits, *rf_value, *rf_value_var;  // [B], [B,A]
     // fused native recurrent fn (src/context.py:117-155): raw network outputs + fields of the stepped state
     int fused_rf;
-    const float *net_logits, *net_value, *net_ube;  // [B,A] (head chosen by `exploration`), [B], [B]
+    const float *net_logits, *net_value, *net_ube;  // [B,A] (head chosen by `exploration`), [B], [B] (u * max_u, pre-novelty)
+    const float* net_novelty;                        // [B]   scaled_state_novelty of the stepped state (hash kernel)
+    float max_u;                                     //       fully_connected.py:19
     const float* next_reward;                        // [B]   rewards[b, current_player]   context.py:139
     const uint8_t* next_term;                        // [B]   state.terminated             context.py:140-144
     const uint8_t* next_legal;                       // [B,A] state.legal_action_mask      context.py:137
@@ -281,7 +283,7 @@ __global__ void __launch_bounds__(256) tree_step_kernel(TreeDev t, int sim, int 
             const bool term = t.next_term[g.b] != 0;
             reward = t.next_reward[g.b];                                                       // :139
             value = term ? 0.0f : t.net_value[g.b];                                            // :140
-            var = term ? 0.0f : t.net_ube[g.b];                                                // :141
+            var = term ? 0.0f : ube_combine(t.net_ube[g.b], t.net_novelty[g.b], t.max_u);      // :141 (+ fully_connected.py:92-96)
             disc = 1.0f * t.discount;                                                          // :142
             if (t.two_player) disc = disc * -1.0f;                                             // :143
             if (term) disc = 0.0f;                                                             // :144

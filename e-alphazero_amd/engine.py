@@ -298,7 +298,7 @@ class Search:
     def selfplay(self, states: torch.Tensor, T: int, key=0, gumbel: Optional[torch.Tensor] = None,
                  directed_exploration: bool = False, exploration_beta: float = 0.0, uniform_search_policy: bool = False,
                  sample_actions: bool = False, sample_from_improved_policy: bool = False, outputs: Optional[dict] = None,
-                 use_graph: bool = False) -> dict:
+                 use_graph: bool = True) -> dict:
         """src/selfplay.py:78-149.  `states` ([B, state_bytes]) is advanced in place; returns SelfplayOutput fields [T,B,..]."""
         B, A, dev = self.B, self.A, self.device
         assert states.shape == (B, self.env.state_bytes) and states.is_contiguous()
@@ -328,4 +328,8 @@ class Search:
         ms = (C.c_double * 5)()
         n = (C.c_int64 * 5)()
         check(_lib.load().eaz_profile_read(self.h, ms, n, int(reset)))
-        return {name: dict(ms=ms[i], launches=int(n[i])) for i, name in enumerate(_lib.K_NAMES)}
+        out = {name: dict(ms=ms[i], launches=int(n[i])) for i, name in enumerate(_lib.K_NAMES)}
+        ks = C.c_uint64()
+        check(_lib.load().eaz_profile_net_ksteps(self.h, C.byref(ks), int(reset)))
+        out["net"]["layer1_ksteps"] = int(ks.value)
+        return out

@@ -192,6 +192,9 @@ enum { EAZ_K_TREE = 0, EAZ_K_GATHER = 1, EAZ_K_HASH = 2, EAZ_K_NET = 3, EAZ_K_MI
 EAZ_API int eaz_profile_enable(eaz_search* s, int on);
 /* synchronises the stream; returns total ms and launch count per class since the last reset */
 EAZ_API int eaz_profile_read(eaz_search* s, double ms[EAZ_K_COUNT], int64_t launches[EAZ_K_COUNT], int reset);
+/* layer-1 k-steps (64 rows x 256 columns x 4 k each) the FC kernel actually executed while profiling was enabled: all-zero
+ * observation k-steps are skipped exactly, so executed FLOPs <= dense FLOPs */
+EAZ_API int eaz_profile_net_ksteps(eaz_search* s, uint64_t* executed, int reset);
 
 #ifdef __cplusplus
 }

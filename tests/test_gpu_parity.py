@@ -138,7 +138,10 @@ def test_selfplay_matches_oracle(oracle, eaz, torch, G, B, S, T, flags):
     search = engine.Search(env, net, B, S, exploration=flags.get("directed_exploration", False))
     st = env.init(B, key=1)
     ost = oenv.init(B)
-    out = search.selfplay(st, T, key=99, **flags)
+    st_eager = st.clone()
+    out = search.selfplay(st, T, key=99, **flags)  # production path: one captured hipGraph per real step, replayed T times
+    out_eager = search.selfplay(st_eager, T, key=99, use_graph=False, **flags)  # plain stream launches
+    assert all(torch.equal(out[k], out_eager[k]) for k in out) and torch.equal(st, st_eager)
     ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(99, 0), **flags)
     assert np.array_equal(out["action"].cpu().numpy(), ref["action"])
     assert np.array_equal(out["state"].cpu().numpy(), ref["state"])
