@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeaz.so")
+LIB_PATH = os.environ.get("EAZ_LIB", os.path.join(_HERE, "libeaz.so"))  # EAZ_LIB: diagnostic builds only
 
 K_NAMES = ("tree", "gather", "hash", "net", "misc")
 

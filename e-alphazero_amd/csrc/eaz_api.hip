@@ -289,9 +289,10 @@ extern "C" int eaz_net_create_fc(eaz_ctx* ctx, int in_dim, int hidden, int num_a
     HIP_OK(hipMalloc(&n->dev.bitset, n->bitset_bytes));
     HIP_OK(hipMemset(n->dev.bitset, 0, n->bitset_bytes));
     if (in_dim > 256 * kFcMaxBlocks) return fail("observation size %d exceeds the FC kernel's limit %d", in_dim, 256 * kFcMaxBlocks);
-    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kFcLdsBytes));
-    HIP_OK(hipMalloc(&n->d_kstep_storage, sizeof(unsigned long long)));
-    HIP_OK(hipMemset(n->d_kstep_storage, 0, sizeof(unsigned long long)));
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_forward_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFcLdsBytes));
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_forward_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFcLdsBytes));
+    HIP_OK(hipMalloc(&n->d_kstep_storage, 8 * sizeof(unsigned long long)));
+    HIP_OK(hipMemset(n->d_kstep_storage, 0, 8 * sizeof(unsigned long long)));
     n->d_kstep_counter = nullptr;
     *out = n;
     return 0;
@@ -347,7 +348,9 @@ static int fc_launch(eaz_net* n, int B, const uint8_t* obs, const NetOut& o, con
         cmin = c < cmin ? c : cmin;
     }
     const int grid = 8 * cdiv(n_tiles, cmin);
-    fc_forward_kernel<<<grid, 256, kFcLdsBytes, st>>>(n->dev, obs, B, o, heads, n->d_kstep_counter);
+    const bool fast = (n->dev.in_dim % 16 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0);
+    if (fast) fc_forward_kernel<true><<<grid, 256, kFcLdsBytes, st>>>(n->dev, obs, B, o, heads, n->d_kstep_counter);
+    else fc_forward_kernel<false><<<grid, 256, kFcLdsBytes, st>>>(n->dev, obs, B, o, heads, n->d_kstep_counter);
     LAUNCH_OK();
     return 0;
 }
@@ -500,6 +503,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     t.state_bytes = env->dev.state_bytes;
     DALLOC(t.embeddings, bn * t.state_bytes);
     DALLOC(t.sim_parent, B); DALLOC(t.sim_action, B); DALLOC(t.sim_next, B);
+    DALLOC(t.path_node, static_cast<size_t>(B) * s->S); DALLOC(t.path_action, static_cast<size_t>(B) * s->S); DALLOC(t.path_len, B);
     // sequential-halving table
     const int mc = opts->max_num_considered_actions;
     std::vector<int32_t> table(static_cast<size_t>(mc + 1) * s->S);
@@ -903,6 +907,14 @@ extern "C" int eaz_random_play(eaz_env* env, int B, int T, uint64_t key, void* d
 // ------------------------------------------------------------------------------------------------------------------
 // instrumentation
 // ------------------------------------------------------------------------------------------------------------------
+#ifdef EAZ_FC_STAMPS
+extern "C" __attribute__((visibility("default"))) int eaz_diag_fc_stamps(unsigned long long* h_out /* [1024*8] */) {
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_fc_stamps), sizeof(unsigned long long) * 1024 * 8));
+    return 0;
+}
+#endif
+
 extern "C" int eaz_profile_enable(eaz_search* s, int on) {
     ARG_OK(s != nullptr);
     s->prof_on = on;

@@ -59,8 +59,9 @@ constexpr int kFcG = 8;       // k-steps per weight-prefetch group
 constexpr int kFcH1Bytes = kFcH * kFcLD * 4;
 constexpr int kFcMaxBlocks = 64;  // in_dim <= 16384
 constexpr int kFcW3Cols = 16;     // layer-3 weights of heads with <= 16 outputs are staged in LDS ([256][No] floats)
-constexpr int kFcLdsBytes = 2 * kFcH1Bytes + 8 * kFcMaxBlocks + kFcH * kFcW3Cols * 4;
-static_assert(kFcKC * kFcLD == kFcH1Bytes, "the observation chunk aliases the H2 tile exactly");
+constexpr int kFcMaskBytes = 8 * 4 * kFcMaxBlocks;  // one 64-bit mask per (256-input block, wave)
+constexpr int kFcLdsBytes = 2 * kFcH1Bytes + kFcMaskBytes + kFcH * kFcW3Cols * 4;
+static_assert(kFcKC * kFcM <= kFcH1Bytes, "the observation chunk (64 rows x 1024 inputs, uint8) aliases the H2 tile");
 
 // head_list: up to 4 head ids (0 value, 1 ube, 2 exploitation, 3 exploration) to evaluate
 struct HeadList {
@@ -68,54 +69,103 @@ struct HeadList {
     int id[4];
 };
 
-// Observation chunk in flight: thread (kq4 = tid & 63, rg = tid >> 6) holds, for each of the 4 blocks of 256 inputs,
-// inputs 4*kq4..+3 of rows 16*rg..+15 as 16 packed words.
+// Observation chunk in flight (1024 inputs x 64 rows = 64 KB): thread tid holds 4 units u = tid + 256*q; unit u covers
+// the 16 inputs k = 16*(u & 63) .. +15 of the 4 rows 4*(u >> 6) .. +3, i.e. one 16-byte load per row (16 loads per thread,
+// each wave-instruction reads 1 KiB contiguous per row).
 struct AStage {
-    uint32_t w[4][4][4];  // [block][j][i]: row 16*rg + 4*j + i
+    uint4 w[4][4];  // [q][i]: row 4 * ((tid >> 6) + 4 * q) + i
 };
 
-__device__ __forceinline__ void a_stage_load(AStage& s, const uint8_t* obs, int B, int in_dim, int row0, int chunk, int tid, bool fast) {
-    const int kq4 = tid & 63, rg = tid >> 6;
+// Loads are unconditional from a clamped in-range address and zeroed by a select afterwards (no divergent control flow).
+template <bool FAST>
+__device__ __forceinline__ void a_stage_load(AStage& s, const uint8_t* obs, int B, int in_dim, int row0, int chunk, int tid) {
+    const int k = chunk * kFcKC + 16 * (tid & 63);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + 4 * ((tid >> 6) + 4 * q) + i;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (FAST) {
+                // in_dim % 16 == 0 and a 16-byte aligned base: the 16 inputs are either all inside the row or all outside
+                const bool ok = row < B && k < in_dim;
+                const long off = static_cast<long>(ok ? row : 0) * in_dim + (ok ? k : 0);
+                const uint4 ld = *reinterpret_cast<const uint4*>(obs + off);
+                v.x = ok ? ld.x : 0u; v.y = ok ? ld.y : 0u; v.z = ok ? ld.z : 0u; v.w = ok ? ld.w : 0u;
+            } else {
+                uint32_t d[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const bool ok = row < B && k + b < in_dim;
+                    const long off = ok ? static_cast<long>(row) * in_dim + k + b : 0;
+                    const uint32_t byte = obs[off];
+                    d[b >> 2] |= (ok ? byte : 0u) << (8 * (b & 3));
+                }
+                v = make_uint4(d[0], d[1], d[2], d[3]);
+            }
+            s.w[q][i] = v;
+        }
+}
+
+// spread the low 16 bits of x to bit positions 0, 4, 8, ..., 60
+__device__ __forceinline__ unsigned long long spread4(unsigned long long x) {
+    x &= 0xFFFFull;
+    x = (x | (x << 24)) & 0x000000FF000000FFull;
+    x = (x | (x << 12)) & 0x000F000F000F000Full;
+    x = (x | (x << 6)) & 0x0303030303030303ull;
+    x = (x | (x << 3)) & 0x1111111111111111ull;
+    return x;
+}
+
+// Each wave publishes, per 256-input block, the mask of k-steps (4 inputs) in which ITS 16 rows hold a non-zero entry
+// (plain stores into its own slot; the block mask is the OR of the four slots).  k-step ks = 4 * (tid & 63) + w of the
+// chunk lives in block ks >> 6 at bit ks & 63.
+__device__ __forceinline__ void a_stage_masks(unsigned long long* kmask /* [4 blocks][4 waves] */, const AStage& s, int tid) {
+    uint32_t any[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { any[0] |= s.w[q][i].x; any[1] |= s.w[q][i].y; any[2] |= s.w[q][i].z; any[3] |= s.w[q][i].w; }
+    unsigned long long bw[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) bw[w] = __ballot(any[w] != 0);  // bit per lane (= per group of 16 inputs)
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-        const int k = chunk * kFcKC + kb * 256 + 4 * kq4;
+        unsigned long long m = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = row0 + 16 * rg + 4 * j + i;
-                uint32_t v = 0;
-                if (row < B && k < in_dim) {
-                    const uint8_t* p = obs + static_cast<long>(row) * in_dim + k;
-                    if (fast) v = *reinterpret_cast<const uint32_t*>(p);
-                    else
-                        for (int q = 0; q < 4; ++q) v |= (k + q < in_dim ? static_cast<uint32_t>(p[q]) : 0u) << (8 * q);
-                }
-                s.w[kb][j][i] = v;
-            }
+        for (int w = 0; w < 4; ++w) m |= spread4(bw[w] >> (16 * kb)) << w;
+        if ((tid & 63) == 0) kmask[kb * 4 + (tid >> 6)] = m;
     }
 }
 
-// registers -> LDS uint8 [k][row] (4x4 byte transposes) + per-block masks of the k-steps that hold a non-zero entry
-__device__ __forceinline__ void a_stage_store(uint8_t* At, unsigned long long* kmask, const AStage& s, int tid) {
-    const int kq4 = tid & 63, rg = tid >> 6;
+__device__ __forceinline__ unsigned long long block_mask(const unsigned long long* kmask, int kb) {
+    return kmask[kb * 4] | kmask[kb * 4 + 1] | kmask[kb * 4 + 2] | kmask[kb * 4 + 3];
+}
+
+// Observation tile in LDS: ROW-major uint8 [64 rows][1024 inputs] (64 KB), stored with the 16-byte loads as they arrive
+// (ds_write_b128, conflict-free because lanes differ in the 16-byte chunk).  The chunk index is XOR-swizzled with the
+// row group so that the MFMA operand reads (4 rows x 1 byte per lane, rows 4 apart between lanes) spread over the banks.
+__device__ __forceinline__ int a_tile_offset(int row, int k) {
+    return row * kFcKC + ((((k >> 4) ^ ((row >> 2) & 7))) << 4) + (k & 15);
+}
+
+__device__ __forceinline__ void a_stage_store(uint8_t* At, const AStage& s, int tid) {
+    const int k = 16 * (tid & 63);
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        uint32_t any = 0;
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t w0 = s.w[kb][j][0], w1 = s.w[kb][j][1], w2 = s.w[kb][j][2], w3 = s.w[kb][j][3];
-            any |= w0 | w1 | w2 | w3;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const uint32_t o = ((w0 >> (8 * kk)) & 0xFFu) | (((w1 >> (8 * kk)) & 0xFFu) << 8) |
-                                   (((w2 >> (8 * kk)) & 0xFFu) << 16) | (((w3 >> (8 * kk)) & 0xFFu) << 24);
-                *reinterpret_cast<uint32_t*>(At + (kb * 256 + 4 * kq4 + kk) * kFcLD + 16 * rg + 4 * j) = o;
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * ((tid >> 6) + 4 * q) + i;
+            *reinterpret_cast<uint4*>(At + a_tile_offset(row, k)) = s.w[q][i];
         }
-        const unsigned long long m = __ballot(any != 0);  // lane = k-step index within the block
-        if ((tid & 63) == 0 && m) atomicOr(&kmask[kb], m);
-    }
+}
+
+// A operand of one k-step for lane (r, kq): inputs k = 4*ks + kq of rows 4r .. 4r+3 (all four share one row group)
+__device__ __forceinline__ floatx4 a_tile_read(const uint8_t* At, int ks, int r, int kq) {
+    const int k = 4 * ks + kq;
+    const int base = 4 * r * kFcKC + ((((k >> 4) ^ (r & 7))) << 4) + (k & 15);
+    return floatx4{static_cast<float>(At[base]), static_cast<float>(At[base + kFcKC]), static_cast<float>(At[base + 2 * kFcKC]),
+                   static_cast<float>(At[base + 3 * kFcKC])};
 }
 
 #define EAZ_MFMA16(acc, a, b)                                                              \
@@ -157,16 +207,20 @@ struct BGroup {
 };
 
 __device__ __forceinline__ KGroup next_group(unsigned long long& mask) {
+    // A group always has kFcG slots: slots past the last real k-step repeat it with an all-zero weight fragment, which
+    // leaves the accumulators bit-for-bit unchanged (acc is never -0: it starts at +0 and x + (+-0) keeps x).  This keeps
+    // the MFMA body free of per-slot branches (one 128-MFMA body per call site instead of one per group size).
     KGroup g;
     g.n = 0;
+    int last = 0;
 #pragma unroll
     for (int i = 0; i < kFcG; ++i) {
-        g.ks[i] = 0;
         if (mask) {
-            g.ks[i] = __builtin_ctzll(mask);
+            last = __builtin_ctzll(mask);
             mask &= mask - 1;
             g.n = i + 1;
         }
+        g.ks[i] = last;
     }
     return g;
 }
@@ -189,22 +243,20 @@ __device__ __forceinline__ void mma_block(floatx4 (&acc)[4][4], const void* Abas
     if (gc.n == 0) return;
     BGroup bc, bn;
     load_group(bc, gc, W, K, k0, col, kq);
+#pragma clang loop unroll(disable)
     while (true) {
         const KGroup gn = next_group(mask);
         if (gn.n) load_group(bn, gn, W, K, k0, col, kq);
 #pragma unroll
         for (int i = 0; i < kFcG; ++i) {
-            if (i < gc.n) {
-                floatx4 a;
-                if constexpr (U8A) {
-                    const uint8_t* At = static_cast<const uint8_t*>(Abase);
-                    a = cvt_rows(*reinterpret_cast<const uint32_t*>(At + (4 * gc.ks[i] + kq) * kFcLD + 4 * r));
-                } else {
-                    const float* At = static_cast<const float*>(Abase);
-                    a = *reinterpret_cast<const floatx4*>(At + (4 * gc.ks[i] + kq) * kFcLD + 4 * r);
-                }
-                EAZ_MFMA16(acc, a, bc.v[i]);
+            floatx4 a;
+            if constexpr (U8A) {
+                a = a_tile_read(static_cast<const uint8_t*>(Abase), gc.ks[i], r, kq);
+            } else {
+                const float* At = static_cast<const float*>(Abase);
+                a = *reinterpret_cast<const floatx4*>(At + (4 * gc.ks[i] + kq) * kFcLD + 4 * r);
             }
+            EAZ_MFMA16(acc, a, bc.v[i]);
         }
         if (gn.n == 0) break;
         gc = gn;
@@ -212,6 +264,27 @@ __device__ __forceinline__ void mma_block(floatx4 (&acc)[4][4], const void* Abas
     }
 }
 
+#ifdef EAZ_FC_STAMPS
+// Diagnostic build only (make diag): shader-clock stamps at the phase boundaries of workgroup `blockIdx.x`, written to a
+// buffer nothing else reads.  Never compiled into libeaz.so.
+__device__ unsigned long long g_fc_stamps[1024 * 8];
+#define EAZ_STAMP(i)                                                                                   \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                   \
+            unsigned long long t_;                                                                     \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+            g_fc_stamps[blockIdx.x * 8 + (i)] = t_;                                                    \
+        }                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    } while (0)
+#else
+#define EAZ_STAMP(i)
+#endif
+
+// FAST: in_dim % 16 == 0 and a 16-byte aligned observation batch (every configuration of the reference); the generic
+// instantiation stages the tile with guarded byte loads.
+template <bool FAST>
 __global__ void __launch_bounds__(256, 1) fc_forward_kernel(NetDev net, const uint8_t* __restrict__ obs, int B, NetOut out, HeadList heads,
                                                             unsigned long long* kstep_counter) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -237,8 +310,8 @@ __global__ void __launch_bounds__(256, 1) fc_forward_kernel(NetDev net, const ui
     const int K1 = net.in_dim;
     const float *W1 = net.w[head * 3], *W2 = net.w[head * 3 + 1], *W3 = net.w[head * 3 + 2];
     const float *b1 = net.b[head * 3], *b2 = net.b[head * 3 + 1], *b3 = net.b[head * 3 + 2];
-    const bool fast = (K1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 3) == 0);
 
+    EAZ_STAMP(0);
     floatx4 acc[4][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -248,33 +321,43 @@ __global__ void __launch_bounds__(256, 1) fc_forward_kernel(NetDev net, const ui
     // ---------------- layer 1: [64 x K1] x [K1 x 256], all-zero k-steps skipped ----------------
     const int nchunk1 = (K1 + kFcKC - 1) / kFcKC;
     unsigned long long executed = 0;
-    if (tid < kFcMaxBlocks) kmask[tid] = 0ull;
     // layer-3 weights: [256][No] floats, staged now (coalesced) and read back as LDS broadcasts after layer 2
     const int No = head < 2 ? 1 : net.A;
-    float* W3s = reinterpret_cast<float*>(lds + 2 * kFcH1Bytes + 8 * kFcMaxBlocks);
+    float* W3s = reinterpret_cast<float*>(lds + 2 * kFcH1Bytes + kFcMaskBytes);
     const bool w3_lds = No <= kFcW3Cols;
-    if (w3_lds)
-        for (int i = tid; i < kFcH * No; i += 256) W3s[i] = W3[i];
     AStage st;
-    a_stage_load(st, obs, B, K1, row0, 0, tid, fast);
-    __syncthreads();  // masks zeroed
+    a_stage_load<FAST>(st, obs, B, K1, row0, 0, tid);
+    if (w3_lds) {
+        // thread k stages row k of W3, zero-padded to 16 columns (B operand of the layer-3 MFMA): all loads in flight
+        // together with the observation loads above, one round trip
+        float wv[kFcW3Cols];
+#pragma unroll
+        for (int j = 0; j < kFcW3Cols; ++j) wv[j] = j < No ? W3[tid * No + j] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < kFcW3Cols; j += 4)
+            *reinterpret_cast<floatx4*>(W3s + tid * kFcW3Cols + j) = floatx4{wv[j], wv[j + 1], wv[j + 2], wv[j + 3]};
+    }
     for (int c = 0; c < nchunk1; ++c) {
-        a_stage_store(R2, &kmask[4 * c], st, tid);
+        a_stage_masks(&kmask[16 * c], st, tid);
+        a_stage_store(R2, st, tid);
         __syncthreads();  // chunk c and its masks are visible
-        if (c + 1 < nchunk1) a_stage_load(st, obs, B, K1, row0, c + 1, tid, fast);  // in flight during the MFMAs below
+        EAZ_STAMP(1);
+        if (c + 1 < nchunk1) a_stage_load<FAST>(st, obs, B, K1, row0, c + 1, tid);  // in flight during the MFMAs below
 #pragma unroll 1
         for (int kb = 0; kb < 4; ++kb) {
-            const unsigned long long mv = kmask[4 * c + kb];
+            const unsigned long long mv = block_mask(&kmask[16 * c], kb);
             // the mask is the same in every lane: move it to scalar registers so the k-step loop is scalar control flow
             const unsigned long long m = static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(mv))) |
                                          (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(mv >> 32))) << 32);
             executed += __builtin_popcountll(m);
-            mma_block<true>(acc, R2 + kb * 256 * kFcLD, m, W1, K1, c * kFcKC + kb * 256, col, r, kq);
+            mma_block<true>(acc, R2 + kb * 256, m, W1, K1, c * kFcKC + kb * 256, col, r, kq);
         }
         if (c + 1 < nchunk1) __syncthreads();  // everyone is done reading chunk c before it is overwritten
     }
+    EAZ_STAMP(2);
     store_hidden(H1, acc, b1, n0, r, kq);
     __syncthreads();  // H1 complete; region 2 (observation chunk) is dead from here on
+    EAZ_STAMP(3);
 
     // ---------------- layer 2: [64 x 256] x [256 x 256], dense ----------------
 #pragma unroll
@@ -282,23 +365,16 @@ __global__ void __launch_bounds__(256, 1) fc_forward_kernel(NetDev net, const ui
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[s][t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
     mma_block<false>(acc, H1, ~0ull, W2, kFcH, 0, col, r, kq);
+    EAZ_STAMP(4);
     store_hidden(H2, acc, b2, n0, r, kq);
     __syncthreads();
+    EAZ_STAMP(5);
 
-    // ---------------- layer 3 + head activation (VALU, k ascending) ----------------
-    const int row = tid & 63;
-    const bool row_ok = row0 + row < B;
-    for (int o = wave; o < No; o += 4) {
-        float z = 0.0f;
-        if (w3_lds) {
-#pragma unroll 16
-            for (int k = 0; k < kFcH; ++k) z = __builtin_fmaf(H2[k * kFcLD + row], W3s[k * No + o], z);
-        } else {
-#pragma unroll 16
-            for (int k = 0; k < kFcH; ++k) z = __builtin_fmaf(H2[k * kFcLD + row], W3[static_cast<long>(k) * No + o], z);
-        }
-        z = z + b3[o];
-        if (!row_ok) continue;
+    // ---------------- layer 3 + head activation ----------------
+    // out <= 16: one 16x16x4 MFMA chain per wave (rows 16*wave..+15, W3 zero-padded to 16 columns in LDS);
+    // out == 256: the layer-2 code path; anything else: VALU fmaf chains.  All three are k-ascending fmaf chains.
+    auto emit = [&](int row, int o, float z) {
+        if (row0 + row >= B) return;
         const long gi = row0 + row;
         if (head == 0) {
             if (out.value) out.value[gi] = det_tanh(z);                       // fully_connected.py:55
@@ -312,7 +388,49 @@ __global__ void __launch_bounds__(256, 1) fc_forward_kernel(NetDev net, const ui
             float* dst = head == 2 ? out.exploit : out.explore;               // :68-81
             if (dst) dst[gi * net.A + o] = z;
         }
+    };
+    if (w3_lds) {
+        floatx4 a3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
+        for (int ks = 0; ks < kFcH / 4; ++ks) {
+            const float av = H2[(4 * ks + kq) * kFcLD + 16 * wave + r];
+            const float bv = W3s[(4 * ks + kq) * kFcW3Cols + r];
+            a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, a3, 0, 0, 0);
+        }
+        if (r < No) {
+            const float bo = b3[r];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) emit(16 * wave + 4 * kq + reg, r, a3[reg] + bo);
+        }
+    } else if (No == kFcH) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[s][t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        mma_block<false>(acc, H2, ~0ull, W3, kFcH, 0, col, r, kq);
+        // only policy heads can have 256 outputs: plain stores (keeps the 64 epilogue sites free of the tanh code)
+        float* dst = head == 2 ? out.exploit : out.explore;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float bo = b3[col + t];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int row = 16 * kq + 4 * reg + s;
+                    if (dst && row0 + row < B) dst[static_cast<long>(row0 + row) * net.A + col + t] = acc[s][t][reg] + bo;
+                }
+        }
+    } else {
+        const int row = tid & 63;
+        for (int o = wave; o < No; o += 4) {
+            float z = 0.0f;
+#pragma unroll 16
+            for (int k = 0; k < kFcH; ++k) z = __builtin_fmaf(H2[k * kFcLD + row], W3[static_cast<long>(k) * No + o], z);
+            emit(row, o, z + b3[o]);
+        }
     }
+    EAZ_STAMP(6);
     if (kstep_counter && tid == 0) atomicAdd(kstep_counter, executed);
 }
 

@@ -26,6 +26,8 @@ struct TreeDev {
     char* embeddings;       // [B,N,state_bytes]
     int state_bytes;
     int32_t *sim_parent, *sim_action, *sim_next;  // [B] result of the last select
+    int32_t *path_node, *path_action;             // [B,S] root-to-leaf path of the last select (level d: node, action taken)
+    int32_t* path_len;                            // [B]   number of levels of that path (>= 1)
     const int32_t* table;                         // [(max_considered+1), S]
     // outputs of a caller-evaluated recurrent fn for the simulation being expanded (generic path, fused_rf == 0)
     const float *rf_reward, *rf_reward_var, *rf_discount, *rf_logits, *rf_value, *rf_value_var;  // [B], [B,A]
@@ -44,46 +46,65 @@ struct TreeDev {
     float value_scale, maxvisit_init;
 };
 
+// ---- cross-lane exchange ------------------------------------------------------------------------------------
+// lane ^ MASK exchange.  MASK 1 and 2 are DPP quad permutes (no LDS round trip, ~8 cycles), 4..16 ds_swizzle bit-mask
+// mode (LDS crossbar, no address VGPR), 32 falls back to ds_bpermute.  The reductions below run up to log2(LPT) of
+// these per call and several calls per tree level, so their latency is on the critical path of every simulation.
+template <int MASK>
+__device__ __forceinline__ int xor_lane_i(int v) {
+    if constexpr (MASK == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+    else if constexpr (MASK == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    else if constexpr (MASK < 32) return __builtin_amdgcn_ds_swizzle(v, (MASK << 10) | 0x1F);  // and 0x1F, or 0, xor MASK
+    else return __shfl_xor(v, MASK);
+}
+template <int MASK>
+__device__ __forceinline__ float xor_lane_f(float v) {
+    return __builtin_bit_cast(float, xor_lane_i<MASK>(__builtin_bit_cast(int, v)));
+}
+
 // ---- group reductions ---------------------------------------------------------------------------------------
+#define EAZ_FOR_MASKS(LPT, BODY)                      \
+    do {                                              \
+        if constexpr (LPT > 1) { constexpr int M = 1; BODY }   \
+        if constexpr (LPT > 2) { constexpr int M = 2; BODY }   \
+        if constexpr (LPT > 4) { constexpr int M = 4; BODY }   \
+        if constexpr (LPT > 8) { constexpr int M = 8; BODY }   \
+        if constexpr (LPT > 16) { constexpr int M = 16; BODY } \
+        if constexpr (LPT > 32) { constexpr int M = 32; BODY } \
+    } while (0)
 template <int LPT>
 __device__ __forceinline__ float gsum(float v) {
-#pragma unroll
-    for (int s = 1; s < LPT; s <<= 1) v = v + __shfl_xor(v, s);
+    EAZ_FOR_MASKS(LPT, v = v + xor_lane_f<M>(v););
     return v;
 }
 template <int LPT>
 __device__ __forceinline__ int gsumi(int v) {
-#pragma unroll
-    for (int s = 1; s < LPT; s <<= 1) v = v + __shfl_xor(v, s);
+    EAZ_FOR_MASKS(LPT, v = v + xor_lane_i<M>(v););
     return v;
 }
 template <int LPT>
 __device__ __forceinline__ float gmax(float v) {
-#pragma unroll
-    for (int s = 1; s < LPT; s <<= 1) { const float o = __shfl_xor(v, s); v = o > v ? o : v; }
+    EAZ_FOR_MASKS(LPT, { const float o = xor_lane_f<M>(v); v = o > v ? o : v; });
     return v;
 }
 template <int LPT>
 __device__ __forceinline__ float gmin(float v) {
-#pragma unroll
-    for (int s = 1; s < LPT; s <<= 1) { const float o = __shfl_xor(v, s); v = o < v ? o : v; }
+    EAZ_FOR_MASKS(LPT, { const float o = xor_lane_f<M>(v); v = o < v ? o : v; });
     return v;
 }
 template <int LPT>
 __device__ __forceinline__ int gmaxi(int v) {
-#pragma unroll
-    for (int s = 1; s < LPT; s <<= 1) { const int o = __shfl_xor(v, s); v = o > v ? o : v; }
+    EAZ_FOR_MASKS(LPT, { const int o = xor_lane_i<M>(v); v = o > v ? o : v; });
     return v;
 }
 // argmax with ties -> lowest index (jnp.argmax)
 template <int LPT>
 __device__ __forceinline__ int gargmax(float v, int i) {
-#pragma unroll
-    for (int s = 1; s < LPT; s <<= 1) {
-        const float ov = __shfl_xor(v, s);
-        const int oi = __shfl_xor(i, s);
+    EAZ_FOR_MASKS(LPT, {
+        const float ov = xor_lane_f<M>(v);
+        const int oi = xor_lane_i<M>(i);
         if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-    }
+    });
     return i;
 }
 // in-lane pairwise sum of APL slots (levels below the cross-lane butterfly)
@@ -158,7 +179,7 @@ __device__ __forceinline__ float mixed_value(const Group<LPT, APL>& g, float raw
 template <int APL>
 struct NodeRows {
     float logits[APL], values[APL], rewards[APL], discounts[APL], var[APL], rvar[APL];
-    int visits[APL];
+    int visits[APL], index[APL];
 };
 
 template <int LPT, int APL>
@@ -174,11 +195,12 @@ __device__ __forceinline__ void load_rows(const TreeDev& t, const Group<LPT, APL
             r.rewards[j] = t.children_rewards[o];
             r.discounts[j] = t.children_discounts[o];
             r.visits[j] = t.children_visits[o];
+            r.index[j] = t.children_index[o];
             r.var[j] = need_var ? t.children_var[o] : 0.0f;
             r.rvar[j] = need_var ? t.children_reward_var[o] : 0.0f;
         } else {
             r.logits[j] = 0.0f; r.values[j] = 0.0f; r.rewards[j] = 0.0f; r.discounts[j] = 0.0f;
-            r.visits[j] = 0; r.var[j] = 0.0f; r.rvar[j] = 0.0f;
+            r.visits[j] = 0; r.index[j] = -1; r.var[j] = 0.0f; r.rvar[j] = 0.0f;
         }
     }
 }
@@ -309,41 +331,61 @@ __global__ void __launch_bounds__(256) tree_step_kernel(TreeDev t, int sim, int 
             t.parents[nb + nxt] = parent;
             t.action_from_parent[nb + nxt] = action;
         }
-        // ---- backward (A.6): values carried in registers, every lane computes, the lead lane stores ----------
-        float G = value, U = var;            // leaf_value / leaf variance
+        // ---- backward (A.6) ------------------------------------------------------------------------------------
+        // The select of this simulation recorded its root-to-leaf path, so nothing is pointer-chased here: the
+        // statistics of up to 8 ancestors are fetched with independent loads (one memory round trip per chunk instead of
+        // two per level), then folded leaf-to-root in registers.  Every lane computes, the lead lane stores.
+        float G = value, U = var;                    // leaf_value / leaf variance
         float child_value = value, child_var = var;  // node_values[idx] after its own update
-        int idx = nxt, p = parent, a = action;
-        float r = reward, rv = rvar, d = disc;
         if (lead) { t.node_values[nb + nxt] = value; t.node_var[nb + nxt] = var; }
-        while (true) {
-            const long ca = (nb + p) * A + a;
-            const int cnt_i = t.node_visits[nb + p];
-            const float cnt = static_cast<float>(cnt_i);
-            G = r + d * G;
-            U = rv + (d * d) * U;
-            const float pv = (t.node_values[nb + p] * cnt + G) / (cnt + 1.0f);
-            const float pvar = (t.node_var[nb + p] * cnt + U) / (cnt + 1.0f);
-            const int cvis = t.children_visits[ca];
-            // the reads above must complete before the lead lane's stores below (same addresses, other lanes)
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            if (lead) {
-                t.node_values[nb + p] = pv;
-                t.node_var[nb + p] = pvar;
-                t.node_visits[nb + p] = cnt_i + 1;
-                t.children_values[ca] = child_value;
-                t.children_var[ca] = child_var;
-                t.children_visits[ca] = cvis + 1;
+        const int D = t.path_len[g.b];
+        const long pb = static_cast<long>(g.b) * t.S;
+        constexpr int kChunk = 8;
+        for (int d0 = D - 1; d0 >= 0; d0 -= kChunk) {
+            int pn[kChunk], pa[kChunk], cnt_i[kChunk], cvis[kChunk];
+            float nv[kChunk], nvar[kChunk], er[kChunk], erv[kChunk], ed[kChunk];
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j) {
+                const int d = d0 - j;
+                pn[j] = d >= 0 ? t.path_node[pb + d] : 0;
+                pa[j] = d >= 0 ? t.path_action[pb + d] : 0;
             }
-            child_value = pv;
-            child_var = pvar;
-            idx = p;
-            if (idx == 0) break;
-            p = t.parents[nb + idx];
-            a = t.action_from_parent[nb + idx];
-            const long cb = (nb + p) * A + a;
-            r = t.children_rewards[cb];
-            rv = t.children_reward_var[cb];
-            d = t.children_discounts[cb];
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j) {
+                const long ca = (nb + pn[j]) * A + pa[j];
+                cnt_i[j] = t.node_visits[nb + pn[j]];
+                nv[j] = t.node_values[nb + pn[j]];
+                nvar[j] = t.node_var[nb + pn[j]];
+                cvis[j] = t.children_visits[ca];
+                er[j] = t.children_rewards[ca];
+                erv[j] = t.children_reward_var[ca];
+                ed[j] = t.children_discounts[ca];
+            }
+            // all reads of this chunk complete before the lead lane's stores below (same addresses, other lanes)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j) {
+                const int d = d0 - j;
+                if (d < 0) break;
+                // the edge expanded by this very launch was stored by the lead lane a moment ago: take it from registers
+                const float r = d == D - 1 ? reward : er[j], rv = d == D - 1 ? rvar : erv[j], dd = d == D - 1 ? disc : ed[j];
+                const long ca = (nb + pn[j]) * A + pa[j];
+                const float cnt = static_cast<float>(cnt_i[j]);
+                G = r + dd * G;
+                U = rv + (dd * dd) * U;
+                const float pv = (nv[j] * cnt + G) / (cnt + 1.0f);
+                const float pvar = (nvar[j] * cnt + U) / (cnt + 1.0f);
+                if (lead) {
+                    t.node_values[nb + pn[j]] = pv;
+                    t.node_var[nb + pn[j]] = pvar;
+                    t.node_visits[nb + pn[j]] = cnt_i[j] + 1;
+                    t.children_values[ca] = child_value;
+                    t.children_var[ca] = child_var;
+                    t.children_visits[ca] = cvis[j] + 1;
+                }
+                child_value = pv;
+                child_var = pvar;
+            }
         }
         // make the lead lane's stores visible to the other lanes of the group before select re-reads the rows
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -383,7 +425,16 @@ __global__ void __launch_bounds__(256) tree_step_kernel(TreeDev t, int sim, int 
                 for (int j = 0; j < APL; ++j) x[j] = pr[j] - static_cast<float>(r.visits[j]) / den;
                 action = g.argmax(x);
             }
-            nxt = t.children_index[(nb + node) * A + action];
+            // child index of the chosen action: already in the row registers of the lane that owns the action
+            int mine = -2147483647 - 1;
+#pragma unroll
+            for (int j = 0; j < APL; ++j)
+                if (g.ok[j] && g.act[j] == action) mine = r.index[j];
+            nxt = gmaxi<LPT>(mine);
+            if (lead) {
+                t.path_node[static_cast<long>(g.b) * t.S + depth] = node;
+                t.path_action[static_cast<long>(g.b) * t.S + depth] = action;
+            }
             depth += 1;
             // group-uniform exit: every lane of the group computed the same action / nxt
             if (nxt == -1 || depth >= t.max_depth) break;
@@ -393,6 +444,7 @@ __global__ void __launch_bounds__(256) tree_step_kernel(TreeDev t, int sim, int 
             t.sim_parent[g.b] = node;
             t.sim_action[g.b] = action;
             t.sim_next[g.b] = nxt == -1 ? sim + 1 : nxt;
+            t.path_len[g.b] = depth;
         }
     }
 }

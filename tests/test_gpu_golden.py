@@ -134,3 +134,25 @@ def test_hash_update_matches_oracle(oracle, eaz, torch):
     assert np.array_equal(bs, ref)
     seen, _ = net.hash_lookup(torch.from_numpy(obs).cuda())
     assert seen.all()
+
+
+@pytest.mark.parametrize("W,binary,B", [(16, True, 200), (16, False, 77), (256, True, 130), (32, False, 65)])
+def test_fc_forward_subleq_shapes(oracle, eaz, torch, W, binary, B):
+    """FC forward on Subleq observations: in_dim 240 / 544 / 2592 (multi-chunk staging) / 2112, out = 16 (MFMA layer 3 with LDS
+    weights), 256 (layer-2 code path) and 32 (VALU fallback); hash_io slice."""
+    from e_alphazero_amd import engine
+
+    dims, params, state = subleq_setup(eaz, W, binary=binary, seed=W, fill=0.5)
+    env = engine.EnvHandle.subleq(W, (1,), binary, device=0)
+    oenv = oracle.OracleEnv.subleq(W, (1,), binary)
+    assert env.obs_dim == dims["in_dim"]
+    net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
+    onet = oracle.OracleNet(dims["in_dim"], 256, W, eaz.params.fc_weight_list(params), hash_off=dims["hash_off"],
+                            hash_len=dims["hash_len"], bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+    ost, _ = oracle.random_play(oenv, B, 7, key=(W, 1))
+    obs = oenv.observe(ost)
+    ref = onet.forward(obs)
+    out = net.forward(torch.from_numpy(obs).cuda())
+    for n, a, b in zip(["exploit", "explore", "value", "ube", "novelty"], out, ref):
+        np.testing.assert_allclose(a.cpu().numpy(), b, rtol=0, atol=ATOL, err_msg=n)
+    assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(out, ref)), "FC forward is specified to be bit-exact"
