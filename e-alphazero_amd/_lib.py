@@ -19,6 +19,11 @@ class SearchOpts(C.Structure):
     ]
 
 
+class ReanalyzeCfg(C.Structure):
+    _fields_ = [("reanalyze_beta", C.c_float), ("exploration_beta", C.c_float), ("exploration_ube_target", C.c_int),
+                ("exploration_policy_target_temperature", C.c_float)]
+
+
 class SelfplayCfg(C.Structure):
     _fields_ = [
         ("selfplay_steps", C.c_int), ("directed_exploration", C.c_int), ("exploration_beta", C.c_float),
@@ -64,6 +69,8 @@ SIGNATURES = {
     "eaz_search_tree_view": [_vp, _i, _pp, C.POINTER(C.c_int64), C.POINTER(_i)],
     "eaz_selfplay_run": [_vp, C.POINTER(SelfplayCfg), _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eaz_random_play": [_vp, _i, _i, _u64, _vp, _vp, _vp],
+    "eaz_evaluate_run": [_vp, _f, _i, _vp, _vp, C.POINTER(_i), _vp],
+    "eaz_reanalyze_run": [_vp, C.POINTER(ReanalyzeCfg), _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eaz_profile_enable": [_vp, _i],
     "eaz_profile_read": [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), _i],
     "eaz_profile_net_ksteps": [_vp, C.POINTER(C.c_uint64), _i],

@@ -259,6 +259,15 @@ class Config:
     uniform_search_policy: bool = False
     discount: float = 0.997
     exploration_beta: float = 0.0
+    # reanalyze / evaluate (config.py:44-77)
+    max_episode_length: int = 1000
+    exploration_ube_target: bool = True
+    reanalyze_batch_size: int = 4096
+    reanalyze_simulations_per_step: int = 32
+    num_eval_episodes: int = 128
+    exploration_policy_target_temperature: float = 1.0
+    exploitation_beta: float = 0.0
+    reanalyze_beta: float = 0.0
 
     def __hash__(self):  # config.py:95-96
         return 0
@@ -533,6 +542,8 @@ class Context(NamedTuple):
     devices: list
     forward: ForwardFn
     selfplay_recurrent_fn: NativeRecurrentFn
+    reanalyze_recurrent_fn: Optional[NativeRecurrentFn] = None
+    evaluation_recurrent_fn: Optional[NativeRecurrentFn] = None
 
 
 class SelfplayOutput(NamedTuple):  # src/selfplay.py:17-23
@@ -569,3 +580,51 @@ def uniformrandomplay(config: Config, context: Context, rng_key) -> tuple[State,
     last, traj = env._h.random_play(config.selfplay_batch_size // max(len(context.devices), 1), config.selfplay_steps,
                                     key=rng_key, want_traj=True)
     return State(env, last), State(env, traj)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# reanalyze (src/reanalyze.py) and evaluate (src/evaluate.py): same kernels, different roots
+# ------------------------------------------------------------------------------------------------------------------
+
+
+class ExperiencePair(NamedTuple):
+    """flashbax ExperiencePair shape: .first / .second are States of consecutive timesteps (reanalyze.py:62-63)."""
+
+    first: State
+    second: State
+
+
+class ReanalyzeOutput(NamedTuple):  # src/reanalyze.py:43-49
+    observation: torch.Tensor
+    next_observation: torch.Tensor
+    value_target: torch.Tensor
+    ube_target: torch.Tensor
+    exploration_policy_target: torch.Tensor
+    exploitation_policy_target: torch.Tensor
+
+
+def reanalyze(model, config: Config, context: Context, experience_pair: ExperiencePair, rng_key,
+              gumbel: Optional[torch.Tensor] = None) -> ReanalyzeOutput:
+    """src/reanalyze.py:52-131 as one native call (eaz_reanalyze_run)."""
+    rf = context.reanalyze_recurrent_fn or context.selfplay_recurrent_fn
+    states, next_states = experience_pair.first, experience_pair.second
+    B = states.data.shape[0]
+    qopts = dict(value_scale=0.1, maxvisit_init=50.0, rescale_values=True, use_mixed_value=True)  # default qtransform (:84)
+    s = _get_search(rf, model, B, config.reanalyze_simulations_per_step, qopts, 16, 1.0, None)
+    out = s.reanalyze(states.data, next_states.data, key=rng_key, gumbel=gumbel, reanalyze_beta=config.reanalyze_beta,
+                      exploration_beta=config.exploration_beta, exploration_ube_target=config.exploration_ube_target,
+                      exploration_policy_target_temperature=config.exploration_policy_target_temperature)
+    return ReanalyzeOutput(states.observation, next_states.observation, out["value_target"], out["ube_target"],
+                           out["exploration_policy_target"], out["exploitation_policy_target"])
+
+
+def evaluate(model, config: Config, context: Context, rng_key) -> torch.Tensor:
+    """src/evaluate.py:13-57: mean return of num_eval_episodes greedy-search episodes (eaz_evaluate_run)."""
+    rf = context.evaluation_recurrent_fn or context.selfplay_recurrent_fn
+    B = config.num_eval_episodes // max(len(context.devices), 1)
+    qopts = dict(value_scale=0.1, maxvisit_init=50.0, rescale_values=True, use_mixed_value=True)
+    s = _get_search(rf, model, B, config.selfplay_simulations_per_step, qopts, 16, 0.0, None)  # gumbel_scale=0.0 (:44)
+    _, sub_key = random.split(rng_key)
+    states = context.env.init(KeyBatch(engine.as_key(sub_key), B))                              # :51-54 keys = split(sub_key, B)
+    returns, _ = s.evaluate(states.data, exploitation_beta=config.exploitation_beta, max_episode_length=config.max_episode_length)
+    return returns.mean()                                                                       # :57

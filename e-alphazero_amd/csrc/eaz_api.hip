@@ -103,6 +103,9 @@ struct eaz_search {
     float graph_beta;
     // per-real-step staging (fixed addresses so that one captured hipGraph serves every step) + the graph itself
     float *d_root_v, *d_root_u, *d_sum_value, *d_sum_std, *d_sum_qvar, *d_gumbel_stage;
+    float *d_sum_q, *d_sum_vc, *d_next_v, *d_reward_tmp;  // reanalyze / evaluate scratch
+    uint8_t *d_term, *d_term2;
+    int* d_alive;
     Key* d_step_keys;  // [4]: gumbel, env, sample-visits, sample-improved keys of the current real step
     hipGraphExec_t step_graph;
     const void* graph_states;  // the captured graph is valid for this d_states pointer / these flags
@@ -528,6 +531,8 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     DALLOC(s->d_root_v, B); DALLOC(s->d_root_u, B); DALLOC(s->d_sum_value, B); DALLOC(s->d_sum_std, B);
     DALLOC(s->d_sum_qvar, static_cast<size_t>(B) * A); DALLOC(s->d_gumbel_stage, static_cast<size_t>(B) * A);
     DALLOC(s->d_step_keys, 4);
+    DALLOC(s->d_sum_q, static_cast<size_t>(B) * A); DALLOC(s->d_sum_vc, static_cast<size_t>(B) * A); DALLOC(s->d_next_v, B);
+    DALLOC(s->d_term, B); DALLOC(s->d_term2, B); DALLOC(s->d_reward_tmp, B); DALLOC(s->d_alive, 1);
     t.next_reward = s->d_next_reward; t.next_term = s->d_next_term; t.next_legal = s->d_next_legal;
     *out = s;
     return 0;
@@ -785,7 +790,7 @@ static int selfplay_step_body(eaz_search* s, const eaz_selfplay_cfg* cfg, int fl
         root_prep_kernel<<<cdiv(static_cast<long>(B) * A, 256), 256, 0, st>>>(
             B, A, s->d_root_logits, (flags & kFlagUniform) != 0, sbeta, s->d_legal,
             (flags & kFlagExplicitGumbel) ? s->d_gumbel_stage : nullptr, s->d_step_keys, s->opts.gumbel_scale, s->d_root_logits,
-            s->d_root_beta, s->d_root_invalid, s->d_root_gumbel, s->d_root_u, s->d_novelty, s->net->dev.max_u);
+            s->d_root_beta, s->d_root_invalid, s->d_root_gumbel, s->d_root_u, s->d_novelty, s->net->dev.max_u, 0);
         LAUNCH_OK();
     }
     rc = eaz_search_begin(s, s->d_root_logits, s->d_root_v, s->d_root_u, d_states, s->d_root_beta, s->d_root_invalid, s->d_root_gumbel, st);
@@ -880,6 +885,109 @@ extern "C" int eaz_selfplay_run(eaz_search* s, const eaz_selfplay_cfg* cfg, uint
         HIP_OK(hipEventRecord(s->ev_out, st));
         HIP_OK(hipStreamWaitEvent(user, s->ev_out, 0));
     }
+    return 0;
+}
+
+// root of evaluate / reanalyze: observation -> {novelty || heads} -> legal mask -> root_prep with a constant beta
+static int driver_root(eaz_search* s, const void* d_states, float beta, const float* d_gumbel, Key gkey, hipStream_t st) {
+    const int B = s->B, A = s->A;
+    int rc = obs_launch(s->env, B, d_states, s->d_obs, st);
+    if (rc) return rc;
+    HeadList hl{3, {0, 1, 2, 0}};
+    NetOut o{s->d_root_logits, nullptr, s->d_root_v, s->d_root_u};
+    rc = infer_launch(s, s->d_obs, s->d_novelty, o, hl, st);
+    if (rc) return rc;
+    env_fields_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->env->dev, static_cast<const char*>(d_states), B, s->d_term, nullptr, nullptr, nullptr,
+                                                   s->d_legal);
+    LAUNCH_OK();
+    set_step_keys_kernel<<<1, 1, 0, st>>>(s->d_step_keys, gkey, Key{0, 0}, Key{0, 0}, Key{0, 0});
+    LAUNCH_OK();
+    root_prep_kernel<<<cdiv(static_cast<long>(B) * A, 256), 256, 0, st>>>(B, A, s->d_root_logits, 0, beta, s->d_legal, d_gumbel, s->d_step_keys,
+                                                                          s->opts.gumbel_scale, s->d_root_logits, s->d_root_beta,
+                                                                          s->d_root_invalid, s->d_root_gumbel, s->d_root_u, s->d_novelty,
+                                                                          s->net->dev.max_u, 1);
+    LAUNCH_OK();
+    return eaz_search_begin(s, s->d_root_logits, s->d_root_v, s->d_root_u, d_states, s->d_root_beta, s->d_root_invalid, s->d_root_gumbel, st);
+}
+
+extern "C" int eaz_evaluate_run(eaz_search* s, float exploitation_beta, int max_episode_length, void* d_states, float* d_sum_rewards,
+                                int* h_iterations, void* stream) {
+    ARG_OK(s && d_states && d_sum_rewards);
+    if (s->opts.exploration) return fail("evaluate uses the exploitation recurrent fn (main.py:278-285): create the search with exploration = 0");
+    if (s->opts.gumbel_scale != 0.0f) return fail("evaluate searches greedily (evaluate.py:44): create the search with gumbel_scale = 0");
+    HIP_OK(hipSetDevice(s->ctx->device));
+    hipStream_t st = S(stream);
+    const int B = s->B;
+    HIP_OK(hipMemsetAsync(d_sum_rewards, 0, sizeof(float) * B, st));
+    int counter = 0;
+    for (;;) {
+        // cond_fn evaluate.py:18-20
+        HIP_OK(hipMemsetAsync(s->d_alive, 0, sizeof(int), st));
+        env_fields_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->env->dev, static_cast<const char*>(d_states), B, s->d_term, nullptr, nullptr, nullptr, nullptr);
+        LAUNCH_OK();
+        count_alive_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->d_term, B, s->d_alive);
+        LAUNCH_OK();
+        int alive = 0;
+        HIP_OK(hipMemcpyAsync(&alive, s->d_alive, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        if (alive == 0 || !(counter <= max_episode_length)) break;
+        int rc = driver_root(s, d_states, exploitation_beta, nullptr, Key{0, 0}, st);  // :26-35 (gumbel_scale 0 -> zero noise)
+        if (rc) return rc;
+        rc = eaz_search_run(s, st);
+        if (rc) return rc;
+        rc = eaz_search_finish(s, s->d_action, s->d_aw, st);
+        if (rc) return rc;
+        rc = env_step_launch(s->env, B, d_states, s->d_action, Key{0, 0}, 0, d_states, nullptr, st);  // :47
+        if (rc) return rc;
+        env_fields_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->env->dev, static_cast<const char*>(d_states), B, nullptr, nullptr, s->d_reward_tmp,
+                                                       nullptr, nullptr);
+        LAUNCH_OK();
+        accumulate_kernel<<<cdiv(B, 256), 256, 0, st>>>(d_sum_rewards, s->d_reward_tmp, B);  // :48-50
+        LAUNCH_OK();
+        counter += 1;
+    }
+    if (h_iterations) *h_iterations = counter;
+    return 0;
+}
+
+extern "C" int eaz_reanalyze_run(eaz_search* s, const eaz_reanalyze_cfg* cfg, uint64_t key, const void* d_states, const void* d_next_states,
+                                 const float* d_gumbel, float* d_value_target, float* d_ube_target, float* d_exploration_policy_target,
+                                 float* d_exploitation_policy_target, int32_t* d_action, void* stream) {
+    ARG_OK(s && cfg && d_states && d_next_states && d_value_target && d_ube_target && d_exploration_policy_target && d_exploitation_policy_target);
+    if (s->opts.exploration) return fail("reanalyze uses the exploitation recurrent fn (main.py:270-277): create the search with exploration = 0");
+    HIP_OK(hipSetDevice(s->ctx->device));
+    hipStream_t st = S(stream);
+    const int B = s->B, A = s->A;
+    int rc = driver_root(s, d_states, cfg->reanalyze_beta, d_gumbel, fold(key_from_u64(key), kTagGumbel), st);  // reanalyze.py:64-76
+    if (rc) return rc;
+    rc = eaz_search_run(s, st);                                                                               // :77-85
+    if (rc) return rc;
+    rc = eaz_search_finish(s, s->d_action, d_exploitation_policy_target, st);                                 // :129
+    if (rc) return rc;
+    rc = eaz_search_summary(s, s->d_sum_value, s->d_sum_std, s->d_sum_q, s->d_sum_qvar, s->d_sum_vc, nullptr, st);  // :86
+    if (rc) return rc;
+    // value of the next state (:90-92): only the value head is needed
+    rc = obs_launch(s->env, B, d_next_states, s->d_obs, st);
+    if (rc) return rc;
+    {
+        HeadList hl{1, {0, 0, 0, 0}};
+        NetOut o{nullptr, nullptr, s->d_next_v, nullptr};
+        rc = fc_launch(s->net, B, s->d_obs, o, hl, st);
+        if (rc) return rc;
+    }
+    env_fields_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->env->dev, static_cast<const char*>(d_next_states), B, s->d_term2, nullptr, s->d_reward_tmp,
+                                                   nullptr, nullptr);
+    LAUNCH_OK();
+#define CALL_RT(L, P)                                                                                                              \
+    reanalyze_targets_kernel<L, P><<<tree_grid(s), 256, 0, st>>>(B, A, s->d_action, s->d_sum_q, s->d_sum_qvar, s->d_sum_vc, s->d_sum_value,  \
+                                                                 s->d_sum_std, s->d_root_invalid, s->d_next_v, s->d_reward_tmp, s->d_term2,    \
+                                                                 s->d_term, s->opts.discount, cfg->exploration_beta,                         \
+                                                                 cfg->exploration_ube_target, cfg->exploration_policy_target_temperature,   \
+                                                                 d_value_target, d_ube_target, d_exploration_policy_target)
+    TREE_DISPATCH(s, CALL_RT);
+#undef CALL_RT
+    LAUNCH_OK();
+    if (d_action) HIP_OK(hipMemcpyAsync(d_action, s->d_action, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 

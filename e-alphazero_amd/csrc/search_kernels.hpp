@@ -140,7 +140,8 @@ __global__ void __launch_bounds__(256) tree_summary_kernel(TreeDev t, float* val
 __global__ void __launch_bounds__(256) root_prep_kernel(int B, int A, const float* logits_in, int uniform_policy, float sbeta,
                                                         const uint8_t* legal, const float* gumbel_in, const Key* step_keys,
                                                         float gumbel_scale, float* logits_out, float* beta, uint8_t* invalid,
-                                                        float* gumbel_out, float* root_ube, const float* novelty, float max_u) {
+                                                        float* gumbel_out, float* root_ube, const float* novelty, float max_u,
+                                                        int constant_beta) {
     const Key gkey = step_keys[0];
     const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= static_cast<long>(B) * A) return;
@@ -150,7 +151,8 @@ __global__ void __launch_bounds__(256) root_prep_kernel(int B, int A, const floa
     const float g = gumbel_in ? gumbel_in[i] : gumbel(gkey, static_cast<uint32_t>(i));
     gumbel_out[i] = gumbel_scale * g;
     if (i == static_cast<long>(b) * A) {
-        beta[b] = sbeta * (B > 1 ? static_cast<float>(b) / static_cast<float>(B - 1) : 0.0f);  // :105
+        // selfplay.py:105 beta * linspace(0, 1, B); evaluate.py:34 / reanalyze.py:75: beta * ones
+        beta[b] = constant_beta ? sbeta * 1.0f : sbeta * (B > 1 ? static_cast<float>(b) / static_cast<float>(B - 1) : 0.0f);
         root_ube[b] = ube_combine(root_ube[b], novelty[b], max_u);  // fully_connected.py:92-96 joined with the novelty lookup
     }
 }
@@ -187,6 +189,65 @@ __global__ void __launch_bounds__(256) choose_action_kernel(int B, int A, int32_
 __global__ void __launch_bounds__(256) random_action_kernel(int B, int A, Key k, int32_t* action) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) action[b] = static_cast<int32_t>(rbits(k, static_cast<uint32_t>(b)) % static_cast<uint32_t>(A));
+}
+
+// evaluate.py:18-20,48-50: number of not-yet-terminated envs + return accumulation
+__global__ void __launch_bounds__(256) count_alive_kernel(const uint8_t* terminated, int B, int* alive) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && !terminated[b]) atomicAdd(alive, 1);
+}
+__global__ void __launch_bounds__(256) accumulate_kernel(float* sum, const float* reward, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) sum[b] = sum[b] + reward[b];
+}
+
+// reanalyze.py:88-122 target construction, one group per batch element (same reductions as the tree kernel)
+template <int LPT, int APL>
+__global__ void __launch_bounds__(256) reanalyze_targets_kernel(int B, int A, const int32_t* action, const float* qvalues, const float* qvar,
+                                                                const float* visit_counts, const float* root_value, const float* root_std,
+                                                                const uint8_t* invalid, const float* next_value, const float* next_reward,
+                                                                const uint8_t* next_term, const uint8_t* term, float discount,
+                                                                float exploration_beta, int exploration_ube_target, float temperature,
+                                                                float* value_target, float* ube_target, float* exploration_policy_target) {
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = gtid / LPT;
+    const bool live = b < B;
+    const Group<LPT, APL> g = make_group<LPT, APL>(live ? b : 0, gtid % LPT, A);
+    const int act = action[g.b];
+    float q[APL], qv[APL], c[APL], p[APL];
+    const float vfill = root_value[g.b] + exploration_beta * root_std[g.b];                                      // :117
+#pragma unroll
+    for (int j = 0; j < APL; ++j) {
+        const long o = static_cast<long>(g.b) * A + g.act[j];
+        q[j] = g.ok[j] ? qvalues[o] : 0.0f;
+        qv[j] = g.ok[j] ? qvar[o] : 0.0f;
+        const float sc = q[j] + exploration_beta * __builtin_sqrtf(qv[j]);                                        // :115
+        c[j] = (g.ok[j] && visit_counts[o] > 0.0f) ? sc : vfill;                                                  // complete_qs :32-41
+    }
+    const float mx = g.vmax(qv);                                                                                  // :103
+    float q_act = -kInf, qv_act = -kInf;
+#pragma unroll
+    for (int j = 0; j < APL; ++j)
+        if (g.ok[j] && g.act[j] == act) { q_act = q[j]; qv_act = qv[j]; }
+    q_act = gmax<LPT>(q_act);                                                                                     // :88
+    qv_act = gmax<LPT>(qv_act);                                                                                   // :104
+    const float m = g.vmax(c);                                                                                    // mask_invalid_actions :16-29
+#pragma unroll
+    for (int j = 0; j < APL; ++j)
+        if (g.ok[j]) c[j] = (invalid[static_cast<long>(g.b) * A + g.act[j]] ? kF32Min : c[j] - m) * temperature;    // :120-122
+    g.softmax(c, p);
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < APL; ++j)
+        if (g.ok[j]) exploration_policy_target[static_cast<long>(g.b) * A + g.act[j]] = p[j];
+    if (g.gl == 0) {
+        const float not_term1 = next_term[g.b] ? 0.0f : 1.0f, not_term0 = term[g.b] ? 0.0f : 1.0f;
+        const float from_td = next_reward[g.b] + (discount * next_value[g.b]) * not_term1;                        // :95-96
+        const float vt = q_act > from_td ? q_act : from_td;                                                       // :102
+        const float ut = exploration_ube_target ? mx : qv_act;                                                    // :106
+        value_target[g.b] = vt * not_term0;                                                                       // :109
+        ube_target[g.b] = ut * not_term0;                                                                         // :110
+    }
 }
 
 }  // namespace eaz

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import EazError, SearchOpts, SelfplayCfg, check
+from ._lib import EazError, ReanalyzeCfg, SearchOpts, SelfplayCfg, check
 from .params import fc_weight_list, HASH_MODULE
 
 _contexts: dict[int, "Context"] = {}
@@ -319,6 +319,29 @@ class Search:
                                            _ptr(o["ube_prediction"]), _ptr(o["q_values_epistemic_variance"]), _ptr(o.get("action")),
                                            _stream()))
         return outputs
+
+    # -- "next" drivers --------------------------------------------------------------------------------------------
+    def evaluate(self, states: torch.Tensor, exploitation_beta: float = 0.0, max_episode_length: int = 1000):
+        """src/evaluate.py:13-57 from `states` (advanced in place) -> (per-episode returns [B], loop iterations)."""
+        ret = torch.empty(self.B, device=self.device)
+        it = C.c_int()
+        check(_lib.load().eaz_evaluate_run(self.h, exploitation_beta, max_episode_length, _ptr(states), _ptr(ret), C.byref(it), _stream()))
+        return ret, it.value
+
+    def reanalyze(self, states: torch.Tensor, next_states: torch.Tensor, key=0, gumbel: Optional[torch.Tensor] = None,
+                  reanalyze_beta: float = 0.0, exploration_beta: float = 0.0, exploration_ube_target: bool = True,
+                  exploration_policy_target_temperature: float = 1.0) -> dict:
+        """src/reanalyze.py:52-131 -> dict(value_target, ube_target, exploration_policy_target, exploitation_policy_target, action)."""
+        B, A, dev = self.B, self.A, self.device
+        o = dict(value_target=torch.empty(B, device=dev), ube_target=torch.empty(B, device=dev),
+                 exploration_policy_target=torch.empty(B, A, device=dev), exploitation_policy_target=torch.empty(B, A, device=dev),
+                 action=torch.empty(B, dtype=torch.int32, device=dev))
+        cfg = ReanalyzeCfg(reanalyze_beta, exploration_beta, int(exploration_ube_target), exploration_policy_target_temperature)
+        g = None if gumbel is None else gumbel.to(torch.float32).contiguous()
+        check(_lib.load().eaz_reanalyze_run(self.h, C.byref(cfg), as_key(key), _ptr(states.contiguous()), _ptr(next_states.contiguous()), _ptr(g),
+                                            _ptr(o["value_target"]), _ptr(o["ube_target"]), _ptr(o["exploration_policy_target"]),
+                                            _ptr(o["exploitation_policy_target"]), _ptr(o["action"]), _stream()))
+        return o
 
     # -- instrumentation ----------------------------------------------------------------------------------------
     def profile(self, on: bool):

@@ -186,6 +186,33 @@ EAZ_API int eaz_selfplay_run(eaz_search* s, const eaz_selfplay_cfg* cfg, uint64_
  * d_traj optional [T,B] states before each step. */
 EAZ_API int eaz_random_play(eaz_env* env, int B, int T, uint64_t key, void* d_states, void* d_traj, void* stream);
 
+/* ---- "next" rows of the hot-path table: evaluate and reanalyze drivers (same kernels, different roots) --------------- */
+/* evaluate() src/evaluate.py:13-57: greedy search episodes (the search must have been created with gumbel_scale = 0 and
+ * exploration = 0), beta = exploitation_beta for every env (:34), plain env.step without auto-reset (:47), until every env
+ * is terminated or counter > max_episode_length (:18-20).  d_states: vmap(env.init) states, advanced in place.
+ * d_sum_rewards [B]: per-episode return (the reference returns its mean, :57).  *h_iterations: loop trips executed.
+ * Synchronous (the loop condition is read back every iteration). */
+EAZ_API int eaz_evaluate_run(eaz_search* s, float exploitation_beta, int max_episode_length, void* d_states, float* d_sum_rewards,
+                             int* h_iterations, void* stream);
+
+typedef struct {
+    float reanalyze_beta;                        /* config.py:75, beta of every root (reanalyze.py:75) */
+    float exploration_beta;                      /* config.py:69, used in the exploration policy target (reanalyze.py:112-118) */
+    int exploration_ube_target;                  /* config.py:33 */
+    float exploration_policy_target_temperature; /* config.py:66 */
+} eaz_reanalyze_cfg;
+
+/* reanalyze() src/reanalyze.py:52-131 for B (state, next_state) pairs: search from `states` with the exploitation logits
+ * (search created with exploration = 0 and reanalyze_simulations_per_step), then
+ *   value_target = max(Q_tree[action], r' + gamma * v(next) * !term') * !term      (:88-109)
+ *   ube_target   = (max_a | [action]) qvalues_epistemic_variance * !term           (:103-110)
+ *   exploration_policy_target = softmax(mask(complete(Q + beta*sigma)) * temperature)   (:112-122)
+ *   exploitation_policy_target = action_weights                                     (:129)
+ * d_gumbel: optional explicit unscaled root noise [B,A] (NULL = generated from key).  d_action optional [B]. */
+EAZ_API int eaz_reanalyze_run(eaz_search* s, const eaz_reanalyze_cfg* cfg, uint64_t key, const void* d_states, const void* d_next_states,
+                              const float* d_gumbel, float* d_value_target, float* d_ube_target, float* d_exploration_policy_target,
+                              float* d_exploitation_policy_target, int32_t* d_action, void* stream);
+
 /* ---- instrumentation -------------------------------------------------------------------------------------- */
 /* per-kernel-class device time accumulated with hipEvents on the launch stream while profiling is enabled */
 enum { EAZ_K_TREE = 0, EAZ_K_GATHER = 1, EAZ_K_HASH = 2, EAZ_K_NET = 3, EAZ_K_MISC = 4, EAZ_K_COUNT = 5 };

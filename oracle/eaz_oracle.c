@@ -1115,6 +1115,115 @@ EXPORT void eazo_random_play(const OEnv* env, int B, int T, uint32_t k0, uint32_
     free(act); free(nxt);
 }
 
+/* ===================================================================================================== *
+ *  "next" rows: evaluate (src/evaluate.py:13-57) and reanalyze (src/reanalyze.py:52-131)                *
+ * ===================================================================================================== */
+
+/* evaluate(): greedy search episodes (gumbel_scale = 0, beta = exploitation_beta for every env) until all terminated or
+ * counter > max_episode_length; returns the per-env sums of rewards (the reference returns their mean, :57) and the number
+ * of loop iterations executed.  `states` holds the initial states (vmap(env.init), :52-54) and is advanced in place. */
+EXPORT int eazo_evaluate(const OEnv* env, const ONet* net, int B, int S, float discount, int two_player, float exploitation_beta,
+                         int max_episode_length, void* states, float* sum_rewards) {
+    const int A = env->num_actions, D = env->obs_rows * env->obs_cols, SB = env->state_bytes;
+    OTree* t = eazo_tree_create(env, net, B, S);
+    uint8_t* obs = (uint8_t*)malloc((size_t)B * D);
+    float *ex = (float*)malloc((size_t)B * A * 4), *xp = (float*)malloc((size_t)B * A * 4), *v = (float*)malloc((size_t)B * 4),
+          *u = (float*)malloc((size_t)B * 4), *beta = (float*)malloc((size_t)B * 4), *g = (float*)calloc((size_t)B * A, 4),
+          *aw = (float*)malloc((size_t)B * A * 4);
+    uint8_t* invalid = (uint8_t*)calloc((size_t)B * A, 1);
+    int32_t* act = (int32_t*)malloc((size_t)B * 4);
+    char* nxt = (char*)malloc((size_t)B * SB);
+    for (int b = 0; b < B; ++b) sum_rewards[b] = 0.0f;
+    int counter = 0;
+    for (;;) {
+        int all_term = 1;
+        for (int b = 0; b < B; ++b) all_term &= o_state_terminated(env, (char*)states + (size_t)b * SB);
+        if (all_term || !(counter <= max_episode_length)) break; /* cond_fn :18-20 */
+        eazo_env_observe(env, B, states, obs);
+        eazo_net_forward(net, B, obs, ex, xp, v, u, NULL); /* :26-28 */
+        for (int b = 0; b < B; ++b) {
+            beta[b] = exploitation_beta * 1.0f; /* :34 */
+            for (int a = 0; a < A; ++a) invalid[(size_t)b * A + a] = (uint8_t)!o_state_legal(env, (char*)states + (size_t)b * SB, a);
+        }
+        /* gumbel_scale = 0.0 (:44): the root noise is exactly zero */
+        eazo_search_begin(t, ex, v, u, states, beta, invalid, g, discount, two_player, 0, 1, 1, 0.1f, 50.0f, 16, 0);
+        for (int sim = 0; sim < S; ++sim) eazo_search_sim(t, sim);
+        eazo_search_finish(t, act, aw);
+        eazo_env_step(env, B, states, act, 0, 0, 0, nxt); /* :47 plain env.step, no auto-reset */
+        for (int b = 0; b < B; ++b) sum_rewards[b] += o_state_reward(env, nxt + (size_t)b * SB); /* :48-50 rewards[b, current_player] */
+        memcpy(states, nxt, (size_t)B * SB);
+        counter += 1;
+    }
+    free(obs); free(ex); free(xp); free(v); free(u); free(beta); free(g); free(aw); free(invalid); free(act); free(nxt);
+    eazo_tree_free(t);
+    return counter;
+}
+
+typedef struct {
+    int S;
+    float discount;
+    int two_player;
+    float reanalyze_beta;                         /* config.py:75 */
+    float exploration_beta;                       /* config.py:69 */
+    int exploration_ube_target;                   /* config.py:33 */
+    float exploration_policy_target_temperature;  /* config.py:66 */
+} OReanalyzeCfg;
+
+/* reanalyze(): targets for a batch of (state, next_state) pairs.  gumbel: explicit root noise [B,A] (unscaled; scale 1). */
+EXPORT void eazo_reanalyze(const OEnv* env, const ONet* net, int B, const OReanalyzeCfg* cfg, const void* states, const void* next_states,
+                           const float* gumbel, float* value_target, float* ube_target, float* exploration_policy_target,
+                           float* exploitation_policy_target, int32_t* action_out) {
+    const int A = env->num_actions, D = env->obs_rows * env->obs_cols, SB = env->state_bytes, S = cfg->S;
+    OTree* t = eazo_tree_create(env, net, B, S);
+    uint8_t* obs = (uint8_t*)malloc((size_t)B * D);
+    float *ex = (float*)malloc((size_t)B * A * 4), *xp = (float*)malloc((size_t)B * A * 4), *v = (float*)malloc((size_t)B * 4),
+          *u = (float*)malloc((size_t)B * 4), *nv = (float*)malloc((size_t)B * 4), *nu = (float*)malloc((size_t)B * 4),
+          *beta = (float*)malloc((size_t)B * 4), *sval = (float*)malloc((size_t)B * 4), *sstd = (float*)malloc((size_t)B * 4),
+          *q = (float*)malloc((size_t)B * A * 4), *qv = (float*)malloc((size_t)B * A * 4), *vc = (float*)malloc((size_t)B * A * 4);
+    uint8_t* invalid = (uint8_t*)calloc((size_t)B * A, 1);
+    int32_t* act = (int32_t*)malloc((size_t)B * 4);
+    eazo_env_observe(env, B, states, obs);
+    eazo_net_forward(net, B, obs, ex, xp, v, u, NULL); /* :64-66 */
+    for (int b = 0; b < B; ++b) {
+        beta[b] = 1.0f * cfg->reanalyze_beta; /* :75 */
+        for (int a = 0; a < A; ++a) invalid[(size_t)b * A + a] = (uint8_t)!o_state_legal(env, (const char*)states + (size_t)b * SB, a); /* :62 */
+    }
+    eazo_search_begin(t, ex, v, u, states, beta, invalid, gumbel, cfg->discount, cfg->two_player, 0, 1, 1, 0.1f, 50.0f, 16, 0); /* :77-85 */
+    for (int sim = 0; sim < S; ++sim) eazo_search_sim(t, sim);
+    eazo_search_finish(t, act, exploitation_policy_target); /* :129 exploitation_policy_target = action_weights */
+    eazo_search_summary(t, sval, sstd, q, qv, vc, NULL);
+    eazo_env_observe(env, B, next_states, obs);
+    eazo_net_forward(net, B, obs, xp, xp, nv, nu, NULL); /* :90-92 next_state_value */
+    for (int b = 0; b < B; ++b) {
+        const char* s0 = (const char*)states + (size_t)b * SB;
+        const char* s1 = (const char*)next_states + (size_t)b * SB;
+        const float from_tree = q[(size_t)b * A + act[b]];                                                       /* :88 */
+        const float not_term1 = o_state_terminated(env, s1) ? 0.0f : 1.0f;
+        const float from_td = o_state_reward(env, s1) + (cfg->discount * nv[b]) * not_term1;                    /* :95-96 */
+        float vt = from_tree > from_td ? from_tree : from_td;                                                    /* :102 */
+        float mx = qv[(size_t)b * A];
+        for (int a = 1; a < A; ++a) mx = qv[(size_t)b * A + a] > mx ? qv[(size_t)b * A + a] : mx;               /* :103 */
+        float ut = cfg->exploration_ube_target ? mx : qv[(size_t)b * A + act[b]];                                /* :104-106 */
+        const float not_term0 = o_state_terminated(env, s0) ? 0.0f : 1.0f;
+        value_target[b] = vt * not_term0;                                                                        /* :109 */
+        ube_target[b] = ut * not_term0;                                                                          /* :110 */
+        /* :112-122 exploration policy target: softmax(mask(complete_qs(q + b*sqrt(qvar), visits, value + b*std)) * temperature) */
+        float c[O_MAX_A], m2[O_MAX_A];
+        const float vfill = sval[b] + cfg->exploration_beta * sstd[b];
+        for (int a = 0; a < A; ++a) {
+            const float sc = q[(size_t)b * A + a] + cfg->exploration_beta * sqrtf(qv[(size_t)b * A + a]);
+            c[a] = vc[(size_t)b * A + a] > 0.0f ? sc : vfill;
+        }
+        o_mask_invalid(c, invalid + (size_t)b * A, A, m2);
+        for (int a = 0; a < A; ++a) m2[a] = m2[a] * cfg->exploration_policy_target_temperature;
+        o_softmax(m2, A, exploration_policy_target + (size_t)b * A);
+        if (action_out) action_out[b] = act[b];
+    }
+    free(obs); free(ex); free(xp); free(v); free(u); free(nv); free(nu); free(beta); free(sval); free(sstd); free(q); free(qv);
+    free(vc); free(invalid); free(act);
+    eazo_tree_free(t);
+}
+
 /* misc exports for tests */
 EXPORT float eazo_expf(float x) { return o_expf(x); }
 EXPORT float eazo_logf(float x) { return o_logf(x); }

@@ -82,6 +82,8 @@ def lib():
             "eazo_search_summary": (None, [vp, vp, vp, vp, vp, vp, vp]),
             "eazo_selfplay": (None, [vp, vp, i32, vp, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
             "eazo_random_play": (None, [vp, i32, i32, u32, u32, vp, vp]),
+            "eazo_evaluate": (i32, [vp, vp, i32, i32, f32, i32, f32, i32, vp, vp]),
+            "eazo_reanalyze": (None, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
             "eazo_expf": (f32, [f32]),
             "eazo_logf": (f32, [f32]),
             "eazo_tanhf": (f32, [f32]),
@@ -314,6 +316,36 @@ def random_play(env, B, T, key=(0, 0), want_traj=False):
     traj = np.empty((T, B, env.state_bytes), np.uint8) if want_traj else None
     lib().eazo_random_play(env.h, B, T, key[0], key[1], _p(states), _p(traj))
     return states, traj
+
+
+class ReanalyzeCfg(C.Structure):
+    _fields_ = [("S", C.c_int), ("discount", C.c_float), ("two_player", C.c_int), ("reanalyze_beta", C.c_float),
+                ("exploration_beta", C.c_float), ("exploration_ube_target", C.c_int),
+                ("exploration_policy_target_temperature", C.c_float)]
+
+
+def evaluate(env, net, states, S, discount=0.997, two_player=False, exploitation_beta=0.0, max_episode_length=1000):
+    """src/evaluate.py:13-57; `states` advanced in place -> (returns [B], iterations)."""
+    B = states.shape[0]
+    ret = np.empty(B, np.float32)
+    it = lib().eazo_evaluate(env.h, net.h, B, S, discount, int(two_player), exploitation_beta, max_episode_length, _p(states), _p(ret))
+    return ret, it
+
+
+def reanalyze(env, net, states, next_states, S, gumbel, discount=0.997, two_player=False, reanalyze_beta=0.0, exploration_beta=0.0,
+              exploration_ube_target=True, exploration_policy_target_temperature=1.0):
+    """src/reanalyze.py:52-131."""
+    B, A = states.shape[0], env.num_actions
+    cfg = ReanalyzeCfg(S, discount, int(two_player), reanalyze_beta, exploration_beta, int(exploration_ube_target),
+                       exploration_policy_target_temperature)
+    o = dict(value_target=np.empty(B, np.float32), ube_target=np.empty(B, np.float32),
+             exploration_policy_target=np.empty((B, A), np.float32), exploitation_policy_target=np.empty((B, A), np.float32),
+             action=np.empty(B, np.int32))
+    g = np.ascontiguousarray(gumbel, np.float32)
+    lib().eazo_reanalyze(env.h, net.h, B, C.byref(cfg), _p(np.ascontiguousarray(states)), _p(np.ascontiguousarray(next_states)), _p(g),
+                         _p(o["value_target"]), _p(o["ube_target"]), _p(o["exploration_policy_target"]),
+                         _p(o["exploitation_policy_target"]), _p(o["action"]))
+    return o
 
 
 def considered_visits(m, S):

@@ -122,3 +122,25 @@ def test_subleq_facade_and_uniformrandomplay(eaz, torch):
     assert (out.ube_prediction >= 0).all() and (out.ube_prediction <= 1).all()
     with pytest.raises(AssertionError):
         api.Subleq(tasks=[1], word_size=8)
+
+
+def test_reanalyze_and_evaluate_facade(eaz, torch):
+    from e_alphazero_amd import api
+
+    G, B, S, T = 8, 32, 16, 10
+    env = api.DeepSea(size_of_grid=G, action_map_key=3)
+    config = api.Config(selfplay_batch_size=B, selfplay_simulations_per_step=S, selfplay_steps=T, reanalyze_batch_size=B,
+                        reanalyze_simulations_per_step=S, num_eval_episodes=B)
+    forward = api.get_forward_fn(env, config)
+    model = forward.init(api.random.PRNGKey(0))
+    mk = lambda explore: api.get_epistemic_recurrent_fn(env, forward, B, explore, config.discount, False)  # noqa: E731
+    context = api.Context(env, [0], forward, mk(False), mk(False), mk(False))
+    last, traj = api.uniformrandomplay(config, context, api.random.PRNGKey(4))
+    pair = api.ExperiencePair(first=traj[3], second=traj[4])
+    out = api.reanalyze(model, config, context, pair, api.random.PRNGKey(5))
+    assert out.observation.shape == (B, G, G) and out.value_target.shape == (B,)
+    assert torch.allclose(out.exploitation_policy_target.sum(-1), torch.ones(B, device="cuda"), atol=1e-5)
+    assert torch.allclose(out.exploration_policy_target.sum(-1), torch.ones(B, device="cuda"), atol=1e-5)
+    assert (out.ube_target >= 0).all()
+    ret = api.evaluate(model, config, context, api.random.PRNGKey(6))
+    assert ret.ndim == 0 and 0.0 <= float(ret) <= 1.0

@@ -156,3 +156,45 @@ def test_fc_forward_subleq_shapes(oracle, eaz, torch, W, binary, B):
     for n, a, b in zip(["exploit", "explore", "value", "ube", "novelty"], out, ref):
         np.testing.assert_allclose(a.cpu().numpy(), b, rtol=0, atol=ATOL, err_msg=n)
     assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(out, ref)), "FC forward is specified to be bit-exact"
+
+
+@pytest.mark.parametrize("kind,size,B,S,beta", [("deepsea", 8, 64, 16, 0.0), ("subleq", 16, 48, 16, -0.5)])
+def test_evaluate_matches_oracle(oracle, eaz, torch, kind, size, B, S, beta):
+    """N2: evaluate driver (src/evaluate.py:13-57): greedy search episodes, per-episode returns and loop trip count."""
+    engine, env, net, discount = _build_engine(eaz, kind, size, 7, 0.3)
+    oenv, onet, _ = MG.build(kind, size, 7, 0.3)
+    search = engine.Search(env, net, B, S, discount=discount, gumbel_scale=0.0)
+    st = env.init(B, key=3)
+    ost = oenv.init(B, key=(3, 0))
+    max_len = 10 if kind == "subleq" else 1000  # config.py:123 max_episode_length for subleq
+    ret, it = search.evaluate(st, exploitation_beta=beta, max_episode_length=max_len)
+    oret, oit = oracle.evaluate(oenv, onet, ost, S, discount=discount, exploitation_beta=beta, max_episode_length=max_len)
+    assert it == oit and it >= (size - 1 if kind == "deepsea" else 1)
+    assert np.array_equal(ret.cpu().numpy(), oret)
+    assert np.array_equal(_to_oracle_states(kind, size, st), ost)
+
+
+@pytest.mark.parametrize("kind,size,B,S,kw", [
+    ("deepsea", 8, 96, 16, dict(reanalyze_beta=0.0, exploration_beta=0.0)),
+    ("deepsea", 8, 96, 16, dict(reanalyze_beta=-0.5, exploration_beta=1.0, exploration_ube_target=False, exploration_policy_target_temperature=2.0)),
+    ("subleq", 16, 40, 32, dict(reanalyze_beta=-1.0, exploration_beta=1.0)),
+])
+def test_reanalyze_matches_oracle(oracle, eaz, torch, kind, size, B, S, kw):
+    """N1: reanalyze target builder (src/reanalyze.py:52-131) on (state, next_state) pairs taken from a random-play trajectory."""
+    engine, env, net, discount = _build_engine(eaz, kind, size, 9, 0.3)
+    oenv, onet, _ = MG.build(kind, size, 9, 0.3)
+    _, traj = oracle.random_play(oenv, B, 12, key=(5, 5), want_traj=True)
+    rng = np.random.default_rng(0)
+    t = rng.integers(0, 11, B)
+    s0 = traj[t, np.arange(B)]
+    s1 = traj[t + 1, np.arange(B)]  # contains terminal -> reset transitions as well (reanalyze.py:127 FIXME)
+    g = oracle.gumbel((8, 8), B * env.num_actions).reshape(B, env.num_actions)
+    ref = oracle.reanalyze(oenv, onet, s0, s1, S, g, discount=discount, **kw)
+    conv = (lambda a: a) if kind == "deepsea" else __import__("helpers").subleq_oracle_to_device
+    search = engine.Search(env, net, B, S, discount=discount)
+    out = search.reanalyze(torch.from_numpy(conv(s0)).cuda(), torch.from_numpy(conv(s1)).cuda(), gumbel=torch.from_numpy(g).cuda(), **kw)
+    assert np.array_equal(out["action"].cpu().numpy(), ref["action"])
+    for k in ("value_target", "ube_target", "exploration_policy_target", "exploitation_policy_target"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
+    f = oenv.fields(s0)
+    assert (ref["value_target"][f["terminated"]] == 0).all() and (ref["ube_target"][f["terminated"]] == 0).all()
