@@ -40,6 +40,26 @@ def fc_flops_per_eval(in_dim, H, A, heads):
     return f
 
 
+def cpu_share():
+    """Host cores this process may actually use: affinity mask, cgroup CPU quota, and the 16-core share of a 1-GPU box."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // p))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 16))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,8 +71,8 @@ def main():
     ap.add_argument("--selfplay-steps", type=int, default=32)
     ap.add_argument("--hash-fill", type=float, default=0.5, help="fraction of the novelty bit-set that is set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=1024)
-    ap.add_argument("--cpu-sample-steps", type=int, default=3)
+    ap.add_argument("--cpu-sample-batch", type=int, default=4096)
+    ap.add_argument("--cpu-sample-steps", type=int, default=8)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -161,9 +181,27 @@ def main():
     gbytes = B * (2 * env.state_bytes + env.obs_dim)
     g_ms = prof["gather"]["ms"] / max(prof["gather"]["launches"], 1)
     gach = gbytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
+    # HBM-side traffic per launch from the PMC passes committed under profiles/ (rocprofv3 FETCH_SIZE / WRITE_SIZE cannot be
+    # collected from inside this process); only attached when the file was recorded for this workload
+    traffic = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("workload") == f"DeepSea-{G}, B={B}, {S} sims":
+            for kname, field in (("eaz::fc_forward_kernel", "roofline"), ("eaz::leaf_gather_deepsea_kernel", "roofline_gather")):
+                k = pmc["kernels"].get(kname)
+                if k:
+                    traffic[field] = 1024.0 * (k.get("FETCH_SIZE_KB_per_launch", 0.0) + k.get("WRITE_SIZE_KB_per_launch", 0.0))
+    except (OSError, ValueError):
+        pass
+    if "roofline" in traffic:
+        result["roofline"]["traffic"] = traffic["roofline"]
+        result["roofline"]["traffic_source"] = "profiles/r01_b_pmc_traffic.json (raw FETCH_SIZE+WRITE_SIZE, bytes per launch)"
     result["roofline_gather"] = {"kernel": "leaf_gather_deepsea_kernel", "bound": "hbm", "achieved": gach, "peak": PEAK_HBM_GBPS,
                                  "unit": "GB/s", "frac": gach / PEAK_HBM_GBPS, "traffic": None, "avg_launch_us": 1e3 * g_ms,
                                  "launches": prof["gather"]["launches"], "bytes_per_launch": gbytes}
+    if "roofline_gather" in traffic:
+        result["roofline_gather"]["traffic"] = traffic["roofline_gather"]
     result["kernel_ms_instrumented_pass"] = {k: round(v["ms"], 3) for k, v in prof.items()}
     result["instrumented_pass_env_steps_per_s"] = B * T * args.steps / dt_instr
 
@@ -173,7 +211,7 @@ def main():
         import eaz_oracle as O
 
         cb, ct = args.cpu_sample_batch, args.cpu_sample_steps
-        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        ncores = cpu_share()
         O.lib().eazo_set_num_threads(ncores)
         oenv = O.OracleEnv.deepsea(G, am)
         onet = O.OracleNet(G * G, H, A, eaz.params.fc_weight_list(params), bitset=hstate[eaz.params.HASH_MODULE]["binary_set"])
