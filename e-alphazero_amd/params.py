@@ -82,3 +82,77 @@ def load_npz(path: str):
         mod, name = key.rsplit("/", 1)
         (state if name == "binary_set" else params).setdefault(mod, {})[name] = z[key]
     return params, state
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# EpistemicResidualAZNet (src/network/resnet.py): haiku module names in creation order [EXT naming]
+# ------------------------------------------------------------------------------------------------------------------
+RESNET_PREFIX = "az_resnet"
+RESNET_HASH_MODULE = "az_resnet/xxhash32"
+
+
+def _suffix(base: str, i: int) -> str:
+    return base if i == 0 else f"{base}_{i}"
+
+
+def resnet_module_order(num_blocks: int):
+    """[(kind, module name)] in the order resnet.py:72-121 creates them: kind in {"conv", "bn", "linear"}."""
+    P = RESNET_PREFIX
+    order = [("conv", f"{P}/conv2_d")]
+    for b in range(num_blocks):
+        order += [("bn", f"{P}/block_{b}/batch_norm"), ("conv", f"{P}/block_{b}/conv2_d"),
+                  ("bn", f"{P}/block_{b}/batch_norm_1"), ("conv", f"{P}/block_{b}/conv2_d_1")]
+    order += [("bn", f"{P}/batch_norm")]
+    order += [("conv", f"{P}/conv2_d_1"), ("bn", f"{P}/batch_norm_1"), ("linear", f"{P}/linear")]                       # policy
+    order += [("conv", f"{P}/conv2_d_2"), ("bn", f"{P}/batch_norm_2"), ("linear", f"{P}/linear_1")]                     # exploration
+    order += [("conv", f"{P}/conv2_d_3"), ("bn", f"{P}/batch_norm_3"), ("linear", f"{P}/linear_2"), ("linear", f"{P}/linear_3")]  # value
+    order += [("conv", f"{P}/conv2_d_4"), ("bn", f"{P}/batch_norm_4"), ("linear", f"{P}/linear_4"), ("linear", f"{P}/linear_5")]  # ube
+    return order
+
+
+def init_resnet_params(H: int, W: int, cin: int, num_actions: int, num_channels: int = 64, num_blocks: int = 5, seed: int = 0):
+    """Random-init weights of the reference architecture (hk.Conv2D / hk.Linear: trunc-normal, sigma = 1/sqrt(fan_in), zero
+    bias) and SYNTHETIC BatchNorm statistics (scale ~ U(0.8,1.2), offset ~ N(0,0.1), mean ~ N(0,0.1), var ~ U(0.5,1.5)): a
+    never-trained haiku state has var_ema = 0, which would scale activations by 316x per BatchNorm.  -> (params, state)."""
+    rng = np.random.default_rng(seed)
+
+    def tn(shape, fan_in):
+        w = rng.standard_normal(shape)
+        bad = np.abs(w) > 2.0
+        while bad.any():
+            w[bad] = rng.standard_normal(int(bad.sum()))
+            bad = np.abs(w) > 2.0
+        return (w / np.sqrt(fan_in)).astype(np.float32)
+
+    C, P = num_channels, H * W
+    conv_shapes = [(3, 3, cin, C)] + [(3, 3, C, C)] * (2 * num_blocks) + [(1, 1, C, 2), (1, 1, C, 2), (1, 1, C, 1), (1, 1, C, 1)]
+    bn_ch = [C] * (2 * num_blocks) + [C, 2, 2, 1, 1]
+    lin_shapes = [(P * 2, num_actions), (P * 2, num_actions), (P, C), (C, 1), (P, C), (C, 1)]
+    ci, bi, li = iter(conv_shapes), iter(bn_ch), iter(lin_shapes)
+    params, state = {}, {RESNET_HASH_MODULE: {"binary_set": np.zeros(1 << 21, np.uint8)}}
+    for kind, name in resnet_module_order(num_blocks):
+        if kind == "conv":
+            sh = next(ci)
+            params[name] = {"w": tn(sh, sh[0] * sh[1] * sh[2]), "b": np.zeros(sh[3], np.float32)}
+        elif kind == "linear":
+            sh = next(li)
+            params[name] = {"w": tn(sh, sh[0]), "b": np.zeros(sh[1], np.float32)}
+        else:
+            c = next(bi)
+            params[name] = {"scale": rng.uniform(0.8, 1.2, c).astype(np.float32), "offset": (0.1 * rng.standard_normal(c)).astype(np.float32)}
+            state[f"{name}/~/mean_ema"] = {"average": (0.1 * rng.standard_normal(c)).astype(np.float32)}
+            state[f"{name}/~/var_ema"] = {"average": rng.uniform(0.5, 1.5, c).astype(np.float32)}
+    return params, state
+
+
+def resnet_array_list(params, state, num_blocks: int):
+    """Flat list of float32 arrays in the order eaz_net_create_resnet / eazo_resnet_create expect (42 + 12*num_blocks arrays)."""
+    out = []
+    for kind, name in resnet_module_order(num_blocks):
+        if kind in ("conv", "linear"):
+            out += [np.ascontiguousarray(params[name]["w"], np.float32).reshape(-1), np.ascontiguousarray(params[name]["b"], np.float32)]
+        else:
+            out += [np.ascontiguousarray(params[name]["scale"], np.float32), np.ascontiguousarray(params[name]["offset"], np.float32),
+                    np.ascontiguousarray(state[f"{name}/~/mean_ema"]["average"], np.float32),
+                    np.ascontiguousarray(state[f"{name}/~/var_ema"]["average"], np.float32)]
+    return out

@@ -39,7 +39,7 @@
  *  Environments                                                                                         *
  * ===================================================================================================== */
 
-enum { O_ENV_DEEPSEA = 0, O_ENV_SUBLEQ = 1 };
+enum { O_ENV_DEEPSEA = 0, O_ENV_SUBLEQ = 1, O_ENV_CONNECT4 = 2 };
 
 typedef struct OEnv {
     int kind;
@@ -312,30 +312,104 @@ static void o_subleq_observe(const OEnv* e, const OSubleqState* s, uint8_t* obs)
     for (int i = 0; i < O_IOLEN; ++i, p += C) o_subleq_encode_row(e, s->ex_out_after[i], p);
 }
 
-/* ---- generic env (pgx.Env wrapper [EXT], SURVEY.md A.1; called at context.py:127, selfplay.py:135,166) - */
+/* ---- connect_four: pgx.connect_four [EXT] -- **parity unpinned** (pgx is un-vendored, Pipfile:8 "*").  Restated from the
+ * public pgx v2 game: 6x7 board stored row-major with row 0 at the TOP, stones fall to the highest free row index,
+ * color 0 moves first, a player identity (current_player) is drawn at init, winner = +1 / loser = -1, draw = 0,
+ * observation [6,7,2] = (stones of the player to move, stones of the opponent).  Used by BASELINE.json configs[3]. ---- */
+typedef struct {
+    int32_t step_count;      /* _step_count */
+    int32_t current_player;  /* State.current_player (identity of the player to move) */
+    float reward0;           /* rewards[0] */
+    uint8_t terminated, truncated, color /* GameState.color: whose stones are placed next */, pad;
+    float reward1;           /* rewards[1] */
+    int32_t winner;          /* GameState.winner: -1 none, else color */
+    int8_t board[42];        /* -1 empty, 0 / 1 stone color */
+    uint8_t pad2[14];
+} OConnect4State; /* 80 bytes, identical to eaz_connect4_state of include/eaz.h */
 
-static int o_state_terminated(const OEnv* e, const void* s) {
-    return e->kind == O_ENV_DEEPSEA ? ((const ODeepSeaState*)s)->terminated : ((const OSubleqState*)s)->terminated;
+static void o_c4_init(OKey key, OConnect4State* s) {
+    memset(s, 0, sizeof(*s));
+    s->current_player = (int32_t)(o_bits(key, 0) & 1u); /* jnp.int32(jax.random.bernoulli(key)) */
+    s->winner = -1;
+    for (int i = 0; i < 42; ++i) s->board[i] = -1;
 }
-static int o_state_truncated(const OEnv* e, const void* s) {
-    return e->kind == O_ENV_DEEPSEA ? ((const ODeepSeaState*)s)->truncated : ((const OSubleqState*)s)->truncated;
+static int o_c4_col_count(const OConnect4State* s, int c) {
+    int n = 0;
+    for (int r = 0; r < 6; ++r) n += s->board[r * 7 + c] >= 0;
+    return n;
 }
-static float o_state_reward(const OEnv* e, const void* s) {
-    return e->kind == O_ENV_DEEPSEA ? ((const ODeepSeaState*)s)->reward : ((const OSubleqState*)s)->reward;
+static int o_c4_won(const int8_t* b, int color) { /* any of the 69 lines of four */
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 7; ++c) {
+            static const int D[4][2] = {{0, 1}, {1, 0}, {1, 1}, {1, -1}};
+            for (int d = 0; d < 4; ++d) {
+                int ok = 1;
+                for (int k = 0; k < 4 && ok; ++k) {
+                    const int rr = r + k * D[d][0], cc = c + k * D[d][1];
+                    ok = rr >= 0 && rr < 6 && cc >= 0 && cc < 7 && b[rr * 7 + cc] == color;
+                }
+                if (ok) return 1;
+            }
+        }
+    return 0;
 }
-static void o_state_set_reward(const OEnv* e, void* s, float r) {
-    if (e->kind == O_ENV_DEEPSEA) ((ODeepSeaState*)s)->reward = r; else ((OSubleqState*)s)->reward = r;
+/* ConnectFour._step (step_count already incremented) */
+static void o_c4_step(OConnect4State* s, int action) {
+    const int n = o_c4_col_count(s, action);
+    const int color = s->color;
+    const int mover = s->current_player;
+    if (n < 6) s->board[(5 - n) * 7 + action] = (int8_t)color; /* a full column is an illegal action: handled by the wrapper */
+    const int won = o_c4_won(s->board, color);
+    s->winner = won ? color : -1;
+    s->color = (uint8_t)(1 - color);
+    s->current_player = 1 - mover;
+    int full = 1;
+    for (int c = 0; c < 7; ++c) full &= o_c4_col_count(s, c) == 6;
+    s->terminated = (uint8_t)(won || full);
+    /* rewards: the player who completed four gets +1, the other -1; zeros otherwise */
+    s->reward0 = 0.0f; s->reward1 = 0.0f;
+    if (won) { if (mover == 0) { s->reward0 = 1.0f; s->reward1 = -1.0f; } else { s->reward0 = -1.0f; s->reward1 = 1.0f; } }
 }
-static void o_state_set_terminated(const OEnv* e, void* s) {
-    if (e->kind == O_ENV_DEEPSEA) ((ODeepSeaState*)s)->terminated = 1; else ((OSubleqState*)s)->terminated = 1;
+/* observation from the perspective of the player to move: [6,7,2] = (board == my color, board == other color) */
+static void o_c4_observe(const OConnect4State* s, uint8_t* obs) {
+    for (int i = 0; i < 42; ++i) {
+        obs[2 * i] = (uint8_t)(s->board[i] == (int8_t)s->color);
+        obs[2 * i + 1] = (uint8_t)(s->board[i] == (int8_t)(1 - s->color));
+    }
 }
-/* legal_action_mask: all-true for DeepSea (deep_sea.py:19) and Subleq (subleq.py:626); pgx resets it to
- * all-true at terminal states, which is a no-op here. */
-static int o_state_legal(const OEnv* e, const void* s, int a) { (void)e; (void)s; (void)a; return 1; }
+
+/* ---- generic env (pgx.Env wrapper [EXT], SURVEY.md A.1; called at context.py:127, selfplay.py:135,166) - */
+/* every state blob starts with {int32 step_count; int32 aux; float reward0; uint8 terminated, truncated, ..} */
+typedef struct { int32_t step_count, aux; float reward0; uint8_t terminated, truncated, x, y; } OStateHeader;
+
+static int o_state_terminated(const OEnv* e, const void* s) { (void)e; return ((const OStateHeader*)s)->terminated; }
+static int o_state_truncated(const OEnv* e, const void* s) { (void)e; return ((const OStateHeader*)s)->truncated; }
+static int o_state_current_player(const OEnv* e, const void* s) {
+    return e->kind == O_ENV_CONNECT4 ? ((const OConnect4State*)s)->current_player : 0;
+}
+/* rewards[player] */
+static float o_state_reward(const OEnv* e, const void* s, int player) {
+    if (e->kind == O_ENV_CONNECT4 && player == 1) return ((const OConnect4State*)s)->reward1;
+    return ((const OStateHeader*)s)->reward0;
+}
+static void o_state_zero_rewards(const OEnv* e, void* s) {
+    ((OStateHeader*)s)->reward0 = 0.0f;
+    if (e->kind == O_ENV_CONNECT4) ((OConnect4State*)s)->reward1 = 0.0f;
+}
+static void o_state_set_terminated(const OEnv* e, void* s) { (void)e; ((OStateHeader*)s)->terminated = 1; }
+/* legal_action_mask: all-true for DeepSea (deep_sea.py:19) and Subleq (subleq.py:626); connect_four: column not full.
+ * pgx resets the mask to all-true at terminal states. */
+static int o_state_legal(const OEnv* e, const void* s, int a) {
+    if (e->kind != O_ENV_CONNECT4) return 1;
+    const OConnect4State* c = (const OConnect4State*)s;
+    if (c->terminated) return 1;
+    return o_c4_col_count(c, a) < 6;
+}
 
 static void o_env_init(const OEnv* e, OKey key, void* s) {
     if (e->kind == O_ENV_DEEPSEA) o_deepsea_init(e, (ODeepSeaState*)s);
-    else o_subleq_init(e, key, (OSubleqState*)s);
+    else if (e->kind == O_ENV_SUBLEQ) o_subleq_init(e, key, (OSubleqState*)s);
+    else o_c4_init(key, (OConnect4State*)s);
 }
 
 /* pgx.Env.step [EXT] */
@@ -343,26 +417,37 @@ static void o_env_step(const OEnv* e, const void* in, int action, OKey key, void
     (void)key;
     int illegal = !o_state_legal(e, in, action);
     memcpy(out, in, (size_t)e->state_bytes);
+    const int mover = o_state_current_player(e, in);
     if (o_state_terminated(e, in) || o_state_truncated(e, in)) {
-        o_state_set_reward(e, out, 0.0f); /* same state, zero rewards */
+        o_state_zero_rewards(e, out); /* same state, zero rewards */
     } else if (e->kind == O_ENV_DEEPSEA) {
         ODeepSeaState* s = (ODeepSeaState*)out;
         s->step_count += 1;
         o_deepsea_step(e, s, action);
-    } else {
+    } else if (e->kind == O_ENV_SUBLEQ) {
         OSubleqState* s = (OSubleqState*)out;
         s->step_count += 1;
         o_subleq_step(e, s, action);
+    } else {
+        OConnect4State* s = (OConnect4State*)out;
+        s->step_count += 1;
+        o_c4_step(s, action);
     }
-    if (illegal) { /* _step_with_illegal_action: single player -> rewards = [-1], terminated */
-        o_state_set_reward(e, out, -1.0f);
+    if (illegal) { /* _step_with_illegal_action: the mover gets -1, every other player +1 * (num_players - 1); terminated */
+        ((OStateHeader*)out)->reward0 = -1.0f;
+        if (e->kind == O_ENV_CONNECT4) {
+            OConnect4State* s = (OConnect4State*)out;
+            s->reward0 = mover == 0 ? -1.0f : 1.0f;
+            s->reward1 = mover == 1 ? -1.0f : 1.0f;
+        }
         o_state_set_terminated(e, out);
     }
 }
 
 static void o_env_observe(const OEnv* e, const void* s, uint8_t* obs) {
     if (e->kind == O_ENV_DEEPSEA) o_deepsea_observe(e, (const ODeepSeaState*)s, obs);
-    else o_subleq_observe(e, (const OSubleqState*)s, obs);
+    else if (e->kind == O_ENV_SUBLEQ) o_subleq_observe(e, (const OSubleqState*)s, obs);
+    else o_c4_observe((const OConnect4State*)s, obs);
 }
 
 /* src/selfplay.py:26-75 (auto_reset): reset if ALREADY terminal, else step.  key1 -> init, key2 -> step */
@@ -401,6 +486,16 @@ EXPORT OEnv* eazo_env_subleq(int W, const int* tasks, int n_tasks, int binary) {
     e->obs_rows = W + 4 * O_IOLEN;              /* subleq.py:618-621 */
     e->obs_cols = binary ? e->enc_width : W + 1;
     e->state_bytes = (int)sizeof(OSubleqState);
+    return e;
+}
+
+EXPORT OEnv* eazo_env_connect4(void) {
+    OEnv* e = (OEnv*)calloc(1, sizeof(OEnv));
+    e->kind = O_ENV_CONNECT4;
+    e->num_actions = 7;
+    e->obs_rows = 42; /* [6,7,2] flattened as 42 cells x 2 planes */
+    e->obs_cols = 2;
+    e->state_bytes = (int)sizeof(OConnect4State);
     return e;
 }
 
@@ -447,9 +542,8 @@ EXPORT void eazo_env_fields(const OEnv* e, int B, const void* states, uint8_t* t
         const void* s = (const char*)states + (size_t)b * e->state_bytes;
         if (terminated) terminated[b] = (uint8_t)o_state_terminated(e, s);
         if (truncated) truncated[b] = (uint8_t)o_state_truncated(e, s);
-        if (reward) reward[b] = o_state_reward(e, s);
-        if (step_count) step_count[b] = e->kind == O_ENV_DEEPSEA ? ((const ODeepSeaState*)s)->step_count
-                                                                 : ((const OSubleqState*)s)->step_count;
+        if (reward) reward[b] = o_state_reward(e, s, 0);
+        if (step_count) step_count[b] = ((const OStateHeader*)s)->step_count;
     }
 }
 
@@ -535,7 +629,9 @@ EXPORT uint32_t eazo_xxh_avalanche(uint32_t h) {
  *  Fully-connected epistemic net (src/network/fully_connected.py:41-101)                                *
  * ===================================================================================================== */
 
+struct OResNet;
 typedef struct ONet {
+    struct OResNet* resnet; /* non-NULL: EpistemicResidualAZNet (src/network/resnet.py), the FC fields below are unused */
     int in_dim, H, A;
     float* w[12]; /* haiku creation order: value 0-2, ube 3-5, exploitation 6-8, exploration 9-11; w:[in,out] */
     float* b[12];
@@ -563,8 +659,10 @@ EXPORT ONet* eazo_net_create(int in_dim, int H, int A, const float* const* w, co
     n->hash_off = hash_off; n->hash_len = hash_len; n->hash_bits = hash_bits; n->bitset = bitset;
     return n;
 }
+static void o_resnet_free(struct OResNet* r);
 EXPORT void eazo_net_free(ONet* n) {
     if (!n) return;
+    if (n->resnet) { o_resnet_free(n->resnet); free(n); return; }
     for (int l = 0; l < 12; ++l) { free(n->w[l]); free(n->b[l]); }
     free(n);
 }
@@ -598,8 +696,10 @@ static void o_linear(int B, int K, int N, const float* x, const float* w, const 
 
 /* EpistemicFullyConnectedAZNet.__call__(x, is_training=False), src/network/fully_connected.py:41-101.
  * Returns (exploitation_logits, exploration_logits, v, u, scaled_state_novelty) -- the code's order (:101). */
+static void o_resnet_forward(const ONet* n, int B, const uint8_t* obs, float* exploit, float* explore, float* v, float* u, float* nov);
 EXPORT void eazo_net_forward(const ONet* n, int B, const uint8_t* obs, float* exploit, float* explore, float* v,
                              float* u, float* nov) {
+    if (n->resnet) { o_resnet_forward(n, B, obs, exploit, explore, v, u, nov); return; }
     const int K = n->in_dim, H = n->H, A = n->A;
     if (H > 256 || A > O_MAX_A) { fprintf(stderr, "eazo_net_forward: H/A too large\n"); abort(); }
     float* x = (float*)malloc((size_t)B * K * sizeof(float));
@@ -634,6 +734,152 @@ EXPORT void eazo_net_forward(const ONet* n, int B, const uint8_t* obs, float* ex
 }
 
 /* ===================================================================================================== *
+ *  Residual epistemic net (src/network/resnet.py:42-135), NHWC, BlockV2 (:26-39), eval-mode BatchNorm      *
+ * ===================================================================================================== */
+/* Numerics spec of the build (DESIGN.md "ResNet forward"):
+ *   hk.Conv2D (SAME, stride 1): acc = +0; for tap (kh, kw) row-major, for ci ascending: acc = fmaf(x[h+kh-1][w+kw-1][ci], w[tap][ci][co], acc)
+ *                               with out-of-board taps skipped (their contribution is an exact +-0); y = acc + b[co]
+ *   hk.BatchNorm eval:          y = (x - mean) * inv + offset,  inv = scale / sqrtf(var + 1e-5f)  (precomputed per channel)
+ *   hk.Linear:                  as in the FC net (k-ascending fmaf chain, then + b) */
+typedef struct { float *w, *b; int taps, cin, cout; } OConv;
+typedef struct { float *scale, *offset, *mean, *var, *inv; int c; } OBN;
+typedef struct { float *w, *b; int in, out; } OLin;
+typedef struct OResNet {
+    int H, W, Cin, C, nb, A;
+    OConv conv0, c1[16], c2[16];
+    OBN bn1[16], bn2[16], bnf;
+    OConv hc[4]; /* 1x1 convs of the policy, exploration, value, ube heads (resnet.py:84,92,102,114) */
+    OBN hbn[4];
+    OLin pl, xl, vl1, vl2, ul1, ul2;
+} OResNet;
+
+static float* o_dup(const float* p, size_t n) { float* q = (float*)malloc(n * sizeof(float)); memcpy(q, p, n * sizeof(float)); return q; }
+static int o_take_conv(OConv* c, const float* const* a, int i, int taps, int cin, int cout) {
+    c->taps = taps; c->cin = cin; c->cout = cout;
+    c->w = o_dup(a[i], (size_t)taps * cin * cout); c->b = o_dup(a[i + 1], (size_t)cout);
+    return i + 2;
+}
+static int o_take_bn(OBN* b, const float* const* a, int i, int c) {
+    b->c = c;
+    b->scale = o_dup(a[i], c); b->offset = o_dup(a[i + 1], c); b->mean = o_dup(a[i + 2], c); b->var = o_dup(a[i + 3], c);
+    b->inv = (float*)malloc(sizeof(float) * c);
+    for (int k = 0; k < c; ++k) b->inv[k] = b->scale[k] / sqrtf(b->var[k] + 1e-5f);
+    return i + 4;
+}
+static int o_take_lin(OLin* l, const float* const* a, int i, int in, int out) {
+    l->in = in; l->out = out;
+    l->w = o_dup(a[i], (size_t)in * out); l->b = o_dup(a[i + 1], (size_t)out);
+    return i + 2;
+}
+static void o_free_conv(OConv* c) { free(c->w); free(c->b); }
+static void o_free_bn(OBN* b) { free(b->scale); free(b->offset); free(b->mean); free(b->var); free(b->inv); }
+static void o_free_lin(OLin* l) { free(l->w); free(l->b); }
+static void o_resnet_free(OResNet* r) {
+    o_free_conv(&r->conv0); o_free_bn(&r->bnf);
+    for (int i = 0; i < r->nb; ++i) { o_free_conv(&r->c1[i]); o_free_conv(&r->c2[i]); o_free_bn(&r->bn1[i]); o_free_bn(&r->bn2[i]); }
+    for (int h = 0; h < 4; ++h) { o_free_conv(&r->hc[h]); o_free_bn(&r->hbn[h]); }
+    o_free_lin(&r->pl); o_free_lin(&r->xl); o_free_lin(&r->vl1); o_free_lin(&r->vl2); o_free_lin(&r->ul1); o_free_lin(&r->ul2);
+    free(r);
+}
+
+/* arrays in haiku creation order (resnet.py:72-121): conv0 {w,b}; per block {bn1 x4, conv1 {w,b}, bn2 x4, conv2 {w,b}}; final bn x4;
+ * policy {conv w,b; bn x4; linear w,b}; exploration (same); value {conv; bn; linear(C) w,b; linear(1) w,b}; ube (same).
+ * bn x4 = scale, offset, mean EMA, var EMA.  42 + 12*num_blocks arrays. */
+EXPORT ONet* eazo_resnet_create(int H, int W, int Cin, int C, int num_blocks, int A, const float* const* a, int n_arrays,
+                                int hash_bits, const uint8_t* bitset) {
+    if (num_blocks > 16 || n_arrays != 42 + 12 * num_blocks || (H * W * Cin) % 4 != 0) return NULL;
+    OResNet* r = (OResNet*)calloc(1, sizeof(OResNet));
+    r->H = H; r->W = W; r->Cin = Cin; r->C = C; r->nb = num_blocks; r->A = A;
+    int i = o_take_conv(&r->conv0, a, 0, 9, Cin, C);
+    for (int k = 0; k < num_blocks; ++k) {
+        i = o_take_bn(&r->bn1[k], a, i, C); i = o_take_conv(&r->c1[k], a, i, 9, C, C);
+        i = o_take_bn(&r->bn2[k], a, i, C); i = o_take_conv(&r->c2[k], a, i, 9, C, C);
+    }
+    i = o_take_bn(&r->bnf, a, i, C);
+    i = o_take_conv(&r->hc[0], a, i, 1, C, 2); i = o_take_bn(&r->hbn[0], a, i, 2); i = o_take_lin(&r->pl, a, i, H * W * 2, A);
+    i = o_take_conv(&r->hc[1], a, i, 1, C, 2); i = o_take_bn(&r->hbn[1], a, i, 2); i = o_take_lin(&r->xl, a, i, H * W * 2, A);
+    i = o_take_conv(&r->hc[2], a, i, 1, C, 1); i = o_take_bn(&r->hbn[2], a, i, 1); i = o_take_lin(&r->vl1, a, i, H * W, C); i = o_take_lin(&r->vl2, a, i, C, 1);
+    i = o_take_conv(&r->hc[3], a, i, 1, C, 1); i = o_take_bn(&r->hbn[3], a, i, 1); i = o_take_lin(&r->ul1, a, i, H * W, C); i = o_take_lin(&r->ul2, a, i, C, 1);
+    ONet* n = (ONet*)calloc(1, sizeof(ONet));
+    n->resnet = r;
+    n->in_dim = H * W * Cin; n->A = A; n->H = C;
+    n->max_u = 1.0f; n->nov_scale = 1.0f; /* resnet.py:63-64 */
+    n->hash_off = 0; n->hash_len = H * W * Cin; n->hash_bits = hash_bits; n->bitset = bitset;
+    return n;
+}
+
+/* y[p][co] = conv(x)[p][co] + b[co]   (x: [H*W][cin] NHWC) */
+static void o_conv(const OResNet* r, const OConv* c, const float* x, float* y) {
+    const int H = r->H, W = r->W, cin = c->cin, cout = c->cout, half = c->taps == 9 ? 1 : 0;
+    for (int h = 0; h < H; ++h)
+        for (int w = 0; w < W; ++w) {
+            float acc[64];
+            for (int co = 0; co < cout; ++co) acc[co] = 0.0f;
+            for (int kh = -half; kh <= half; ++kh)
+                for (int kw = -half; kw <= half; ++kw) {
+                    const int hh = h + kh, ww = w + kw;
+                    if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+                    const int tap = (kh + half) * (2 * half + 1) + (kw + half);
+                    const float* xp = x + (size_t)(hh * W + ww) * cin;
+                    const float* wp = c->w + (size_t)tap * cin * cout;
+                    for (int ci = 0; ci < cin; ++ci) {
+                        const float xv = xp[ci];
+                        for (int co = 0; co < cout; ++co) acc[co] = fmaf(xv, wp[(size_t)ci * cout + co], acc[co]);
+                    }
+                }
+            for (int co = 0; co < cout; ++co) y[(size_t)(h * W + w) * cout + co] = acc[co] + c->b[co];
+        }
+}
+static void o_bn_relu(const OBN* b, const float* x, float* y, int P) {
+    for (int p = 0; p < P; ++p)
+        for (int k = 0; k < b->c; ++k) {
+            const float v = (x[(size_t)p * b->c + k] - b->mean[k]) * b->inv[k] + b->offset[k];
+            y[(size_t)p * b->c + k] = v > 0.0f ? v : 0.0f;
+        }
+}
+static void o_lin(const OLin* l, const float* x, float* y, int relu) {
+    for (int j = 0; j < l->out; ++j) {
+        float acc = 0.0f;
+        for (int k = 0; k < l->in; ++k) acc = fmaf(x[k], l->w[(size_t)k * l->out + j], acc);
+        acc = acc + l->b[j];
+        y[j] = relu ? (acc > 0.0f ? acc : 0.0f) : acc;
+    }
+}
+
+static void o_resnet_forward(const ONet* n, int B, const uint8_t* obs, float* exploit, float* explore, float* v, float* u, float* nov) {
+    const OResNet* r = n->resnet;
+    const int P = r->H * r->W, C = r->C, D = P * r->Cin, A = r->A;
+    if (C > 64 || A > 64) { fprintf(stderr, "o_resnet_forward: C/A too large\n"); abort(); }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < B; ++b) {
+        float x0[42 * 8], X[42 * 64], U[42 * 64], T[42 * 64], hbuf[42 * 2], hact[42 * 2], fc[64], out[64];
+        for (int i = 0; i < D; ++i) x0[i] = (float)obs[(size_t)b * D + i];         /* resnet.py:69 astype(float32) */
+        o_conv(r, &r->conv0, x0, X);                                                /* :70 */
+        for (int k = 0; k < r->nb; ++k) {                                           /* BlockV2 :31-39 */
+            o_bn_relu(&r->bn1[k], X, U, P);
+            o_conv(r, &r->c1[k], U, T);
+            o_bn_relu(&r->bn2[k], T, U, P);
+            o_conv(r, &r->c2[k], U, T);
+            for (int i = 0; i < P * C; ++i) X[i] = T[i] + X[i];                     /* :39 x + i */
+        }
+        o_bn_relu(&r->bnf, X, U, P);                                                /* :79-81 */
+        for (int h = 0; h < 4; ++h) {
+            o_conv(r, &r->hc[h], U, hbuf);
+            o_bn_relu(&r->hbn[h], hbuf, hact, P);                                   /* flatten keeps (h, w, c) order */
+            if (h == 0 && exploit) o_lin(&r->pl, hact, exploit + (size_t)b * A, 0);    /* :84-88 */
+            else if (h == 1 && explore) o_lin(&r->xl, hact, explore + (size_t)b * A, 0); /* :91-98 */
+            else if (h == 2) { o_lin(&r->vl1, hact, fc, 1); o_lin(&r->vl2, fc, out, 0); if (v) v[b] = o_tanhf(out[0]); }             /* :101-109 */
+            else if (h == 3) { o_lin(&r->ul1, hact, fc, 1); o_lin(&r->ul2, fc, out, 0); if (u) u[b] = 0.5f * (o_tanhf(out[0]) + 1.0f); } /* :112-121 */
+        }
+        int seen = 0;
+        if (n->bitset) seen = o_hash_seen(n->bitset, o_xxhash_variant(obs + (size_t)b * D, D, n->hash_bits));
+        const float novelty = (seen ? 0.0f : 1.0f) * n->nov_scale;                  /* :124-125 */
+        if (u) u[b] = novelty > u[b] ? novelty : u[b];                              /* :127-130 (not is_training) */
+        if (nov) nov[b] = novelty;
+    }
+}
+
+/* ===================================================================================================== *
  *  Gumbel-MuZero search with epistemic fields  (emctx [EXT]; call site src/selfplay.py:100-121)         *
  *  **parity unpinned** -- restated from the public mctx design + E-MCTS paper, SURVEY.md Appendix A.     *
  * ===================================================================================================== */
@@ -651,7 +897,7 @@ typedef struct OTree {
     char* embeddings;      /* [B,N,state_bytes] */
     int state_bytes;
     /* per-simulation scratch */
-    int32_t *sim_parent, *sim_action, *sim_next; /* [B] */
+    int32_t *sim_parent, *sim_action, *sim_next, *sim_player; /* [B] */
     uint8_t* obs;                                /* [B,obs_dim] */
     char* next_states;                           /* [B,state_bytes] */
     float *o_exploit, *o_explore, *o_v, *o_u, *o_nov;
@@ -847,7 +1093,7 @@ EXPORT OTree* eazo_tree_create(const OEnv* env, const ONet* net, int B, int S) {
     ALLOC(t->children_discounts, float, bna); ALLOC(t->children_var, float, bna); ALLOC(t->children_reward_var, float, bna);
     ALLOC(t->beta, float, B); ALLOC(t->root_invalid, uint8_t, (size_t)B * A); ALLOC(t->root_gumbel, float, (size_t)B * A);
     ALLOC(t->embeddings, char, bn * (size_t)t->state_bytes);
-    ALLOC(t->sim_parent, int32_t, B); ALLOC(t->sim_action, int32_t, B); ALLOC(t->sim_next, int32_t, B);
+    ALLOC(t->sim_parent, int32_t, B); ALLOC(t->sim_action, int32_t, B); ALLOC(t->sim_next, int32_t, B); ALLOC(t->sim_player, int32_t, B);
     ALLOC(t->obs, uint8_t, (size_t)B * env->obs_rows * env->obs_cols);
     ALLOC(t->next_states, char, (size_t)B * t->state_bytes);
     ALLOC(t->o_exploit, float, (size_t)B * A); ALLOC(t->o_explore, float, (size_t)B * A);
@@ -862,7 +1108,7 @@ EXPORT void eazo_tree_free(OTree* t) {
     free(t->raw_var); free(t->node_var); free(t->children_index); free(t->children_visits); free(t->children_prior_logits);
     free(t->children_values); free(t->children_rewards); free(t->children_discounts); free(t->children_var);
     free(t->children_reward_var); free(t->beta); free(t->root_invalid); free(t->root_gumbel); free(t->embeddings);
-    free(t->sim_parent); free(t->sim_action); free(t->sim_next); free(t->obs); free(t->next_states);
+    free(t->sim_parent); free(t->sim_action); free(t->sim_next); free(t->sim_player); free(t->obs); free(t->next_states);
     free(t->o_exploit); free(t->o_explore); free(t->o_v); free(t->o_u); free(t->o_nov); free(t->table);
     free(t);
 }
@@ -934,6 +1180,7 @@ EXPORT void eazo_search_sim(OTree* t, int sim) {
         t->sim_parent[b] = parent; t->sim_action[b] = action; t->sim_next[b] = nxt;
         const char* emb = t->embeddings + ((size_t)b * N + parent) * SB;
         char* ns = t->next_states + (size_t)b * SB;
+        t->sim_player[b] = o_state_current_player(env, emb); /* context.py:125 */
         o_env_step(env, emb, action, key, ns);
         o_env_observe(env, ns, t->obs + (size_t)b * D);
     }
@@ -950,7 +1197,7 @@ EXPORT void eazo_search_sim(OTree* t, int sim) {
         const float m = o_max(lg, A);
         for (int a = 0; a < A; ++a) dst[a] = o_state_legal(env, ns, a) ? lg[a] - m : O_F32_MIN; /* :135-137 */
         const int term = o_state_terminated(env, ns);
-        const float reward = o_state_reward(env, ns);                     /* :139 rewards[b, current_player] */
+        const float reward = o_state_reward(env, ns, t->sim_player[b]);   /* :139 rewards[b, current_player BEFORE the step (:125)] */
         const float value = term ? 0.0f : t->o_v[b];                      /* :140 */
         const float var = term ? 0.0f : t->o_u[b];                        /* :141 */
         float disc = 1.0f * t->discount;                                  /* :142 */
@@ -1150,7 +1397,8 @@ EXPORT int eazo_evaluate(const OEnv* env, const ONet* net, int B, int S, float d
         for (int sim = 0; sim < S; ++sim) eazo_search_sim(t, sim);
         eazo_search_finish(t, act, aw);
         eazo_env_step(env, B, states, act, 0, 0, 0, nxt); /* :47 plain env.step, no auto-reset */
-        for (int b = 0; b < B; ++b) sum_rewards[b] += o_state_reward(env, nxt + (size_t)b * SB); /* :48-50 rewards[b, current_player] */
+        for (int b = 0; b < B; ++b) /* :48-50 next_states.rewards[b, states.current_player] */
+            sum_rewards[b] += o_state_reward(env, nxt + (size_t)b * SB, o_state_current_player(env, (char*)states + (size_t)b * SB));
         memcpy(states, nxt, (size_t)B * SB);
         counter += 1;
     }
@@ -1199,7 +1447,7 @@ EXPORT void eazo_reanalyze(const OEnv* env, const ONet* net, int B, const OReana
         const char* s1 = (const char*)next_states + (size_t)b * SB;
         const float from_tree = q[(size_t)b * A + act[b]];                                                       /* :88 */
         const float not_term1 = o_state_terminated(env, s1) ? 0.0f : 1.0f;
-        const float from_td = o_state_reward(env, s1) + (cfg->discount * nv[b]) * not_term1;                    /* :95-96 */
+        const float from_td = o_state_reward(env, s1, 0) + (cfg->discount * nv[b]) * not_term1;                 /* :95-96 (single-player envs) */
         float vt = from_tree > from_td ? from_tree : from_td;                                                    /* :102 */
         float mx = qv[(size_t)b * A];
         for (int a = 1; a < A; ++a) mx = qv[(size_t)b * A + a] > mx ? qv[(size_t)b * A + a] : mx;               /* :103 */

@@ -48,6 +48,8 @@ def lib():
         sig = {
             "eazo_env_deepsea": (vp, [i32, vp]),
             "eazo_env_subleq": (vp, [i32, vp, i32, i32]),
+            "eazo_env_connect4": (vp, []),
+            "eazo_resnet_create": (vp, [i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
             "eazo_env_free": (None, [vp]),
             "eazo_env_state_bytes": (i32, [vp]),
             "eazo_env_num_actions": (i32, [vp]),
@@ -145,6 +147,10 @@ class OracleEnv:
         e.W = W
         return e
 
+    @classmethod
+    def connect4(cls):
+        return cls(lib().eazo_env_connect4(), "connect4")
+
     def __del__(self):
         try:
             lib().eazo_env_free(self.h)
@@ -196,6 +202,19 @@ class OracleNet:
         bp = (C.c_void_p * 12)(*[b.ctypes.data for b in self._b])
         self.bitset = bitset
         self.h = lib().eazo_net_create(in_dim, H, A, wp, bp, max_u, nov_scale, hash_off, hash_len, hash_bits, _p(bitset))
+
+    @classmethod
+    def resnet(cls, H, W, cin, A, arrays, num_channels=64, num_blocks=5, hash_bits=24, bitset=None):
+        """arrays: e_alphazero_amd.params.resnet_array_list(params, state, num_blocks)."""
+        self = cls.__new__(cls)
+        self.in_dim, self.H, self.A = H * W * cin, num_channels, A
+        self._w = [np.ascontiguousarray(a, np.float32) for a in arrays]
+        ptrs = (C.c_void_p * len(self._w))(*[a.ctypes.data for a in self._w])
+        self.bitset = bitset
+        self.h = lib().eazo_resnet_create(H, W, cin, num_channels, num_blocks, A, ptrs, len(self._w), hash_bits, _p(bitset))
+        if not self.h:
+            raise ValueError("invalid resnet parameters")
+        return self
 
     def set_bitset(self, bitset):
         self.bitset = bitset
