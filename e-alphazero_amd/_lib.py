@@ -43,13 +43,16 @@ SIGNATURES = {
     "eaz_key_fold": [_u64, C.c_uint32, C.POINTER(_u64)],
     "eaz_env_create_deepsea": [_vp, _i, _vp, _pp],
     "eaz_env_create_subleq": [_vp, _i, _vp, _i, _i, _pp],
+    "eaz_env_create_connect4": [_vp, _pp],
+    "eaz_env_num_players": [_vp],
     "eaz_env_destroy": [_vp],
     "eaz_env_info": [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
     "eaz_env_init": [_vp, _i, _u64, _vp, _vp],
     "eaz_env_step": [_vp, _i, _vp, _vp, _u64, _i, _vp, _vp],
     "eaz_env_observe": [_vp, _i, _vp, _vp, _vp],
-    "eaz_env_fields": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "eaz_env_fields": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eaz_net_create_fc": [_vp, _i, _i, _i, _vp, _vp, _f, _f, _i, _i, _i, _pp],
+    "eaz_net_create_resnet": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _pp],
     "eaz_net_destroy": [_vp],
     "eaz_net_set_weights": [_vp, _vp, _vp, _vp],
     "eaz_net_set_bitset": [_vp, _vp, _vp],

@@ -13,6 +13,7 @@
 #include "../../include/eaz.h"
 #include "env_kernels.hpp"
 #include "net_fc.hpp"
+#include "net_resnet.hpp"
 #include "search_kernels.hpp"
 
 using namespace eaz;
@@ -62,6 +63,9 @@ struct eaz_env {
 
 struct eaz_net {
     eaz_ctx* ctx;
+    int kind;  // 0 = fully connected (fully_connected.py), 1 = residual (resnet.py)
+    ResNetDev rdev;
+    float* d_rparams;
     NetDev dev;
     float* d_w[12];
     float* d_b[12];
@@ -186,6 +190,24 @@ extern "C" int eaz_env_create_subleq(eaz_ctx* ctx, int W, const int32_t* h_tasks
     return 0;
 }
 
+extern "C" int eaz_env_create_connect4(eaz_ctx* ctx, eaz_env** out) {
+    ARG_OK(ctx && out);
+    eaz_env* e = new eaz_env();
+    e->ctx = ctx;
+    e->d_action_map = nullptr;
+    std::memset(&e->dev, 0, sizeof e->dev);
+    e->dev.kind = EAZ_ENV_CONNECT4;
+    e->dev.A = 7;
+    e->dev.obs_rows = 42;  // [6,7,2] flattened: 42 cells x 2 planes
+    e->dev.obs_cols = 2;
+    e->dev.obs_dim = 84;
+    e->dev.state_bytes = sizeof(eaz_connect4_state);
+    *out = e;
+    return 0;
+}
+
+extern "C" int eaz_env_num_players(const eaz_env* env) { return env && env->dev.kind == EAZ_ENV_CONNECT4 ? 2 : 1; }
+
 extern "C" int eaz_env_destroy(eaz_env* env) {
     if (!env) return 0;
     if (env->d_action_map) (void)hipFree(env->d_action_map);
@@ -204,19 +226,30 @@ extern "C" int eaz_env_info(const eaz_env* env, int* kind, int* num_actions, int
 }
 
 // mode: 0 step, 1 auto-reset step, 2 init.  src/dst: plain [B] batches.
+// mover_reward (optional): rewards[b, current_player before the step] of the new states
 static int env_step_launch(eaz_env* env, int B, const void* in, const int32_t* action, Key key, int mode, void* out,
-                           void* out_copy, hipStream_t st, const Key* d_key = nullptr) {
+                           void* out_copy, hipStream_t st, const Key* d_key = nullptr, float* mover_reward = nullptr) {
     if (B <= 0) return 0;
+    StateRef src{const_cast<char*>(static_cast<const char*>(in ? in : out)), nullptr, 1};
+    StateRef dst{static_cast<char*>(out), nullptr, 1};
     if (env->dev.kind == EAZ_ENV_DEEPSEA) {
         deepsea_step_kernel<<<cdiv(B, 256), 256, 0, st>>>(env->dev, static_cast<const char*>(in), action, B, mode,
                                                          static_cast<char*>(out), static_cast<char*>(out_copy));
-    } else {
-        StateRef src{const_cast<char*>(static_cast<const char*>(in ? in : out)), nullptr, 1};
-        StateRef dst{static_cast<char*>(out), nullptr, 1};
+        LAUNCH_OK();
+        if (mover_reward) {
+            env_fields_kernel<<<cdiv(B, 256), 256, 0, st>>>(env->dev, static_cast<const char*>(out), B, nullptr, nullptr, mover_reward, nullptr,
+                                                           nullptr, nullptr);
+            LAUNCH_OK();
+        }
+    } else if (env->dev.kind == EAZ_ENV_SUBLEQ) {
         subleq_step_kernel<<<cdiv(B, 64), 192, 192 * env->dev.W, st>>>(env->dev, src, dst, action, B, mode, key, d_key,
-                                                                         static_cast<char*>(out_copy), nullptr, nullptr, nullptr);
+                                                                         static_cast<char*>(out_copy), mover_reward, nullptr, nullptr);
+        LAUNCH_OK();
+    } else {
+        connect4_step_kernel<<<cdiv(B, 256), 256, 0, st>>>(env->dev, src, dst, action, B, mode, key, d_key, mover_reward, nullptr, nullptr);
+        LAUNCH_OK();
+        if (out_copy) HIP_OK(hipMemcpyAsync(out_copy, out, static_cast<size_t>(B) * env->dev.state_bytes, hipMemcpyDeviceToDevice, st));
     }
-    LAUNCH_OK();
     return 0;
 }
 
@@ -245,11 +278,11 @@ extern "C" int eaz_env_observe(eaz_env* env, int B, const void* d_states, uint8_
 }
 
 extern "C" int eaz_env_fields(eaz_env* env, int B, const void* d_states, uint8_t* d_term, uint8_t* d_trunc, float* d_reward,
-                              int32_t* d_step_count, uint8_t* d_legal, void* stream) {
+                              int32_t* d_step_count, uint8_t* d_legal, int32_t* d_current_player, void* stream) {
     ARG_OK(env && d_states && B >= 0);
     if (B == 0) return 0;
     env_fields_kernel<<<cdiv(B, 256), 256, 0, S(stream)>>>(env->dev, static_cast<const char*>(d_states), B, d_term, d_trunc,
-                                                         d_reward, d_step_count, d_legal);
+                                                         d_reward, d_step_count, d_legal, d_current_player);
     LAUNCH_OK();
     return 0;
 }
@@ -273,6 +306,8 @@ extern "C" int eaz_net_create_fc(eaz_ctx* ctx, int in_dim, int hidden, int num_a
     HIP_OK(hipSetDevice(ctx->device));
     eaz_net* n = new eaz_net();
     n->ctx = ctx;
+    n->kind = 0;
+    n->d_rparams = nullptr;
     std::memset(&n->dev, 0, sizeof n->dev);
     n->dev.in_dim = in_dim; n->dev.H = hidden; n->dev.A = num_actions;
     n->dev.max_u = max_ube; n->dev.nov_scale = max_reward_variance;
@@ -301,9 +336,82 @@ extern "C" int eaz_net_create_fc(eaz_ctx* ctx, int in_dim, int hidden, int num_a
     return 0;
 }
 
+extern "C" int eaz_net_create_resnet(eaz_ctx* ctx, int H, int W, int Cin, int C, int nb, int A, const float* const* a, int n_arrays,
+                                     int hash_bits, eaz_net** out) {
+    ARG_OK(ctx && out && a && H > 0 && W > 0 && A > 0 && A <= 64 && nb >= 0 && nb <= 16);
+    if (C != kRnC) return fail("the gfx950 ResNet kernel is specialised for num_channels = %d (resnet.py:48), got %d", kRnC, C);
+    if (Cin < 1 || Cin > 64 || (Cin & (Cin - 1)) != 0) return fail("input planes must be a power of two <= 64, got %d", Cin);
+    if (n_arrays != 42 + 12 * nb) return fail("expected %d parameter arrays, got %d", 42 + 12 * nb, n_arrays);
+    if ((H * W * Cin) % 4 != 0) return fail("hash input length %d is not a multiple of 4 (hashes.py:210)", H * W * Cin);
+    if (H * W > 42) return fail("board of %d cells exceeds the kernel's 42-cell head buffers", H * W);
+    ARG_OK(hash_bits >= 4 && hash_bits <= 32);
+    HIP_OK(hipSetDevice(ctx->device));
+    std::vector<float> pk;
+    auto push = [&](const float* src, size_t cnt) { const int off = static_cast<int>(pk.size()); pk.insert(pk.end(), src, src + cnt); while (pk.size() % 4) pk.push_back(0.0f); return off; };
+    eaz_net* n = new eaz_net();
+    n->ctx = ctx;
+    n->kind = 1;
+    std::memset(&n->dev, 0, sizeof n->dev);
+    std::memset(&n->rdev, 0, sizeof n->rdev);
+    for (int l = 0; l < 12; ++l) { n->d_w[l] = nullptr; n->d_b[l] = nullptr; }
+    ResNetDev& r = n->rdev;
+    r.H = H; r.W = W; r.Cin = Cin; r.nb = nb; r.A = A; r.P = H * W;
+    r.cin_log2 = 0;
+    while ((1 << r.cin_log2) < Cin) r.cin_log2++;
+    int i = 0, ci = 0, bi = 0;
+    auto take_conv = [&](int taps, int cin, int cout, int& w_off, int& b_off, int* kpad) {
+        const int K = taps * cin, Kp = (K + 3) & ~3;
+        w_off = push(a[i], static_cast<size_t>(K) * cout);
+        pk.resize(static_cast<size_t>(w_off) + static_cast<size_t>(Kp) * cout, 0.0f);  // zero rows up to the padded K
+        while (pk.size() % 4) pk.push_back(0.0f);
+        b_off = push(a[i + 1], cout);
+        if (kpad) *kpad = Kp;
+        i += 2;
+    };
+    auto take_bn = [&](int c, int& mean_off, int& inv_off, int& off_off) {
+        std::vector<float> inv(c);
+        for (int k = 0; k < c; ++k) inv[k] = a[i][k] / std::sqrt(a[i + 3][k] + 1e-5f);  // scale / sqrt(var + eps), f32 like the oracle
+        mean_off = push(a[i + 2], c); inv_off = push(inv.data(), c); off_off = push(a[i + 1], c);
+        i += 4;
+    };
+    take_conv(9, Cin, C, r.conv_w[0], r.conv_b[0], &r.conv_k[0]);
+    ci = 1;
+    for (int k = 0; k < nb; ++k) {
+        take_bn(C, r.bn_mean[bi], r.bn_inv[bi], r.bn_off[bi]); bi++;
+        take_conv(9, C, C, r.conv_w[ci], r.conv_b[ci], &r.conv_k[ci]); ci++;
+        take_bn(C, r.bn_mean[bi], r.bn_inv[bi], r.bn_off[bi]); bi++;
+        take_conv(9, C, C, r.conv_w[ci], r.conv_b[ci], &r.conv_k[ci]); ci++;
+    }
+    take_bn(C, r.bn_mean[bi], r.bn_inv[bi], r.bn_off[bi]);  // final batch norm at index 2*nb
+    auto take_lin = [&](int in, int outn, int& w_off, int& b_off) { w_off = push(a[i], static_cast<size_t>(in) * outn); b_off = push(a[i + 1], outn); i += 2; };
+    take_conv(1, C, 2, r.hc_w[0], r.hc_b[0], nullptr); take_bn(2, r.hbn_mean[0], r.hbn_inv[0], r.hbn_off[0]); take_lin(r.P * 2, A, r.lin_w[0], r.lin_b[0]);
+    take_conv(1, C, 2, r.hc_w[1], r.hc_b[1], nullptr); take_bn(2, r.hbn_mean[1], r.hbn_inv[1], r.hbn_off[1]); take_lin(r.P * 2, A, r.lin_w[1], r.lin_b[1]);
+    take_conv(1, C, 1, r.hc_w[2], r.hc_b[2], nullptr); take_bn(1, r.hbn_mean[2], r.hbn_inv[2], r.hbn_off[2]);
+    take_lin(r.P, C, r.lin_w[2], r.lin_b[2]); take_lin(C, 1, r.lin_w[3], r.lin_b[3]);
+    take_conv(1, C, 1, r.hc_w[3], r.hc_b[3], nullptr); take_bn(1, r.hbn_mean[3], r.hbn_inv[3], r.hbn_off[3]);
+    take_lin(r.P, C, r.lin_w[4], r.lin_b[4]); take_lin(C, 1, r.lin_w[5], r.lin_b[5]);
+    HIP_OK(hipMalloc(&n->d_rparams, pk.size() * sizeof(float)));
+    HIP_OK(hipMemcpy(n->d_rparams, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    r.p = n->d_rparams;
+    n->dev.in_dim = H * W * Cin; n->dev.H = C; n->dev.A = A;
+    n->dev.max_u = 1.0f; n->dev.nov_scale = 1.0f;  // resnet.py:63-64
+    n->dev.hash_off = 0; n->dev.hash_len = H * W * Cin; n->dev.hash_bits = hash_bits;
+    n->bitset_bytes = static_cast<size_t>(1) << (hash_bits - 3);
+    if (n->bitset_bytes < 4) n->bitset_bytes = 4;
+    HIP_OK(hipMalloc(&n->dev.bitset, n->bitset_bytes));
+    HIP_OK(hipMemset(n->dev.bitset, 0, n->bitset_bytes));
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(resnet_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kRnLdsBytes));
+    HIP_OK(hipMalloc(&n->d_kstep_storage, 8 * sizeof(unsigned long long)));
+    HIP_OK(hipMemset(n->d_kstep_storage, 0, 8 * sizeof(unsigned long long)));
+    n->d_kstep_counter = nullptr;
+    *out = n;
+    return 0;
+}
+
 extern "C" int eaz_net_destroy(eaz_net* n) {
     if (!n) return 0;
-    for (int l = 0; l < 12; ++l) { (void)hipFree(n->d_w[l]); (void)hipFree(n->d_b[l]); }
+    if (n->d_rparams) (void)hipFree(n->d_rparams);
+    for (int l = 0; l < 12; ++l) { if (n->d_w[l]) (void)hipFree(n->d_w[l]); if (n->d_b[l]) (void)hipFree(n->d_b[l]); }
     (void)hipFree(n->dev.bitset);
     (void)hipFree(n->d_kstep_storage);
     delete n;
@@ -312,6 +420,7 @@ extern "C" int eaz_net_destroy(eaz_net* n) {
 
 extern "C" int eaz_net_set_weights(eaz_net* n, const float* const* h_w, const float* const* h_b, void* stream) {
     ARG_OK(n && h_w && h_b);
+    if (n->kind != 0) return fail("eaz_net_set_weights: FC networks only (recreate a ResNet with eaz_net_create_resnet)");
     for (int l = 0; l < 12; ++l) {
         int k, m;
         layer_dims(n->dev.in_dim, n->dev.H, n->dev.A, l, &k, &m);
@@ -343,6 +452,11 @@ static int hash_launch(eaz_net* n, int B, const uint8_t* obs, float* novelty, ui
 
 static int fc_launch(eaz_net* n, int B, const uint8_t* obs, const NetOut& o, const HeadList& heads, hipStream_t st) {
     if (B <= 0 || heads.n <= 0) return 0;
+    if (n->kind == 1) {  // residual tower: six samples per workgroup, all heads in one launch
+        resnet_forward_kernel<<<cdiv(B, kRnSamples), 256, kRnLdsBytes, st>>>(n->rdev, obs, B, o);
+        LAUNCH_OK();
+        return 0;
+    }
     const int n_tiles = cdiv(B, kFcM);
     int cmin = 8;
     for (int h = 0; h < heads.n; ++h) {
@@ -622,6 +736,14 @@ static int recurrent_launch(eaz_search* s, hipStream_t st) {
             leaf_gather_deepsea_kernel<<<cdiv(static_cast<long>(B) * 64, 256), 256, 0, st>>>(
                 env->dev, s->tree, s->d_obs, s->d_next_reward, s->d_next_term, s->d_next_legal);
             LAUNCH_OK();
+        } else if (env->dev.kind == EAZ_ENV_CONNECT4) {
+            StateRef src{s->tree.embeddings, s->tree.sim_parent, s->N};
+            StateRef dst{s->tree.embeddings, s->tree.sim_next, s->N};
+            connect4_step_kernel<<<cdiv(B, 256), 256, 0, st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0}, nullptr,
+                                                              s->d_next_reward, s->d_next_term, s->d_next_legal);
+            LAUNCH_OK();
+            obs_emit_kernel<<<cdiv(static_cast<long>(B) * 64, 256), 256, 0, st>>>(env->dev, dst, B, s->d_obs);
+            LAUNCH_OK();
         } else {
             StateRef src{s->tree.embeddings, s->tree.sim_parent, s->N};
             StateRef dst{s->tree.embeddings, s->tree.sim_next, s->N};
@@ -784,7 +906,7 @@ static int selfplay_step_body(eaz_search* s, const eaz_selfplay_cfg* cfg, int fl
     {
         ProfScope ps(s, EAZ_K_MISC, st);
         env_fields_kernel<<<cdiv(B, 256), 256, 0, st>>>(env->dev, static_cast<const char*>(d_states), B, nullptr, nullptr, nullptr,
-                                                       nullptr, s->d_legal);
+                                                       nullptr, s->d_legal, nullptr);
         LAUNCH_OK();
         const float sbeta = explore ? cfg->exploration_beta : 0.0f;  // selfplay.py:92
         root_prep_kernel<<<cdiv(static_cast<long>(B) * A, 256), 256, 0, st>>>(
@@ -898,7 +1020,7 @@ static int driver_root(eaz_search* s, const void* d_states, float beta, const fl
     rc = infer_launch(s, s->d_obs, s->d_novelty, o, hl, st);
     if (rc) return rc;
     env_fields_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->env->dev, static_cast<const char*>(d_states), B, s->d_term, nullptr, nullptr, nullptr,
-                                                   s->d_legal);
+                                                   s->d_legal, nullptr);
     LAUNCH_OK();
     set_step_keys_kernel<<<1, 1, 0, st>>>(s->d_step_keys, gkey, Key{0, 0}, Key{0, 0}, Key{0, 0});
     LAUNCH_OK();
@@ -923,7 +1045,7 @@ extern "C" int eaz_evaluate_run(eaz_search* s, float exploitation_beta, int max_
     for (;;) {
         // cond_fn evaluate.py:18-20
         HIP_OK(hipMemsetAsync(s->d_alive, 0, sizeof(int), st));
-        env_fields_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->env->dev, static_cast<const char*>(d_states), B, s->d_term, nullptr, nullptr, nullptr, nullptr);
+        env_fields_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->env->dev, static_cast<const char*>(d_states), B, s->d_term, nullptr, nullptr, nullptr, nullptr, nullptr);
         LAUNCH_OK();
         count_alive_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->d_term, B, s->d_alive);
         LAUNCH_OK();
@@ -937,11 +1059,8 @@ extern "C" int eaz_evaluate_run(eaz_search* s, float exploitation_beta, int max_
         if (rc) return rc;
         rc = eaz_search_finish(s, s->d_action, s->d_aw, st);
         if (rc) return rc;
-        rc = env_step_launch(s->env, B, d_states, s->d_action, Key{0, 0}, 0, d_states, nullptr, st);  // :47
+        rc = env_step_launch(s->env, B, d_states, s->d_action, Key{0, 0}, 0, d_states, nullptr, st, nullptr, s->d_reward_tmp);  // :47
         if (rc) return rc;
-        env_fields_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->env->dev, static_cast<const char*>(d_states), B, nullptr, nullptr, s->d_reward_tmp,
-                                                       nullptr, nullptr);
-        LAUNCH_OK();
         accumulate_kernel<<<cdiv(B, 256), 256, 0, st>>>(d_sum_rewards, s->d_reward_tmp, B);  // :48-50
         LAUNCH_OK();
         counter += 1;
@@ -975,8 +1094,9 @@ extern "C" int eaz_reanalyze_run(eaz_search* s, const eaz_reanalyze_cfg* cfg, ui
         rc = fc_launch(s->net, B, s->d_obs, o, hl, st);
         if (rc) return rc;
     }
+    if (s->env->dev.kind == EAZ_ENV_CONNECT4) return fail("reanalyze: the reference's TD target squeezes a [B,1] reward (reanalyze.py:95), i.e. single-player envs only");
     env_fields_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->env->dev, static_cast<const char*>(d_next_states), B, s->d_term2, nullptr, s->d_reward_tmp,
-                                                   nullptr, nullptr);
+                                                   nullptr, nullptr, nullptr);
     LAUNCH_OK();
 #define CALL_RT(L, P)                                                                                                              \
     reanalyze_targets_kernel<L, P><<<tree_grid(s), 256, 0, st>>>(B, A, s->d_action, s->d_sum_q, s->d_sum_qvar, s->d_sum_vc, s->d_sum_value,  \

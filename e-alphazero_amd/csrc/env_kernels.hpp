@@ -213,28 +213,61 @@ __global__ void __launch_bounds__(192) subleq_step_kernel(EnvDev e, StateRef src
         for (int a = 0; a < e.A; ++a) next_legal[static_cast<long>(b) * e.A + a] = 1;  // all legal (subleq.py:626)
 }
 
+// ---- connect_four -------------------------------------------------------------------------------------------------
+// One thread per environment.  mode as deepsea_step_kernel.  mover_reward[b] = rewards[b, current_player BEFORE the step]
+// (context.py:125,139 / evaluate.py:48-50).
+__global__ void __launch_bounds__(256) connect4_step_kernel(EnvDev e, StateRef src, StateRef dst, const int32_t* action, int B, int mode,
+                                                            Key key_arg, const Key* key_ptr, float* mover_reward, uint8_t* next_term,
+                                                            uint8_t* next_legal) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const Key key = key_ptr ? *key_ptr : key_arg;
+    eaz_connect4_state s;
+    int mover = 0;
+    if (mode == 2) {
+        c4_init(s, fold(key, static_cast<uint32_t>(b)));
+    } else {
+        const uint4* sp = reinterpret_cast<const uint4*>(state_ptr(src, b, e.state_bytes));
+        uint4* sv = reinterpret_cast<uint4*>(&s);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) sv[i] = sp[i];
+        mover = s.current_player;
+        if (mode == 1 && (s.terminated | s.truncated)) c4_init(s, fold(fold(key, static_cast<uint32_t>(b)), 1u));
+        else c4_step(s, action[b]);
+    }
+    uint4* dp = reinterpret_cast<uint4*>(state_ptr(dst, b, e.state_bytes));
+    const uint4* sv = reinterpret_cast<const uint4*>(&s);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dp[i] = sv[i];
+    if (mover_reward) mover_reward[b] = mover == 0 ? s.reward0 : s.reward1;
+    if (next_term) next_term[b] = s.terminated;
+    if (next_legal)
+        for (int a = 0; a < 7; ++a) next_legal[static_cast<long>(b) * 7 + a] = c4_legal(s, a) ? 1 : 0;
+}
+
 // ---- state field export (pgx.State-visible fields) -----------------------------------------------------------------
 __global__ void __launch_bounds__(256) env_fields_kernel(EnvDev e, const char* states, int B, uint8_t* terminated,
-                                                         uint8_t* truncated, float* reward, int32_t* step_count, uint8_t* legal) {
+                                                         uint8_t* truncated, float* rewards, int32_t* step_count, uint8_t* legal,
+                                                         int32_t* current_player) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const char* sp = states + static_cast<long>(b) * e.state_bytes;
-    uint8_t term, trunc;
-    float rew;
-    int sc;
-    if (e.kind == EAZ_ENV_DEEPSEA) {
-        const eaz_deepsea_state s = ds_load(sp);
-        term = s.terminated; trunc = s.truncated; rew = s.reward; sc = s.step_count;
+    const StateHeader* h = reinterpret_cast<const StateHeader*>(sp);
+    if (terminated) terminated[b] = h->terminated;
+    if (truncated) truncated[b] = h->truncated;
+    if (step_count) step_count[b] = h->step_count;
+    if (e.kind == EAZ_ENV_CONNECT4) {
+        const eaz_connect4_state* c = reinterpret_cast<const eaz_connect4_state*>(sp);
+        if (rewards) { rewards[2 * b] = c->reward0; rewards[2 * b + 1] = c->reward1; }
+        if (current_player) current_player[b] = c->current_player;
+        if (legal)
+            for (int a = 0; a < 7; ++a) legal[static_cast<long>(b) * 7 + a] = c4_legal(*c, a) ? 1 : 0;
     } else {
-        const eaz_subleq_state* s = reinterpret_cast<const eaz_subleq_state*>(sp);
-        term = s->terminated; trunc = s->truncated; rew = s->reward; sc = s->step_count;
+        if (rewards) rewards[b] = h->reward0;
+        if (current_player) current_player[b] = 0;
+        if (legal)
+            for (int a = 0; a < e.A; ++a) legal[static_cast<long>(b) * e.A + a] = 1;
     }
-    if (terminated) terminated[b] = term;
-    if (truncated) truncated[b] = trunc;
-    if (reward) reward[b] = rew;
-    if (step_count) step_count[b] = sc;
-    if (legal)
-        for (int a = 0; a < e.A; ++a) legal[static_cast<long>(b) * e.A + a] = 1;
 }
 
 }  // namespace eaz

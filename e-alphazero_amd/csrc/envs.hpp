@@ -214,18 +214,79 @@ __device__ __forceinline__ int subleq_row_word(const EnvDev& e, const eaz_subleq
 // generic observation byte i of the flattened observation
 __device__ __forceinline__ uint8_t obs_byte(const EnvDev& e, const char* sp, int hot, int i) {
     if (e.kind == EAZ_ENV_DEEPSEA) return static_cast<uint8_t>(i == hot);
+    if (e.kind == EAZ_ENV_CONNECT4) {  // [6,7,2]: plane 0 = stones of the colour to move, plane 1 = the other colour
+        const eaz_connect4_state* c = reinterpret_cast<const eaz_connect4_state*>(sp);
+        const int v = c->board[i >> 1];
+        return static_cast<uint8_t>((i & 1) ? v == 1 - static_cast<int>(c->color) : v == static_cast<int>(c->color));
+    }
     const eaz_subleq_state* s = reinterpret_cast<const eaz_subleq_state*>(sp);
     const int row = i / e.obs_cols, col = i - row * e.obs_cols;
     return subleq_enc(e, subleq_row_word(e, s, row), col);
 }
 
+// every state blob starts with {int32 step_count; int32 aux; float reward0; uint8 terminated, truncated, ..}
+struct StateHeader {
+    int32_t step_count, aux;
+    float reward0;
+    uint8_t terminated, truncated, x, y;
+};
 __device__ __forceinline__ bool state_is_done(const EnvDev& e, const char* sp) {
-    if (e.kind == EAZ_ENV_DEEPSEA) {
-        const eaz_deepsea_state* s = reinterpret_cast<const eaz_deepsea_state*>(sp);
-        return (s->terminated | s->truncated) != 0;
+    const StateHeader* h = reinterpret_cast<const StateHeader*>(sp);
+    return (h->terminated | h->truncated) != 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// connect_four: pgx.connect_four [EXT] (un-vendored, Pipfile:8) -- parity unpinned, game rules restated
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int c4_col_count(const eaz_connect4_state& s, int c) {
+    int n = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) n += s.board[r * 7 + c] >= 0;
+    return n;
+}
+__device__ __forceinline__ bool c4_won(const int8_t* b, int color) {
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 7; ++c) {
+            if (b[r * 7 + c] != color) continue;
+            if (c <= 3 && b[r * 7 + c + 1] == color && b[r * 7 + c + 2] == color && b[r * 7 + c + 3] == color) return true;
+            if (r <= 2 && b[(r + 1) * 7 + c] == color && b[(r + 2) * 7 + c] == color && b[(r + 3) * 7 + c] == color) return true;
+            if (r <= 2 && c <= 3 && b[(r + 1) * 7 + c + 1] == color && b[(r + 2) * 7 + c + 2] == color && b[(r + 3) * 7 + c + 3] == color) return true;
+            if (r <= 2 && c >= 3 && b[(r + 1) * 7 + c - 1] == color && b[(r + 2) * 7 + c - 2] == color && b[(r + 3) * 7 + c - 3] == color) return true;
+        }
+    return false;
+}
+__device__ __forceinline__ void c4_init(eaz_connect4_state& s, Key key) {
+    s.step_count = 0;
+    s.current_player = static_cast<int32_t>(rbits(key, 0) & 1u);  // jnp.int32(jax.random.bernoulli(key))
+    s.reward0 = 0.0f; s.reward1 = 0.0f;
+    s.terminated = 0; s.truncated = 0; s.color = 0; s.pad = 0;
+    s.winner = -1;
+    for (int i = 0; i < 42; ++i) s.board[i] = -1;
+    for (int i = 0; i < 14; ++i) s.pad2[i] = 0;
+}
+__device__ __forceinline__ bool c4_legal(const eaz_connect4_state& s, int a) { return s.terminated ? true : c4_col_count(s, a) < 6; }
+// pgx.Env.step wrapper (A.1) around ConnectFour._step
+__device__ __forceinline__ void c4_step(eaz_connect4_state& s, int action) {
+    if (s.terminated | s.truncated) { s.reward0 = 0.0f; s.reward1 = 0.0f; return; }
+    const int mover = s.current_player, color = s.color;
+    const int n = c4_col_count(s, action);
+    const bool illegal = n >= 6;
+    s.step_count += 1;
+    if (!illegal) s.board[(5 - n) * 7 + action] = static_cast<int8_t>(color);
+    const bool won = c4_won(s.board, color);
+    s.winner = won ? color : -1;
+    s.color = static_cast<uint8_t>(1 - color);
+    s.current_player = 1 - mover;
+    bool full = true;
+    for (int c = 0; c < 7; ++c) full = full && c4_col_count(s, c) == 6;
+    s.terminated = (won || full) ? 1 : 0;
+    s.reward0 = 0.0f; s.reward1 = 0.0f;
+    if (won) { s.reward0 = mover == 0 ? 1.0f : -1.0f; s.reward1 = mover == 1 ? 1.0f : -1.0f; }
+    if (illegal) {  // _step_with_illegal_action: mover -1, the other player +1, terminated
+        s.reward0 = mover == 0 ? -1.0f : 1.0f;
+        s.reward1 = mover == 1 ? -1.0f : 1.0f;
+        s.terminated = 1;
     }
-    const eaz_subleq_state* s = reinterpret_cast<const eaz_subleq_state*>(sp);
-    return (s->terminated | s->truncated) != 0;
 }
 
 }  // namespace eaz

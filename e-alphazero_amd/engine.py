@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import EazError, ReanalyzeCfg, SearchOpts, SelfplayCfg, check
-from .params import fc_weight_list, HASH_MODULE
+from .params import fc_weight_list, resnet_array_list, HASH_MODULE, RESNET_HASH_MODULE
 
 _contexts: dict[int, "Context"] = {}
 
@@ -89,8 +89,9 @@ class EnvHandle:
         v = [C.c_int() for _ in range(5)]
         check(_lib.load().eaz_env_info(handle, *[C.byref(x) for x in v]))
         self.kind, self.num_actions, rows, cols, self.state_bytes = [x.value for x in v]
-        self.obs_shape = (rows, cols)
+        self.obs_shape = (rows, cols) if self.kind != 2 else (6, 7, 2)  # connect_four observations are [6,7,2]
         self.obs_dim = rows * cols
+        self.num_players = _lib.load().eaz_env_num_players(handle)
 
     @classmethod
     def deepsea(cls, size_of_grid: int, action_map: Optional[np.ndarray] = None, device=None):
@@ -107,6 +108,13 @@ class EnvHandle:
         t = np.ascontiguousarray(tasks, np.int32)
         h = C.c_void_p()
         check(_lib.load().eaz_env_create_subleq(ctx.h, word_size, t.ctypes.data_as(C.c_void_p), len(t), int(use_binary_encoding), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def connect4(cls, device=None):
+        ctx = Context.get(device)
+        h = C.c_void_p()
+        check(_lib.load().eaz_env_create_connect4(ctx.h, C.byref(h)))
         return cls(ctx, h)
 
     def new_states(self, *lead) -> torch.Tensor:
@@ -135,13 +143,15 @@ class EnvHandle:
         n, dev = flat.shape[0], states.device
         term = torch.empty(n, dtype=torch.uint8, device=dev)
         trunc = torch.empty(n, dtype=torch.uint8, device=dev)
-        rew = torch.empty(n, dtype=torch.float32, device=dev)
+        rew = torch.empty(n, self.num_players, dtype=torch.float32, device=dev)
         sc = torch.empty(n, dtype=torch.int32, device=dev)
         legal = torch.empty(n, self.num_actions, dtype=torch.uint8, device=dev)
-        check(_lib.load().eaz_env_fields(self.h, n, _ptr(flat), _ptr(term), _ptr(trunc), _ptr(rew), _ptr(sc), _ptr(legal), _stream()))
+        cp = torch.empty(n, dtype=torch.int32, device=dev)
+        check(_lib.load().eaz_env_fields(self.h, n, _ptr(flat), _ptr(term), _ptr(trunc), _ptr(rew), _ptr(sc), _ptr(legal), _ptr(cp), _stream()))
         lead = states.shape[:-1]
-        return dict(terminated=term.bool().reshape(lead), truncated=trunc.bool().reshape(lead), rewards=rew.reshape(*lead, 1),
-                    step_count=sc.reshape(lead), legal_action_mask=legal.bool().reshape(*lead, self.num_actions))
+        return dict(terminated=term.bool().reshape(lead), truncated=trunc.bool().reshape(lead),
+                    rewards=rew.reshape(*lead, self.num_players), step_count=sc.reshape(lead),
+                    legal_action_mask=legal.bool().reshape(*lead, self.num_actions), current_player=cp.reshape(lead))
 
     def random_play(self, B: int, T: int, key=0, want_traj: bool = False):
         states = self.new_states(B)
@@ -213,6 +223,25 @@ class FCNet:
     def hash_update(self, obs: torch.Tensor):
         o = obs.reshape(-1, self.in_dim).to(torch.uint8).contiguous()
         check(_lib.load().eaz_hash_update(self.h, o.shape[0], _ptr(o), _stream()))
+
+
+class ResNet(FCNet):
+    """eaz_net for EpistemicResidualAZNet (src/network/resnet.py) on [H, W, Cin] observations; same methods as FCNet."""
+
+    def __init__(self, ctx: Context, H: int, W: int, cin: int, num_actions: int, params, state, num_channels: int = 64,
+                 num_blocks: int = 5, hash_bits: int = 24):
+        self.ctx, self.in_dim, self.hidden, self.num_actions, self.hash_bits = ctx, H * W * cin, num_channels, num_actions, hash_bits
+        arrs = resnet_array_list(params, state, num_blocks)
+        self._keep = arrs
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        h = C.c_void_p()
+        check(_lib.load().eaz_net_create_resnet(ctx.h, H, W, cin, num_channels, num_blocks, num_actions, ptrs, len(arrs), hash_bits, C.byref(h)))
+        self.h = h
+        if state is not None and RESNET_HASH_MODULE in state:
+            self.set_state({HASH_MODULE: state[RESNET_HASH_MODULE]})
+
+    def set_params(self, params):
+        raise EazError("ResNet weights are packed at creation: create a new ResNet for new weights")
 
 
 class Search:

@@ -146,7 +146,7 @@ def init_resnet_params(H: int, W: int, cin: int, num_actions: int, num_channels:
 
 
 def resnet_array_list(params, state, num_blocks: int):
-    """Flat list of float32 arrays in the order eaz_net_create_resnet / eazo_resnet_create expect (42 + 12*num_blocks arrays)."""
+    """Flat list of float32 arrays in the order eaz_net_create_resnet expects (42 + 12*num_blocks arrays)."""
     out = []
     for kind, name in resnet_module_order(num_blocks):
         if kind in ("conv", "linear"):

@@ -39,6 +39,7 @@ typedef struct eaz_search eaz_search;
 
 #define EAZ_ENV_DEEPSEA 0
 #define EAZ_ENV_SUBLEQ 1
+#define EAZ_ENV_CONNECT4 2
 
 /* ---- compact env state blobs (AoS, one per environment instance) --------------------------------------------
  * The reference keeps the whole pgx.State (incl. the observation) per tree node (src/selfplay.py:104); the
@@ -61,6 +62,18 @@ typedef struct {
     uint8_t memory[256]; /* _memory_state :558 (only the first W bytes are meaningful; words are < W <= 256) */
 } eaz_subleq_state; /* 336 bytes */
 
+/* pgx connect_four [EXT] (BASELINE.json configs[3]): 6x7 board, row 0 at the top, -1 empty / 0 / 1 stone colour */
+typedef struct {
+    int32_t step_count;     /* _step_count */
+    int32_t current_player; /* State.current_player: identity (0/1) of the player to move */
+    float reward0;          /* rewards[0] */
+    uint8_t terminated, truncated, color /* colour to move */, pad;
+    float reward1;          /* rewards[1] */
+    int32_t winner;         /* -1 or the winning colour */
+    int8_t board[42];
+    uint8_t pad2[14];
+} eaz_connect4_state; /* 80 bytes */
+
 /* ---- context ------------------------------------------------------------------------------------------------ */
 EAZ_API const char* eaz_last_error(void);
 EAZ_API int eaz_version(void);
@@ -75,6 +88,8 @@ EAZ_API int eaz_key_fold(uint64_t key, uint32_t tag, uint64_t* out);
 EAZ_API int eaz_env_create_deepsea(eaz_ctx* ctx, int size_of_grid, const uint8_t* h_action_map /* [G*G] or NULL */, eaz_env** out);
 /* Subleq(tasks, word_size, use_binary_encoding) subleq.py:599-621 */
 EAZ_API int eaz_env_create_subleq(eaz_ctx* ctx, int word_size, const int32_t* h_tasks, int n_tasks, int use_binary_encoding, eaz_env** out);
+/* pgx.make("connect_four") [EXT] main.py:190-194 */
+EAZ_API int eaz_env_create_connect4(eaz_ctx* ctx, eaz_env** out);
 EAZ_API int eaz_env_destroy(eaz_env* env);
 /* num_actions, observation shape [rows, cols] and the byte size of one compact state */
 EAZ_API int eaz_env_info(const eaz_env* env, int* kind, int* num_actions, int* obs_rows, int* obs_cols, int* state_bytes);
@@ -85,9 +100,11 @@ EAZ_API int eaz_env_step(eaz_env* env, int B, const void* d_states_in, const int
                  void* d_states_out, void* stream);
 /* state.observation -> uint8 [B, rows*cols] */
 EAZ_API int eaz_env_observe(eaz_env* env, int B, const void* d_states, uint8_t* d_obs, void* stream);
-/* state.terminated / truncated / rewards[:,0] / _step_count / legal_action_mask[B,A] (any pointer may be NULL) */
+/* state.terminated / truncated / rewards [B, num_players] / _step_count / legal_action_mask [B,A] / current_player [B]
+ * (any pointer may be NULL; num_players is 1 for DeepSea and Subleq, 2 for connect_four) */
 EAZ_API int eaz_env_fields(eaz_env* env, int B, const void* d_states, uint8_t* d_terminated, uint8_t* d_truncated,
-                   float* d_reward, int32_t* d_step_count, uint8_t* d_legal_mask, void* stream);
+                   float* d_rewards, int32_t* d_step_count, uint8_t* d_legal_mask, int32_t* d_current_player, void* stream);
+EAZ_API int eaz_env_num_players(const eaz_env* env);
 
 /* ---- (ii) network: forward.apply(params, state, obs, is_training=False) ------------------------------------ */
 /* EpistemicFullyConnectedAZNet fully_connected.py:14-39.  h_w[i] is [in,out] row-major, h_b[i] is [out], i in haiku
@@ -95,6 +112,12 @@ EAZ_API int eaz_env_fields(eaz_env* env, int B, const void* d_states, uint8_t* d
  * hash_off/hash_len select the flattened slice that is hashed (hash_io: rows word_size.. , fully_connected.py:85-87). */
 EAZ_API int eaz_net_create_fc(eaz_ctx* ctx, int in_dim, int hidden, int num_actions, const float* const* h_w, const float* const* h_b,
                       float max_ube, float max_reward_variance, int hash_off, int hash_len, int hash_bits, eaz_net** out);
+/* EpistemicResidualAZNet(num_actions, num_channels=64, num_blocks) resnet.py:42-66 on [H,W,Cin] observations.  h_arrays: the
+ * 42 + 12*num_blocks parameter/state arrays in haiku creation order (resnet.py:72-121): conv {w,b}; per block {bn, conv, bn,
+ * conv}; final bn; policy {conv, bn, linear}; exploration {same}; value {conv, bn, linear, linear}; ube {same};
+ * bn = {scale, offset, mean EMA, var EMA}, conv w = [kh,kw,in,out], linear w = [in,out]. */
+EAZ_API int eaz_net_create_resnet(eaz_ctx* ctx, int H, int W, int Cin, int num_channels, int num_blocks, int num_actions,
+                                  const float* const* h_arrays, int n_arrays, int hash_bits, eaz_net** out);
 EAZ_API int eaz_net_destroy(eaz_net* net);
 /* replace weights (after a learner update) -- same layout as eaz_net_create_fc */
 EAZ_API int eaz_net_set_weights(eaz_net* net, const float* const* h_w, const float* const* h_b, void* stream);

@@ -198,3 +198,72 @@ def test_reanalyze_matches_oracle(oracle, eaz, torch, kind, size, B, S, kw):
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
     f = oenv.fields(s0)
     assert (ref["value_target"][f["terminated"]] == 0).all() and (ref["ube_target"][f["terminated"]] == 0).all()
+
+
+# ---- C4: connect_four + EpistemicResidualAZNet ----------------------------------------------------------------------
+def _c4_setup(oracle, eaz, nb, seed=0, fill=0.3):
+    from e_alphazero_amd import engine
+
+    params, state = eaz.params.init_resnet_params(6, 7, 2, 7, 64, nb, seed=seed)
+    bs = eaz.params.init_hash_state(fill=fill, seed=seed)[eaz.params.HASH_MODULE]["binary_set"]
+    state[eaz.params.RESNET_HASH_MODULE] = {"binary_set": bs}
+    env = engine.EnvHandle.connect4(device=0)
+    net = engine.ResNet(env.ctx, 6, 7, 2, 7, params, state, num_blocks=nb)
+    oenv = oracle.OracleEnv.connect4()
+    onet = oracle.OracleNet.resnet(6, 7, 2, 7, eaz.params.resnet_array_list(params, state, nb), 64, nb, bitset=bs)
+    return engine, env, net, oenv, onet
+
+
+def test_connect4_env_matches_oracle(oracle, eaz, torch):
+    from e_alphazero_amd import engine
+
+    env = engine.EnvHandle.connect4(device=0)
+    oenv = oracle.OracleEnv.connect4()
+    assert env.num_actions == 7 and env.num_players == 2 and env.obs_dim == 84 and env.state_bytes == 80
+    B = 300
+    st = env.init(B, key=11)
+    ost = oenv.init(B, key=(11, 0))
+    assert np.array_equal(st.cpu().numpy(), ost)
+    rng = np.random.default_rng(0)
+    for t in range(50):  # random play incl. illegal moves (full columns), wins, draws, terminal no-ops and auto-resets
+        a = rng.integers(0, 7, B).astype(np.int32)
+        auto = t % 4 == 3
+        st = env.step(st, torch.from_numpy(a).cuda(), key=200 + t, autoreset=auto)
+        ost = oenv.step(ost, a, key=(200 + t, 0), autoreset=auto)
+        assert np.array_equal(st.cpu().numpy(), ost), f"t={t}"
+        assert np.array_equal(env.observe(st).cpu().numpy(), oenv.observe(ost))
+    f = env.fields(st)
+    assert f["rewards"].shape == (B, 2) and f["legal_action_mask"].shape == (B, 7)
+    assert f["terminated"].any() and not f["terminated"].all()
+
+
+@pytest.mark.parametrize("nb,B", [(1, 50), (5, 97)])
+def test_resnet_forward_matches_oracle(oracle, eaz, torch, nb, B):
+    engine, env, net, oenv, onet = _c4_setup(oracle, eaz, nb, seed=nb)
+    ost, _ = oracle.random_play(oenv, B, 11, key=(1, 2))
+    obs = oenv.observe(ost)
+    ref = onet.forward(obs)
+    out = net.forward(torch.from_numpy(obs).cuda())
+    for n, a, b in zip(["exploit", "explore", "value", "ube", "novelty"], out, ref):
+        np.testing.assert_allclose(a.cpu().numpy(), b, rtol=0, atol=ATOL, err_msg=n)
+    print("resnet forward bit-exact vs oracle:", all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(out, ref)))
+
+
+@pytest.mark.parametrize("flags", [{}, dict(directed_exploration=True, exploration_beta=1.0)])
+def test_connect4_selfplay_matches_oracle(oracle, eaz, torch, flags):
+    """BASELINE.json configs[3] reduced: connect_four, two-player discount (-gamma), ResNet, sequential halving with m = 7."""
+    engine, env, net, oenv, onet = _c4_setup(oracle, eaz, 2, seed=4)
+    B, S, T = 40, 24, 12
+    explore = bool(flags.get("directed_exploration", False))
+    search = engine.Search(env, net, B, S, discount=0.997, two_players_game=True, exploration=explore)
+    st = env.init(B, key=2)
+    ost = oenv.init(B, key=(2, 0))
+    out = search.selfplay(st, T, key=31, **flags)
+    ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(31, 0), two_player=True, **flags)
+    assert np.array_equal(out["action"].cpu().numpy(), ref["action"])
+    assert np.array_equal(out["state"].cpu().numpy(), ref["state"])
+    for k in ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction", "q_values_epistemic_variance"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
+    ret, it = engine.Search(env, net, B, S, discount=0.997, two_players_game=True, gumbel_scale=0.0).evaluate(env.init(B, key=5), max_episode_length=50)
+    oret, oit = oracle.evaluate(oenv, onet, oenv.init(B, key=(5, 0)), S, discount=0.997, two_player=True, max_episode_length=50)
+    assert it == oit and np.array_equal(ret.cpu().numpy(), oret)
