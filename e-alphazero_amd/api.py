@@ -111,7 +111,7 @@ class State:
 
     @property
     def current_player(self) -> torch.Tensor:
-        return torch.zeros(self.data.shape[:-1], dtype=torch.int32, device=self.data.device)
+        return self._f()["current_player"]
 
     @property
     def _step_count(self) -> torch.Tensor:
@@ -206,6 +206,23 @@ class Subleq(Env):
         self._h = engine.EnvHandle.subleq(word_size, self.tasks, use_binary_encoding, device=device)
 
 
+class ConnectFour(Env):
+    """pgx.make("connect_four") [EXT] (main.py:190-194): 2 players, 7 actions, observation [6, 7, 2]."""
+
+    id = "connect_four"
+    num_players = 2
+
+    def __init__(self, device=None):
+        self._h = engine.EnvHandle.connect4(device=device)
+
+
+def make(env_id: str, **kw) -> Env:
+    """pgx.make stand-in for the environments the engine implements natively."""
+    if env_id == "connect_four":
+        return ConnectFour(**kw)
+    raise EazError(f"environment {env_id!r} is not implemented natively (available: connect_four, DeepSea, Subleq)")
+
+
 class _Vmapped:
     def __init__(self, fn):
         self.fn = fn
@@ -280,7 +297,11 @@ class ForwardFn:
         if config.hash_class != "XXHash":
             raise EazError(f"hash_class {config.hash_class!r}: only XXHash is implemented natively (config.py:27 default)")
         self.env, self.config = env, config
-        rows, cols = env.observation_shape
+        # get_network (context.py:41-82): FC net for deep_sea / subleq, EpistemicResidualAZNet for every other pgx game
+        self.residual = isinstance(env, ConnectFour)
+        self.num_blocks = 5  # resnet.py:49 (get_network passes no override, context.py:79-82)
+        shape = env.observation_shape
+        rows, cols = (shape[0], shape[1]) if len(shape) == 2 else (shape[0] * shape[1], shape[2])
         self.in_dim = rows * cols
         self.hash_off = 0
         if isinstance(env, Subleq) and config.subleq_hash_only_io:  # context.py:73, fully_connected.py:85-87
@@ -291,13 +312,21 @@ class ForwardFn:
     def init(self, rng_key, dummy_input=None):
         """-> (params, state) in the haiku layout (e-alphazero_amd/params.py)."""
         seed = engine.as_key(rng_key) & 0x7FFFFFFF
+        if self.residual:
+            H, W, cin = self.env.observation_shape
+            return params_lib.init_resnet_params(H, W, cin, self.env.num_actions, 64, self.num_blocks, seed)
         return (params_lib.init_fc_params(self.in_dim, self.config.linear_layer_size, self.env.num_actions, seed),
                 params_lib.init_hash_state())
 
     def net(self, model) -> engine.FCNet:
         model_params, model_state = model
         mid = (id(model_params), id(model_state))
-        if self._net is None:
+        if self._net is None and self.residual:
+            H, W, cin = self.env.observation_shape
+            self._net = engine.ResNet(self.env._h.ctx, H, W, cin, self.env.num_actions, model_params, model_state, 64, self.num_blocks)
+        elif self.residual and mid != self._model_id:
+            raise EazError("ResNet weights are packed at creation: build a new forward fn for new weights")
+        elif self._net is None:
             # get_network does not forward max_ube / max_epistemic_variance_reward to the FC net (context.py:68-75)
             self._net = engine.FCNet(self.env._h.ctx, self.in_dim, self.config.linear_layer_size, self.env.num_actions,
                                      model_params, model_state, max_ube=1.0, max_epistemic_variance_reward=1.0,
@@ -312,7 +341,8 @@ class ForwardFn:
         if is_training:
             raise EazError("forward.apply(is_training=True) is the learner path and is out of scope for the self-play engine")
         net = self.net((model_params, model_state))
-        lead = x.shape[: x.dim() - 2] if x.dim() > 2 else x.shape[:1]
+        nobs = len(self.env.observation_shape)
+        lead = x.shape[: x.dim() - nobs] if x.dim() > nobs else x.shape[:1]
         ex, xp, v, u, nov = net.forward(x)
         if update_hash:
             net.hash_update(x)
@@ -414,7 +444,8 @@ class NativeRecurrentFn:
         logits = logits - logits.max(dim=-1, keepdim=True).values                             # :135
         logits = torch.where(nxt.legal_action_mask, logits, torch.finfo(torch.float32).min)   # :137
         term = nxt.terminated
-        reward = nxt.rewards[:, 0]                                                            # :139 (single player)
+        cp = state.current_player.long()                                                      # :125 captured BEFORE the step
+        reward = nxt.rewards[torch.arange(cp.shape[0], device=cp.device), cp]                 # :139
         value = torch.where(term, 0.0, value)                                                 # :140
         var = torch.where(term, 0.0, var)                                                     # :141
         disc = torch.full_like(value, self.discount) * (-1.0 if self.two_players_game else 1.0)  # :142-143

@@ -144,3 +144,29 @@ def test_reanalyze_and_evaluate_facade(eaz, torch):
     assert (out.ube_target >= 0).all()
     ret = api.evaluate(model, config, context, api.random.PRNGKey(6))
     assert ret.ndim == 0 and 0.0 <= float(ret) <= 1.0
+
+
+def test_connect_four_facade(eaz, torch):
+    """configs[3] through the reference-named surface: pgx.make("connect_four"), ResNet forward, two-player search."""
+    from e_alphazero_amd import api
+
+    env = api.make("connect_four")
+    assert env.num_players == 2 and env.num_actions == 7 and env.observation_shape == (6, 7, 2)
+    B, S, T = 24, 16, 6
+    config = api.Config(env_id="connect_four", two_players_game=True, selfplay_batch_size=B, selfplay_simulations_per_step=S, selfplay_steps=T)
+    forward = api.get_forward_fn(env, config)
+    assert forward.residual
+    model = forward.init(api.random.PRNGKey(1))
+    rf = api.get_epistemic_recurrent_fn(env, forward, B, False, config.discount, config.two_players_game)
+    context = api.Context(env, [0], forward, rf)
+    states = api.vmap(env.init)(api.random.split(2, B))
+    assert states.observation.shape == (B, 6, 7, 2) and set(states.current_player.tolist()) <= {0, 1}
+    (ex, xp, v, u, nov), _ = forward.apply(model[0], model[1], states.observation)
+    assert ex.shape == (B, 7) and v.shape == (B,)
+    # the native recurrent fn called with the emctx signature: reward of the player who moved, discount -gamma
+    out, nxt = rf(model, 0, torch.full((B,), 3, dtype=torch.int32, device="cuda"), states)
+    assert torch.allclose(out.discount, torch.full((B,), -config.discount, device="cuda")) and (out.reward == 0).all()
+    assert (nxt.current_player == 1 - states.current_player).all()
+    last, data = api.selfplay(model, config, context, states, api.random.PRNGKey(3))
+    assert data.state.data.shape[:2] == (T, B) and (data.state._step_count[-1] == T).all()
+    assert torch.isfinite(data.root_value).all()
