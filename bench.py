@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- self-play env-steps/sec of the HIP engine on BASELINE.json's headline configuration.
 
-A "step" is one selfplay() call (src/selfplay.py:78-149): T = 32 real environment steps (config.py:37) of a batch of
-B = 4096 DeepSea-32 environments per GPU, 64 Gumbel-MuZero simulations per real step, FC H=256 network -- BASELINE.json
-configs[1] ("C2").  env-steps = B_total * T per step (src/main.py:378); search-internal steps are not counted.
+A "step" is one selfplay() call (src/selfplay.py:78-149): T real environment steps (config.py:37, T = 32) of a batch of B
+environments per GPU with S Gumbel-MuZero simulations per real step.  env-steps = B_total * T per step (src/main.py:378);
+search-internal steps are not counted.
+
+--workload c2 (default, the configuration BASELINE.json's metric is quoted on): DeepSea-32, B = 4096, S = 64, FC H = 256.
+--workload c3: Subleq word_size 16, B = 4096, S = 64, FC H = 256 (configs[2]).
+--workload c4: connect_four, B = 8192, S = 200, ResNet 64ch x 5 blocks, two-player (configs[3]); T = 4 per step by default
+               (one real step is 201 ResNet forwards of 8192 positions, ~0.6 s).
 
 N > 1: one process per GPU (torchrun), the batch is sharded (weak scaling, B per GPU fixed); the only collective is one RCCL
 all-gather per selfplay() call that pools the [T, B, ...] trajectory block of every rank (the counterpart of
-src/main.py:383-385), inside the timed region.
+src/main.py:383-385), inside the timed region.  When there are more ranks than visible GPUs (rehearsing the launch path on a
+one-GPU box) the ranks share the card and the process group is gloo; the JSON line then carries "rehearsal".
 
-Prints ONE JSON line on rank 0 (see the task contract), with `roofline` for the dominant kernel (fused FC forward,
-f32 MFMA) measured live with HIP events on the launch stream, `roofline_gather` for the leaf-gather kernel (HBM),
-and `cpu_baseline` = the CPU oracle timed on this host on a bounded sample of the same workload.
+Prints ONE JSON line on rank 0 (see the task contract), with `roofline` for the dominant kernel (network forward, f32 MFMA)
+measured live with HIP events on the launch stream, `roofline_gather` for the leaf-gather kernel class (HBM), and
+`cpu_baseline` = the CPU oracle timed on this host on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -30,14 +36,31 @@ from e_alphazero_amd import engine, pool  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBPS = 8000.0        # MI355X_MICROARCH.md "HBM3E peak BW"
+H = 256                       # config.py:24
+
+WORKLOADS = {
+    #        env-steps metric line (BASELINE.json)                 B     S    T   cpu sample (batch, real steps)
+    "c2": dict(metric="self-play env-steps/sec (batch 4096, 64 sims)", B=4096, S=64, T=32, cpu=(4096, 8)),
+    "c3": dict(metric="self-play env-steps/sec (Subleq-16, batch 4096, 64 sims)", B=4096, S=64, T=32, cpu=(1024, 4)),
+    "c4": dict(metric="self-play env-steps/sec (connect_four, batch 8192, 200 sims, ResNet-5)", B=8192, S=200, T=4, cpu=(16, 1)),
+}
 
 
-def fc_flops_per_eval(in_dim, H, A, heads):
+def fc_flops_per_eval(in_dim, A, heads):
     f = 0
     for h in heads:
         out = 1 if h < 2 else A
         f += 2 * (in_dim * H + H * H + H * out)
     return f
+
+
+def resnet_flops_per_eval(Hb=6, Wb=7, cin=2, C=64, nb=5, A=7):
+    """2 * MACs of src/network/resnet.py:72-121 on one [6,7,2] board (all four heads)."""
+    P = Hb * Wb
+    macs = P * 9 * cin * C + 2 * nb * P * 9 * C * C                    # stem + tower
+    macs += 2 * (P * C * 2 + 2 * P * A)                                # two policy heads: 1x1 conv(2) + linear(2P -> A)
+    macs += 2 * (P * C * 1 + P * C + C)                                # value / ube heads: 1x1 conv(1) + linear(P -> C) + linear(C -> 1)
+    return 2 * macs
 
 
 def cpu_share():
@@ -60,45 +83,109 @@ def cpu_share():
     return max(1, min(n, 16))
 
 
+def build_workload(name, args, device, rank):
+    """-> dict(env, net, search, selfplay kwargs, description strings, oracle factory for the CPU baseline)."""
+    w = dict(WORKLOADS[name])
+    B = args.batch or w["B"]
+    S = args.sims or w["S"]
+    T = args.selfplay_steps or w["T"]
+    if name == "c2":
+        G, A = args.grid, 2
+        # synthetic inputs (SURVEY.md 8d): action_map ~ Bernoulli(0.5) seed 0, random-init FC net seed 0, half-filled bit set
+        am = (np.random.default_rng(0).random((G, G)) < 0.5).astype(np.uint8)
+        params = eaz.params.init_fc_params(G * G, H, A, seed=0)
+        hstate = eaz.params.init_hash_state(fill=args.hash_fill, seed=0)
+        env = engine.EnvHandle.deepsea(G, am, device=device)
+        net = engine.FCNet(env.ctx, G * G, H, A, params, hstate)
+        search = engine.Search(env, net, B, S, discount=0.997)
+        desc = f"DeepSea size={G}, batch={B}/GPU, {S} sims, {T} real steps per selfplay() call, FC H={H} (BASELINE.json configs[1])"
+        data = "synthetic (seeded DeepSea action map, random-init FC net, half-filled novelty set)"
+        net_kernel, net_flops = "fc16_forward_kernel", fc_flops_per_eval(G * G, A, (0, 1, 2)) * B
+        pmc_tag = f"DeepSea-{G}, B={B}, {S} sims"
+        gather_kernel = "leaf_gather_deepsea_kernel"
+
+        def oracle(O):
+            oenv = O.OracleEnv.deepsea(G, am)
+            onet = O.OracleNet(G * G, H, A, eaz.params.fc_weight_list(params), bitset=hstate[eaz.params.HASH_MODULE]["binary_set"])
+            return oenv, onet, dict(discount=0.997), f"DeepSea-{G}"
+    elif name == "c3":
+        W = 16
+        cols, rows = (W - 1).bit_length() + 1, W + 32                   # binary encoding, envs/subleq.py:59-60,697-705
+        in_dim, hash_off = rows * cols, W * cols                        # hash_io: rows W.. only (fully_connected.py:85-87)
+        params = eaz.params.init_fc_params(in_dim, H, W, seed=0)
+        hstate = eaz.params.init_hash_state(fill=args.hash_fill, seed=0)
+        env = engine.EnvHandle.subleq(W, (1,), True, device=device)     # task NEGATION_POSITIVE (config.py:18)
+        net = engine.FCNet(env.ctx, in_dim, H, W, params, hstate, hash_off=hash_off, hash_len=in_dim - hash_off)
+        search = engine.Search(env, net, B, S, discount=0.97)
+        A = W
+        desc = f"Subleq word_size={W} task=1 binary obs, batch={B}/GPU, {S} sims, {T} real steps per selfplay() call, FC H={H} (BASELINE.json configs[2])"
+        data = "synthetic (random-init FC net, half-filled novelty set)"
+        net_kernel, net_flops = "fc16_forward_kernel", fc_flops_per_eval(in_dim, A, (0, 1, 2)) * B
+        pmc_tag, gather_kernel = None, "subleq_step_kernel + obs_emit_kernel"
+
+        def oracle(O):
+            oenv = O.OracleEnv.subleq(W, (1,), True)
+            onet = O.OracleNet(in_dim, H, W, eaz.params.fc_weight_list(params), hash_off=hash_off, hash_len=in_dim - hash_off,
+                               bitset=hstate[eaz.params.HASH_MODULE]["binary_set"])
+            return oenv, onet, dict(discount=0.97), f"Subleq-{W}"
+    else:
+        nb, A = 5, 7
+        params, state = eaz.params.init_resnet_params(6, 7, 2, A, 64, nb, seed=0)
+        env = engine.EnvHandle.connect4(device=device)
+        net = engine.ResNet(env.ctx, 6, 7, 2, A, params, state, num_blocks=nb)
+        search = engine.Search(env, net, B, S, discount=0.997, two_players_game=True)
+        desc = f"connect_four, batch={B}/GPU, {S} sims, {T} real steps per selfplay() call, ResNet 64ch x {nb} blocks, two-player (BASELINE.json configs[3])"
+        data = "synthetic (random-init ResNet with synthetic BatchNorm statistics, empty novelty set)"
+        net_kernel, net_flops = "resnet_forward_kernel", resnet_flops_per_eval(nb=nb, A=A) * B
+        pmc_tag, gather_kernel = None, "connect4_step_kernel + obs_emit_kernel"
+
+        def oracle(O):
+            oenv = O.OracleEnv.connect4()
+            onet = O.OracleNet.resnet(6, 7, 2, A, eaz.params.resnet_array_list(params, state, nb), num_blocks=nb)
+            return oenv, onet, dict(discount=0.997, two_player=True), "connect_four"
+    return dict(w, name=name, B=B, S=S, T=T, A=A, env=env, net=net, search=search, desc=desc, data=data, net_kernel=net_kernel,
+                net_flops=net_flops, pmc_tag=pmc_tag, gather_kernel=gather_kernel, oracle=oracle)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--grid", type=int, default=32, help="DeepSea size")
-    ap.add_argument("--batch", type=int, default=4096, help="environments per GPU")
-    ap.add_argument("--sims", type=int, default=64)
-    ap.add_argument("--selfplay-steps", type=int, default=32)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--grid", type=int, default=32, help="DeepSea size (c2)")
+    ap.add_argument("--batch", type=int, default=0, help="environments per GPU (default: the workload's)")
+    ap.add_argument("--sims", type=int, default=0)
+    ap.add_argument("--selfplay-steps", type=int, default=0)
     ap.add_argument("--hash-fill", type=float, default=0.5, help="fraction of the novelty bit-set that is set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=4096)
-    ap.add_argument("--cpu-sample-steps", type=int, default=8)
+    ap.add_argument("--cpu-sample-batch", type=int, default=0)
+    ap.add_argument("--cpu-sample-steps", type=int, default=0)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs a ROCm device: the engine has no CPU path")
+    rehearsal = world > 1 and ndev < world  # more ranks than cards: the ranks share GPUs and talk over gloo
+    device = local_rank % ndev
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-        local_rank = 0
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
     n_gpus = world
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", device)
 
-    G, B, S, T, A, H = args.grid, args.batch, args.sims, args.selfplay_steps, 2, 256
-    # synthetic inputs: action_map ~ Bernoulli(0.5) seed 0, random-init FC net seed 0, half-filled bit set
-    am = (np.random.default_rng(0).random((G, G)) < 0.5).astype(np.uint8)
-    params = eaz.params.init_fc_params(G * G, H, A, seed=0)
-    hstate = eaz.params.init_hash_state(fill=args.hash_fill, seed=0)
-    env = engine.EnvHandle.deepsea(G, am, device=local_rank)
-    net = engine.FCNet(env.ctx, G * G, H, A, params, hstate)
-    search = engine.Search(env, net, B, S, discount=0.997)
+    wl = build_workload(args.workload, args, device, rank)
+    env, search, B, S, T = wl["env"], wl["search"], wl["B"], wl["S"], wl["T"]
     states = env.init(B, key=rank)
     outputs = None
     gathered = None
@@ -108,7 +195,11 @@ def main():
         outputs = search.selfplay(states, T, key=(1000 * rank + i), outputs=outputs)
         if dist is not None:
             # pool the trajectories of all ranks (replay-buffer landing zone): ONE all-gather of the packed block
-            gathered = pool.all_gather_trajectories(pool.pack(outputs), out=gathered)
+            block = pool.pack(outputs)
+            if rehearsal:
+                gathered = pool.all_gather_trajectories(block.cpu(), out=gathered)
+            else:
+                gathered = pool.all_gather_trajectories(block, out=gathered)
 
     def sync():
         if dist is not None:
@@ -124,28 +215,30 @@ def main():
         one_step(i)
     sync()
     dt = time.perf_counter() - t0
-    # ---- instrumented pass: the same K steps again with HIP events recorded on the launch stream around every kernel
+    # ---- instrumented pass: the same kernels again with HIP events recorded on the launch stream around every kernel
     # (event records cannot sit between the nodes of a replayed graph, so this pass uses plain stream launches; kernel
     # durations are unaffected, only the host-side launch gaps differ).  Feeds `roofline`, never `value`. ----
     search.profile(True)
     search.profile_read(reset=True)
     sync()
     t1 = time.perf_counter()
-    for i in range(args.steps):
-        outputs = search.selfplay(states, T, key=(1000 * rank + 500 + i), outputs=outputs, use_graph=False)
+    n_instr = args.steps if args.workload != "c4" else 1
+    T_instr = T if args.workload != "c4" else 1
+    for i in range(n_instr):
+        search.selfplay(states, T_instr, key=(1000 * rank + 500 + i), outputs=outputs if T_instr == T else None, use_graph=False)
     sync()
     dt_instr = time.perf_counter() - t1
     prof = search.profile_read(reset=True)
     search.profile(False)
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     env_steps = B * n_gpus * T * args.steps
-    value = env_steps / dt
+    value = env_steps / dt if dt > 0 else 0.0
     result = {
-        "metric": "self-play env-steps/sec (batch 4096, 64 sims)",
+        "metric": wl["metric"],
         "value": value,
         "unit": "env-steps/s",
         "n_gpus": n_gpus,
@@ -156,71 +249,102 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (seeded DeepSea action map, random-init FC net, half-filled novelty set)",
-        "config": {"workload": f"DeepSea size={G}, batch={B}/GPU, {S} sims, {T} real steps per selfplay() call, FC H={H} (BASELINE.json configs[1])",
-                   "global_batch": B * n_gpus, "parallelism": f"batch-sharded x{n_gpus}, RCCL all-gather of trajectories" if n_gpus > 1 else "single GPU"},
+        "data": wl["data"],
+        "config": {"workload": wl["desc"], "global_batch": B * n_gpus,
+                   "parallelism": f"batch-sharded x{n_gpus}, RCCL all-gather of trajectories" if n_gpus > 1 else "single GPU"},
     }
-    # ---- roofline of the dominant kernel (fused FC forward; 3 heads evaluated: value, ube, exploitation) -----------
-    # `achieved` counts the FLOPs the kernel EXECUTED: layers 2-3 are dense; in layer 1 every 64x4 observation block that
-    # is entirely zero is skipped (exact: fma(0,w,acc)=acc), so executed <= dense.  `dense_equiv` prices the same
-    # launches at the dense count of SURVEY.md 8(d) (2 * MACs of every layer).
-    heads = (0, 1, 2)
+    if rehearsal:
+        result["rehearsal"] = f"{world} ranks share {ndev} GPU(s), gloo all-gather through host memory: launch-path check, not a scaling number"
+    # ---- roofline of the dominant kernel (network forward; the three heads self-play reads: value, ube, exploitation) -----
+    # FC: `achieved` counts the FLOPs the kernel EXECUTED: layers 2-3 are dense; in layer 1 every 64x4 observation block that
+    # is entirely zero is skipped (exact: fma(0,w,acc)=acc), so executed <= dense.  `dense_equiv` prices the same launches at
+    # the dense count of SURVEY.md 8(d) (2 * MACs of every layer).  ResNet: dense implicit GEMMs, executed == dense.
     n_launch = max(prof["net"]["launches"], 1)
-    dense_flops = fc_flops_per_eval(G * G, H, A, heads) * B
-    l23 = sum(2 * (H * H + H * (1 if h < 2 else A)) for h in heads) * B
-    l1_exec = prof["net"]["layer1_ksteps"] * (64 * H * 4 * 2) / n_launch
-    flops = l23 + l1_exec
+    dense_flops = wl["net_flops"]
+    if wl["net_kernel"] == "fc16_forward_kernel":
+        heads = (0, 1, 2)
+        l23 = sum(2 * (H * H + H * (1 if h < 2 else wl["A"])) for h in heads) * B
+        flops = l23 + prof["net"]["layer1_ksteps"] * (16 * H * 4 * 2) / n_launch   # counter unit: one k-step of a 16-row tile
+    else:
+        flops = dense_flops
     net_ms = prof["net"]["ms"] / n_launch
     ach = flops / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0
-    result["roofline"] = {"kernel": "fc_forward_kernel", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+    result["roofline"] = {"kernel": wl["net_kernel"], "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                           "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                           "avg_launch_us": 1e3 * net_ms, "launches": prof["net"]["launches"],
                           "flops_per_launch": flops, "dense_flops_per_launch": dense_flops,
                           "dense_equiv_tflops": dense_flops / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0}
-    # leaf gather: algorithmic bytes on the engine's compact layout = parent state + child state + observation row
+    # leaf gather: algorithmic bytes on the engine's compact layout = parent state + child state + observation row.
+    # C2 production path: the DeepSea step is fused into the tree kernel and the observation row is never materialised
+    # (one-hot index instead), so there is no gather launch; the standalone kernel is measured on a short unfused run
+    # (eaz_tune_set(EAZ_TUNE_FUSED_LEAF, 0)) for the record.
+    gather_note = None
+    if prof["gather"]["launches"] == 0:
+        engine.tune(fused_leaf=0)
+        s2 = engine.Search(env, wl["net"], B, S, discount=0.997)
+        st2 = env.init(B, key=rank)
+        s2.selfplay(st2, 1, key=7, use_graph=False)
+        s2.profile(True)
+        s2.profile_read(reset=True)
+        s2.selfplay(st2, 4, key=8, use_graph=False)
+        torch.cuda.synchronize()
+        prof_g = s2.profile_read(reset=True)
+        del s2
+        engine.tune(fused_leaf=1)
+        gather_note = "standalone kernel of the unfused variant (EAZ_TUNE_FUSED_LEAF=0); the timed path fuses the step into tree_step_kernel"
+    else:
+        prof_g = prof
     gbytes = B * (2 * env.state_bytes + env.obs_dim)
-    g_ms = prof["gather"]["ms"] / max(prof["gather"]["launches"], 1)
+    g_launch = max(prof_g["gather"]["launches"], 1)
+    per_sim = 1 if args.workload == "c2" else 2          # c3/c4: env-step kernel + observation-emit kernel per simulation
+    g_ms = per_sim * prof_g["gather"]["ms"] / g_launch
     gach = gbytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
     # HBM-side traffic per launch from the PMC passes committed under profiles/ (rocprofv3 FETCH_SIZE / WRITE_SIZE cannot be
     # collected from inside this process); only attached when the file was recorded for this workload
     traffic = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")) as f:
-            pmc = json.load(f)
-        if pmc.get("workload") == f"DeepSea-{G}, B={B}, {S} sims":
-            for kname, field in (("eaz::fc_forward_kernel", "roofline"), ("eaz::leaf_gather_deepsea_kernel", "roofline_gather")):
+    pmc_file = None
+    for cand in ("r01_d_pmc_traffic.json", "r01_b_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", cand)) as f:
+                pmc = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if wl["pmc_tag"] and pmc.get("workload") == wl["pmc_tag"]:
+            pmc_file = "profiles/" + cand
+            for kname, field in (("eaz::fc16_forward_kernel", "roofline"), ("eaz::leaf_gather_deepsea_kernel", "roofline_gather")):
                 k = pmc["kernels"].get(kname)
                 if k:
                     traffic[field] = 1024.0 * (k.get("FETCH_SIZE_KB_per_launch", 0.0) + k.get("WRITE_SIZE_KB_per_launch", 0.0))
-    except (OSError, ValueError):
-        pass
+            break
     if "roofline" in traffic:
         result["roofline"]["traffic"] = traffic["roofline"]
-        result["roofline"]["traffic_source"] = "profiles/r01_b_pmc_traffic.json (raw FETCH_SIZE+WRITE_SIZE, bytes per launch)"
-    result["roofline_gather"] = {"kernel": "leaf_gather_deepsea_kernel", "bound": "hbm", "achieved": gach, "peak": PEAK_HBM_GBPS,
+        result["roofline"]["traffic_source"] = pmc_file + " (FETCH_SIZE+WRITE_SIZE, bytes per launch)"
+    result["roofline_gather"] = {"kernel": wl["gather_kernel"], "bound": "hbm", "achieved": gach, "peak": PEAK_HBM_GBPS,
                                  "unit": "GB/s", "frac": gach / PEAK_HBM_GBPS, "traffic": None, "avg_launch_us": 1e3 * g_ms,
-                                 "launches": prof["gather"]["launches"], "bytes_per_launch": gbytes}
+                                 "launches": prof_g["gather"]["launches"] // per_sim, "bytes_per_launch": gbytes}
+    if gather_note:
+        result["roofline_gather"]["note"] = gather_note
     if "roofline_gather" in traffic:
         result["roofline_gather"]["traffic"] = traffic["roofline_gather"]
     result["kernel_ms_instrumented_pass"] = {k: round(v["ms"], 3) for k, v in prof.items()}
-    result["instrumented_pass_env_steps_per_s"] = B * T * args.steps / dt_instr
+    result["instrumented_pass_env_steps_per_s"] = B * T_instr * n_instr / dt_instr
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload, rank 0 at N = 1 only -------------------
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import eaz_oracle as O
 
-        cb, ct = args.cpu_sample_batch, args.cpu_sample_steps
+        cb = args.cpu_sample_batch or wl["cpu"][0]
+        ct = args.cpu_sample_steps or wl["cpu"][1]
         ncores = cpu_share()
         O.lib().eazo_set_num_threads(ncores)
-        oenv = O.OracleEnv.deepsea(G, am)
-        onet = O.OracleNet(G * G, H, A, eaz.params.fc_weight_list(params), bitset=hstate[eaz.params.HASH_MODULE]["binary_set"])
+        oenv, onet, okw, oname = wl["oracle"](O)
         ost = oenv.init(cb)
         c0 = time.perf_counter()
-        O.selfplay(oenv, onet, ost, T=ct, S=S, key=(0, 0))
+        O.selfplay(oenv, onet, ost, T=ct, S=S, key=(0, 0), **okw)
         cdt = time.perf_counter() - c0
         result["cpu_baseline"] = {"value": cb * ct / cdt, "unit": "env-steps/s", "cores": O.lib().eazo_num_threads(),
-                                  "kind": "port", "sample": f"DeepSea-{G}, batch {cb}, {S} sims, {ct} real steps ({cdt:.1f} s)"}
+                                  "kind": "port", "sample": f"{oname}, batch {cb}, {S} sims, {ct} real steps ({cdt:.1f} s)"}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -77,6 +77,7 @@ SIGNATURES = {
     "eaz_profile_enable": [_vp, _i],
     "eaz_profile_read": [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), _i],
     "eaz_profile_net_ksteps": [_vp, C.POINTER(C.c_uint64), _i],
+    "eaz_tune_set": [_i, _i],
 }
 
 _lib = None

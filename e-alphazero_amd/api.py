@@ -320,18 +320,20 @@ class ForwardFn:
 
     def net(self, model) -> engine.FCNet:
         model_params, model_state = model
-        mid = (id(model_params), id(model_state))
+        # identity of the pytrees the device copy was made from; the references are kept so the ids cannot be recycled
+        same = self._model_id is not None and self._model_id[0] is model_params and self._model_id[1] is model_state
+        mid = (model_params, model_state)
         if self._net is None and self.residual:
             H, W, cin = self.env.observation_shape
             self._net = engine.ResNet(self.env._h.ctx, H, W, cin, self.env.num_actions, model_params, model_state, 64, self.num_blocks)
-        elif self.residual and mid != self._model_id:
+        elif self.residual and not same:
             raise EazError("ResNet weights are packed at creation: build a new forward fn for new weights")
         elif self._net is None:
             # get_network does not forward max_ube / max_epistemic_variance_reward to the FC net (context.py:68-75)
             self._net = engine.FCNet(self.env._h.ctx, self.in_dim, self.config.linear_layer_size, self.env.num_actions,
                                      model_params, model_state, max_ube=1.0, max_epistemic_variance_reward=1.0,
                                      hash_off=self.hash_off)
-        elif mid != self._model_id:
+        elif not same:
             self._net.set_params(model_params)
             self._net.set_state(model_state)
         self._model_id = mid
@@ -458,13 +460,13 @@ def get_epistemic_recurrent_fn(env: Env, forward: ForwardFn, batch_size: int, ex
     return NativeRecurrentFn(env, forward, batch_size, exploration, discount, two_players_game)
 
 
-_search_cache: dict = {}
-
-
 def _get_search(rf: NativeRecurrentFn, model, B: int, S: int, qopts: dict, max_considered: int, gumbel_scale: float,
                 max_depth) -> engine.Search:
     net = rf.forward.net(model)
-    key = (id(rf), B, S, tuple(sorted(qopts.items())), max_considered, float(gumbel_scale), max_depth)
+    # searches live on the recurrent fn they were built for (a global table keyed by id(rf) would hand a recycled id the
+    # search of a dead object)
+    _search_cache = rf.__dict__.setdefault("_searches", {})
+    key = (id(net), B, S, tuple(sorted(qopts.items())), max_considered, float(gumbel_scale), max_depth)
     if key not in _search_cache:
         _search_cache[key] = engine.Search(rf.env._h, net, B, S, discount=rf.discount, two_players_game=rf.two_players_game,
                                            exploration=rf.exploration, rescale_values=qopts["rescale_values"],

@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -70,6 +71,7 @@ struct eaz_net {
     float* d_w[12];
     float* d_b[12];
     size_t bitset_bytes;
+    uint32_t* d_ztab;                     // NetDev::ztab storage
     unsigned long long* d_kstep_counter;  // executed layer-1 k-steps (profiling only; nullptr = off)
     unsigned long long* d_kstep_storage;
 };
@@ -92,6 +94,8 @@ struct eaz_search {
     uint8_t* d_obs;
     float *d_novelty, *d_exploit, *d_explore, *d_v, *d_u, *d_next_reward;
     uint8_t *d_next_term, *d_next_legal;
+    int32_t* d_leaf_hot;
+    int fuse_leaf;  // DeepSea + FC network: env.step fused into the tree kernel, one-hot forward (TreeDev::fuse_env)
     int32_t* d_table;
     // root buffers used by the self-play driver
     float *d_root_logits, *d_root_beta, *d_root_gumbel, *d_aw, *d_vprobs;
@@ -326,6 +330,23 @@ extern "C" int eaz_net_create_fc(eaz_ctx* ctx, int in_dim, int hidden, int num_a
     if (n->bitset_bytes < 4) n->bitset_bytes = 4;
     HIP_OK(hipMalloc(&n->dev.bitset, n->bitset_bytes));
     HIP_OK(hipMemset(n->dev.bitset, 0, n->bitset_bytes));
+    {
+        // hash lane i after n all-zero stripes (hashes.py:176-181,217-221 with lane value 0): n = 0 .. L
+        const uint32_t P1 = 0x9E3779B1u, P2 = 0x85EBCA77u, SEED = 1u;
+        const int L = hash_len / 4;
+        std::vector<uint32_t> zt(static_cast<size_t>(4) * (L + 1));
+        const uint32_t init[4] = {SEED + P1 + P2, SEED + P2, SEED, SEED - P1};
+        for (int i = 0; i < 4; ++i) {
+            uint32_t acc = init[i];
+            for (int k = 0; k <= L; ++k) {
+                zt[static_cast<size_t>(i) * (L + 1) + k] = acc;
+                acc = ((acc << 13) | (acc >> 19)) * P1;
+            }
+        }
+        HIP_OK(hipMalloc(&n->d_ztab, zt.size() * sizeof(uint32_t)));
+        HIP_OK(hipMemcpy(n->d_ztab, zt.data(), zt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        n->dev.ztab = n->d_ztab;
+    }
     if (in_dim > 256 * kFcMaxBlocks) return fail("observation size %d exceeds the FC kernel's limit %d", in_dim, 256 * kFcMaxBlocks);
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_forward_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFcLdsBytes));
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_forward_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFcLdsBytes));
@@ -351,6 +372,7 @@ extern "C" int eaz_net_create_resnet(eaz_ctx* ctx, int H, int W, int Cin, int C,
     eaz_net* n = new eaz_net();
     n->ctx = ctx;
     n->kind = 1;
+    n->d_ztab = nullptr;
     std::memset(&n->dev, 0, sizeof n->dev);
     std::memset(&n->rdev, 0, sizeof n->rdev);
     for (int l = 0; l < 12; ++l) { n->d_w[l] = nullptr; n->d_b[l] = nullptr; }
@@ -413,6 +435,7 @@ extern "C" int eaz_net_destroy(eaz_net* n) {
     if (n->d_rparams) (void)hipFree(n->d_rparams);
     for (int l = 0; l < 12; ++l) { if (n->d_w[l]) (void)hipFree(n->d_w[l]); if (n->d_b[l]) (void)hipFree(n->d_b[l]); }
     (void)hipFree(n->dev.bitset);
+    if (n->d_ztab) (void)hipFree(n->d_ztab);
     (void)hipFree(n->d_kstep_storage);
     delete n;
     return 0;
@@ -450,10 +473,49 @@ static int hash_launch(eaz_net* n, int B, const uint8_t* obs, float* novelty, ui
     return 0;
 }
 
+// eaz_tune_set knobs (include/eaz.h); the environment variables EAZ_FC_TILE / EAZ_FUSED_LEAF give the initial values
+static int g_fc_tile = [] { const char* e = std::getenv("EAZ_FC_TILE"); return e ? std::atoi(e) : 0; }();
+static int g_fused_leaf = [] { const char* e = std::getenv("EAZ_FUSED_LEAF"); return e ? std::atoi(e) : 1; }();
+
+extern "C" int eaz_tune_set(int knob, int value) {
+    if (knob == EAZ_TUNE_FC_TILE) {
+        ARG_OK(value == 0 || value == 16 || value == 64);
+        g_fc_tile = value;
+    } else if (knob == EAZ_TUNE_FUSED_LEAF) {
+        g_fused_leaf = value != 0;
+    } else {
+        return fail("eaz_tune_set: unknown knob %d", knob);
+    }
+    return 0;
+}
+
+// forward of B one-hot observations given by index + their novelty lookup, ONE launch (fc16_forward_kernel<2>)
+static int fc_onehot_launch(eaz_net* n, int B, const int32_t* hot, float* novelty, const NetOut& o, const HeadList& heads, hipStream_t st) {
+    if (B <= 0 || heads.n <= 0) return 0;
+    const int per_xcd = cdiv(cdiv(B, kF16M), 8);
+    const int nb = 8 * per_xcd * heads.n;
+    const FcIn in{nullptr, hot, novelty, n->dev.ztab};
+    fc16_forward_kernel<2><<<nb + (novelty ? cdiv(B, 256) : 0), 256, kF16LdsBytes, st>>>(n->dev, in, B, o, heads, per_xcd, nb, n->d_kstep_counter);
+    LAUNCH_OK();
+    return 0;
+}
+
 static int fc_launch(eaz_net* n, int B, const uint8_t* obs, const NetOut& o, const HeadList& heads, hipStream_t st) {
     if (B <= 0 || heads.n <= 0) return 0;
     if (n->kind == 1) {  // residual tower: six samples per workgroup, all heads in one launch
         resnet_forward_kernel<<<cdiv(B, kRnSamples), 256, kRnLdsBytes, st>>>(n->rdev, obs, B, o);
+        LAUNCH_OK();
+        return 0;
+    }
+    // 16-row tiles while the whole launch is resident at once (<= 4 workgroups per CU), 64-row tiles for larger batches
+    // (a quarter of the weight traffic per row)
+    const int per_xcd = cdiv(cdiv(B, kF16M), 8);
+    if (g_fc_tile == 16 || (g_fc_tile == 0 && static_cast<long>(8) * per_xcd * heads.n <= 4 * 256)) {
+        const bool fast16 = (n->dev.in_dim % 16 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0);
+        const FcIn in{obs, nullptr, nullptr, nullptr};
+        const int nb = 8 * per_xcd * heads.n;
+        if (fast16) fc16_forward_kernel<0><<<nb, 256, kF16LdsBytes, st>>>(n->dev, in, B, o, heads, per_xcd, nb, n->d_kstep_counter);
+        else fc16_forward_kernel<1><<<nb, 256, kF16LdsBytes, st>>>(n->dev, in, B, o, heads, per_xcd, nb, n->d_kstep_counter);
         LAUNCH_OK();
         return 0;
     }
@@ -648,6 +710,11 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     DALLOC(s->d_sum_q, static_cast<size_t>(B) * A); DALLOC(s->d_sum_vc, static_cast<size_t>(B) * A); DALLOC(s->d_next_v, B);
     DALLOC(s->d_term, B); DALLOC(s->d_term2, B); DALLOC(s->d_reward_tmp, B); DALLOC(s->d_alive, 1);
     t.next_reward = s->d_next_reward; t.next_term = s->d_next_term; t.next_legal = s->d_next_legal;
+    DALLOC(s->d_leaf_hot, B);
+    t.fenv = env->dev; t.fuse_reward = s->d_next_reward; t.fuse_term = s->d_next_term; t.leaf_hot = s->d_leaf_hot;
+    t.fuse_env = 0;
+    s->fuse_leaf = g_fused_leaf && env->dev.kind == EAZ_ENV_DEEPSEA && net->kind == 0 && net->dev.ztab != nullptr;
+    if (s->fuse_leaf) HIP_OK(hipMemset(s->d_next_legal, 1, static_cast<size_t>(B) * A));  // legal_action_mask all true (deep_sea.py:19)
     *out = s;
     return 0;
 }
@@ -730,6 +797,13 @@ static int infer_launch(eaz_search* s, const uint8_t* obs, float* novelty, const
 static int recurrent_launch(eaz_search* s, hipStream_t st) {
     eaz_env* env = s->env;
     const int B = s->B;
+    HeadList hl{3, {0, 1, s->opts.exploration ? 3 : 2, 0}};
+    NetOut o{s->opts.exploration ? nullptr : s->d_exploit, s->opts.exploration ? s->d_explore : nullptr, s->d_v, s->d_u};
+    if (s->tree.fuse_env) {
+        // the tree kernel already stepped the environment and left the one-hot index of the new observation
+        ProfScope ps(s, EAZ_K_NET, st);
+        return fc_onehot_launch(s->net, B, s->d_leaf_hot, s->d_novelty, o, hl, st);
+    }
     {
         ProfScope ps(s, EAZ_K_GATHER, st);
         if (env->dev.kind == EAZ_ENV_DEEPSEA) {
@@ -755,8 +829,6 @@ static int recurrent_launch(eaz_search* s, hipStream_t st) {
             LAUNCH_OK();
         }
     }
-    HeadList hl{3, {0, 1, s->opts.exploration ? 3 : 2, 0}};
-    NetOut o{s->opts.exploration ? nullptr : s->d_exploit, s->opts.exploration ? s->d_explore : nullptr, s->d_v, s->d_u};
     return infer_launch(s, s->d_obs, s->d_novelty, o, hl, st);
 }
 
@@ -764,6 +836,7 @@ extern "C" int eaz_search_simulate(eaz_search* s, int sim, void* stream) {
     ARG_OK(s && sim >= 0 && sim < s->S);
     hipStream_t st = S(stream);
     s->tree.fused_rf = 1;
+    s->tree.fuse_env = s->fuse_leaf ? 1 + s->env->dev.kind : 0;
     int mode = kTreeSelect | (s->pending_expand >= 0 ? kTreeExpand : 0);
     int rc = tree_step_launch(s, sim, mode, st);
     if (rc) return rc;
@@ -819,6 +892,7 @@ extern "C" int eaz_search_select(eaz_search* s, int sim, int32_t* d_parent, int3
     ARG_OK(s && sim >= 0 && sim < s->S);
     hipStream_t st = S(stream);
     if (s->pending_expand >= 0) return fail("eaz_search_select: simulation %d has not been expanded yet", s->pending_expand);
+    s->tree.fuse_env = 0;  // the caller's recurrent_fn steps the environment
     int rc = tree_step_launch(s, sim, kTreeSelect, st);
     if (rc) return rc;
     const size_t n = sizeof(int32_t) * s->B;

@@ -32,6 +32,7 @@ struct NetDev {
     float max_u, nov_scale;
     int hash_off, hash_len, hash_bits;
     uint8_t* bitset;  // device, 2^(hash_bits-3) bytes
+    const uint32_t* ztab;  // device [4][hash_len/4 + 1]: accumulator of hash lane i after n all-zero stripes (one-hot fast path)
 };
 
 struct NetOut {
@@ -431,7 +432,7 @@ __global__ void __launch_bounds__(256, 1) fc_forward_kernel(NetDev net, const ui
         }
     }
     EAZ_STAMP(6);
-    if (kstep_counter && tid == 0) atomicAdd(kstep_counter, executed);
+    if (kstep_counter && tid == 0) atomicAdd(kstep_counter, 4 * executed);  // unit: one k-step of a 16-row tile
 }
 
 // ---- XXHash-variant novelty (src/network/hashes.py:162-229): 4 consecutive lanes per sample, lane i = quarter i ----
@@ -493,6 +494,313 @@ __global__ void __launch_bounds__(256) hash_kernel(NetDev net, const uint8_t* __
     if (novelty) novelty[b] = (seen ? 0.0f : 1.0f) * net.nov_scale;                               // fully_connected.py:90
     if (seen_out) seen_out[b] = seen ? 1 : 0;
     if (idx_out) idx_out[b] = index;
+}
+
+// ==================================================================================================================
+// fc16_forward_kernel -- the same three layers with 16 batch rows per workgroup.
+//
+// Why: at B = 4096 the 64-row kernel has 64 x heads workgroups of ~33 k MFMA cycles each on 256 CUs (one per CU, 25 % of
+// the CUs idle, nothing to overlap the staging / store phases with).  16-row tiles give 256 x heads workgroups of a quarter
+// of the work, three or four co-resident per CU (36 KB of LDS, <= 128 VGPRs): the MFMA pipes of every CU are shared by
+// waves that are in different phases, and the critical path of one launch is a 16-row tile, not a 64-row one.
+// Each wave owns 64 output columns x 16 rows = 1x4 MFMA tiles; operands per k-step: one LDS read (A) + one 16-byte weight
+// load (B) for 4 MFMAs.  Weights are re-read from L2 four times as often as by the 64-row kernel (256 KB of W2 per 16 rows),
+// so the host picks this kernel only while every workgroup of the launch is resident at once.
+//
+// SRC 0: dense uint8 observations, 16-byte loads (in_dim % 16 == 0, aligned base);  SRC 1: dense, guarded byte loads;
+// SRC 2: ONE-HOT observations given as the flat index of the single 1 (hot[b]): layer 1 is the row W1[hot] (exactly
+//        fmaf(1, w, +0) per column; every other term of the chain is fmaf(0, w, acc) = acc), no observation tile at all,
+//        and the novelty lookup of the same observations runs in extra workgroups of the same launch (hash of a one-hot row:
+//        precomputed zero-run prefix + the single non-zero round + the remaining zero rounds).
+// ==================================================================================================================
+constexpr int kF16M = 16;
+constexpr int kF16HFloats = kFcH * 16 + (kFcH / 4) * 4;  // K-major [256][16] with a 16-byte skew every 4 k: conflict-free b128 stores
+constexpr int kF16HBytes = kF16HFloats * 4;              // 17 408
+constexpr int kF16LdsBytes = 2 * kF16HBytes + kFcMaskBytes;
+static_assert(kF16M * kFcKC <= kF16HBytes, "the observation chunk (16 rows x 1024 inputs, uint8) aliases the H2 tile");
+
+__device__ __forceinline__ int h16_off(int k, int row) { return k * 16 + (k >> 2) * 4 + row; }
+
+struct FcIn {
+    const uint8_t* obs;     // SRC 0/1: [B, in_dim]
+    const int32_t* hot;     // SRC 2: [B] flat index of the single 1
+    float* novelty;         // SRC 2: [B] or null
+    const uint32_t* ztab;   // SRC 2: [4][L+1] accumulator of hash lane i after n all-zero stripes (L = hash_len / 4)
+};
+
+struct A16 {
+    uint4 w[4];  // rows 4 * wave + i, inputs 16 * (tid & 63) .. +15 of the chunk
+};
+
+template <int SRC>
+__device__ __forceinline__ void a16_load(A16& s, const uint8_t* obs, int B, int in_dim, int row0, int chunk, int tid) {
+    const int k = chunk * kFcKC + 16 * (tid & 63);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + 4 * (tid >> 6) + i;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (SRC == 0) {
+            const bool ok = row < B && k < in_dim;
+            const long off = static_cast<long>(ok ? row : 0) * in_dim + (ok ? k : 0);
+            const uint4 ld = *reinterpret_cast<const uint4*>(obs + off);
+            v.x = ok ? ld.x : 0u; v.y = ok ? ld.y : 0u; v.z = ok ? ld.z : 0u; v.w = ok ? ld.w : 0u;
+        } else {
+            uint32_t d[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const bool ok = row < B && k + b < in_dim;
+                const long off = ok ? static_cast<long>(row) * in_dim + k + b : 0;
+                const uint32_t byte = obs[off];
+                d[b >> 2] |= (ok ? byte : 0u) << (8 * (b & 3));
+            }
+            v = make_uint4(d[0], d[1], d[2], d[3]);
+        }
+        s.w[i] = v;
+    }
+}
+
+__device__ __forceinline__ void a16_masks(unsigned long long* kmask /* [4 blocks][4 waves] */, const A16& s, int tid) {
+    uint32_t any[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { any[0] |= s.w[i].x; any[1] |= s.w[i].y; any[2] |= s.w[i].z; any[3] |= s.w[i].w; }
+    unsigned long long bw[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) bw[w] = __ballot(any[w] != 0);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        unsigned long long m = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) m |= spread4(bw[w] >> (16 * kb)) << w;
+        if ((tid & 63) == 0) kmask[kb * 4 + (tid >> 6)] = m;
+    }
+}
+
+// observation tile: row-major uint8 [16][1024]; the 16-byte slot index is XOR-ed with the row (low 4 bits), so the 16 rows
+// that one A-operand read touches (same k, rows 0..15) fall into 16 different 16-byte bank groups
+__device__ __forceinline__ void a16_store(uint8_t* At, const A16& s, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 4 * (tid >> 6) + i;
+        *reinterpret_cast<uint4*>(At + row * kFcKC + ((((tid & 63) ^ row)) << 4)) = s.w[i];
+    }
+}
+
+// U8A: A = observation tile block (256 inputs at Abase, layer 1); else A = hidden tile (layer 2 / 3)
+template <bool U8A>
+__device__ __forceinline__ void mma16_block(floatx4 (&acc)[4], const void* Abase, unsigned long long mask, const float* W, int K, int k0,
+                                            int col, int r, int kq) {
+    KGroup gc = next_group(mask);
+    if (gc.n == 0) return;
+    BGroup bc, bn;
+    load_group(bc, gc, W, K, k0, col, kq);
+#pragma clang loop unroll(disable)
+    while (true) {
+        const KGroup gn = next_group(mask);
+        if (gn.n) load_group(bn, gn, W, K, k0, col, kq);
+#pragma unroll
+        for (int i = 0; i < kFcG; ++i) {
+            float a;
+            if constexpr (U8A) {
+                const int k = 4 * gc.ks[i] + kq;
+                a = static_cast<float>(static_cast<const uint8_t*>(Abase)[r * kFcKC + ((((k >> 4) ^ r)) << 4) + (k & 15)]);
+            } else {
+                a = static_cast<const float*>(Abase)[h16_off(4 * gc.ks[i] + kq, r)];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc.v[i][t], acc[t], 0, 0, 0);
+        }
+        if (gn.n == 0) break;
+        gc = gn;
+        bc = bn;
+    }
+}
+
+// accumulators -> relu(acc + bias) -> hidden tile: lane (r, kq) holds rows 4*kq .. 4*kq+3 of column n0 + 4*r + t
+__device__ __forceinline__ void store_hidden16(float* Ht, const floatx4 (&acc)[4], const float* bias, int n0, int r, int kq) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int col = n0 + 4 * r + t;
+        const float bj = bias[col];
+        floatx4 o;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float v = acc[t][reg] + bj;
+            o[reg] = v > 0.0f ? v : 0.0f;
+        }
+        *reinterpret_cast<floatx4*>(Ht + h16_off(col, 4 * kq)) = o;
+    }
+}
+
+__device__ __forceinline__ uint32_t xxh_zero_round(uint32_t acc) { return rotl32(acc, 13) * 0x9E3779B1u; }
+
+template <int SRC>
+__global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn in, int B, NetOut out, HeadList heads, int per_xcd, int n_fc_blocks,
+                                                              unsigned long long* kstep_counter) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x;
+    if constexpr (SRC == 2) {
+        if (static_cast<int>(blockIdx.x) >= n_fc_blocks) {
+            // ---- novelty lookup of one-hot observations (hashes.py:162-229 on a row that is zero except obs[hot] = 1) ----
+            const int b = (blockIdx.x - n_fc_blocks) * 256 + tid;
+            if (b >= B || !in.novelty) return;
+            const uint32_t P1 = 0x9E3779B1u, P2 = 0x85EBCA77u, P3 = 0xC2B2AE3Du;
+            const int L = net.hash_len >> 2;
+            const int h = in.hot[b] - net.hash_off;
+            const bool inside = h >= 0 && h < net.hash_len;
+            const int q = inside ? h / L : -1, n1 = inside ? h - q * L : 0;
+            uint32_t acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = in.ztab[i * (L + 1) + (i == q ? n1 : L)];
+            if (inside) {
+                const uint32_t sel = q == 0 ? acc[0] : (q == 1 ? acc[1] : (q == 2 ? acc[2] : acc[3]));
+                uint32_t a = rotl32(sel + 0x3F800000u * P2, 13) * P1;  // the stripe holding 1.0f (bitcast, hashes.py:207)
+                for (int n = n1 + 1; n < L; ++n) a = xxh_zero_round(a);
+                if (q == 0) acc[0] = a; else if (q == 1) acc[1] = a; else if (q == 2) acc[2] = a; else acc[3] = a;
+            }
+            uint32_t hh = rotl32(acc[0], 1) + rotl32(acc[1], 7) + rotl32(acc[2], 12) + rotl32(acc[3], 18);  // :184-187
+            hh += static_cast<uint32_t>(L);                                                                 // :226
+            hh ^= hh >> 15; hh *= P2; hh ^= hh >> 13; hh *= P3; hh ^= hh >> 16;                             // :190-197
+            const uint32_t index = hh >> (32 - net.hash_bits);                                              // :229
+            const bool seen = net.bitset ? ((net.bitset[index >> 3] >> (index & 7u)) & 1u) != 0 : false;
+            in.novelty[b] = (seen ? 0.0f : 1.0f) * net.nov_scale;
+            return;
+        }
+    }
+    float* H1 = reinterpret_cast<float*>(lds);
+    uint8_t* R2 = lds + kF16HBytes;
+    float* H2 = reinterpret_cast<float*>(R2);
+    unsigned long long* kmask = reinterpret_cast<unsigned long long*>(lds + 2 * kF16HBytes);
+
+    // blockIdx -> (head, row tile): XCD x (= blockIdx % 8) owns row tiles x*per_xcd .. +per_xcd-1 of EVERY head (3-4 heads of
+    // weights = 3.8-5 MB against its 4 MiB L2); consecutive blocks of an XCD walk the tiles of one head
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int hsel = j / per_xcd;
+    const int tile = xcd * per_xcd + (j - hsel * per_xcd);
+    const int n_tiles = (B + kF16M - 1) / kF16M;
+    if (hsel >= heads.n || tile >= n_tiles) return;
+    const int head = heads.id[hsel];
+    const int row0 = tile * kF16M;
+
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
+    const int n0 = wave * 64, col = n0 + 4 * r;
+    const int K1 = net.in_dim;
+    const float *W1 = net.w[head * 3], *W2 = net.w[head * 3 + 1], *W3 = net.w[head * 3 + 2];
+    const float *b1 = net.b[head * 3], *b2 = net.b[head * 3 + 1], *b3 = net.b[head * 3 + 2];
+    const int No = head < 2 ? 1 : net.A;
+
+    floatx4 acc[4];
+    unsigned long long executed = 0;
+    if constexpr (SRC == 2) {
+        // ---------------- layer 1 of a one-hot row: relu(W1[hot] + b1), thread = output column ----------------
+        float w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = row0 + i;
+            int h = in.hot[row < B ? row : B - 1];
+            h = h < 0 ? 0 : (h >= K1 ? K1 - 1 : h);
+            w[i] = W1[static_cast<long>(h) * kFcH + tid];
+        }
+        const float bj = b1[tid];
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            floatx4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = __builtin_fmaf(1.0f, w[4 * i4 + i], 0.0f) + bj;
+                o[i] = v > 0.0f ? v : 0.0f;
+            }
+            *reinterpret_cast<floatx4*>(H1 + h16_off(tid, 4 * i4)) = o;
+        }
+    } else {
+        // ---------------- layer 1: [16 x K1] x [K1 x 256], all-zero k-steps skipped ----------------
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        const int nchunk1 = (K1 + kFcKC - 1) / kFcKC;
+        A16 st;
+        a16_load<SRC>(st, in.obs, B, K1, row0, 0, tid);
+        for (int c = 0; c < nchunk1; ++c) {
+            a16_masks(&kmask[16 * c], st, tid);
+            a16_store(R2, st, tid);
+            __syncthreads();  // chunk c and its masks are visible
+            if (c + 1 < nchunk1) a16_load<SRC>(st, in.obs, B, K1, row0, c + 1, tid);
+#pragma unroll 1
+            for (int kb = 0; kb < 4; ++kb) {
+                const unsigned long long mv = block_mask(&kmask[16 * c], kb);
+                const unsigned long long m = static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(mv))) |
+                                             (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(mv >> 32))) << 32);
+                executed += __builtin_popcountll(m);
+                mma16_block<true>(acc, R2 + kb * 256, m, W1, K1, c * kFcKC + kb * 256, col, r, kq);
+            }
+            if (c + 1 < nchunk1) __syncthreads();  // everyone is done reading chunk c before it is overwritten
+        }
+        store_hidden16(H1, acc, b1, n0, r, kq);
+    }
+    __syncthreads();  // H1 complete; region 2 (observation chunk) is dead from here on
+
+    // ---------------- layer 2: [16 x 256] x [256 x 256], dense ----------------
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    mma16_block<false>(acc, H1, ~0ull, W2, kFcH, 0, col, r, kq);
+    // layer-3 weights of the narrow heads: B operand of wave 0's MFMA chain (column r of W3, zero beyond No), all 64 loads in
+    // flight while H2 is being written
+    float w3[kFcH / 4];
+    const bool narrow = No <= 16;
+    if (narrow && wave == 0) {
+#pragma unroll
+        for (int ks = 0; ks < kFcH / 4; ++ks) w3[ks] = r < No ? W3[(4 * ks + kq) * No + r] : 0.0f;
+    }
+    store_hidden16(H2, acc, b2, n0, r, kq);
+    __syncthreads();
+
+    // ---------------- layer 3 + head activation ----------------
+    auto emit = [&](int row, int o, float z) {
+        if (row0 + row >= B) return;
+        const long gi = row0 + row;
+        if (head == 0) {
+            if (out.value) out.value[gi] = det_tanh(z);                       // fully_connected.py:55
+        } else if (head == 1) {
+            float u = 0.5f * (det_tanh(z) + 1.0f);                            // :64
+            u = u * net.max_u;                                                // :93 (:95-96 joined in ube_combine())
+            if (out.ube) out.ube[gi] = u;
+        } else {
+            float* dst = head == 2 ? out.exploit : out.explore;               // :68-81
+            if (dst) dst[gi * net.A + o] = z;
+        }
+    };
+    if (narrow) {
+        if (wave != 0) return;
+        floatx4 a3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ks = 0; ks < kFcH / 4; ++ks) a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(H2[h16_off(4 * ks + kq, r)], w3[ks], a3, 0, 0, 0);
+        if (r < No) {
+            const float bo = b3[r];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) emit(4 * kq + reg, r, a3[reg] + bo);
+        }
+    } else if (No == kFcH) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        mma16_block<false>(acc, H2, ~0ull, W3, kFcH, 0, col, r, kq);
+        float* dst = head == 2 ? out.exploit : out.explore;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float bo = b3[col + t];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = 4 * kq + reg;
+                if (dst && row0 + row < B) dst[static_cast<long>(row0 + row) * net.A + col + t] = acc[t][reg] + bo;
+            }
+        }
+    } else {
+        const int row = tid & 15;
+        for (int o = tid >> 4; o < No; o += 16) {
+            float z = 0.0f;
+#pragma unroll 16
+            for (int k = 0; k < kFcH; ++k) z = __builtin_fmaf(H2[h16_off(k, row)], W3[static_cast<long>(k) * No + o], z);
+            emit(row, o, z + b3[o]);
+        }
+    }
+    if (kstep_counter && tid == 0 && executed) atomicAdd(kstep_counter, executed);
 }
 
 }  // namespace eaz

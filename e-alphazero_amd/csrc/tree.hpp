@@ -10,6 +10,7 @@
 // butterfly order (lane ^ 1, ^ 2, ...) that the CPU oracle mirrors, so selections are bit-reproducible.
 #pragma once
 #include "dmath.hpp"
+#include "envs.hpp"
 
 namespace eaz {
 
@@ -41,6 +42,14 @@ struct TreeDev {
     const uint8_t* next_legal;                       // [B,A] state.legal_action_mask      context.py:137
     float discount;
     int two_player;
+    // fused leaf step (fuse_env == 1 + EAZ_ENV_DEEPSEA): the select phase also applies env.step to the chosen (parent, action),
+    // stores the child state in its embedding slot and hands the network the flat index of the one-hot observation -- no
+    // leaf-gather launch, no materialised observation row (context.py:125-127 for an environment whose step is a few integer ops)
+    int fuse_env;
+    EnvDev fenv;
+    float* fuse_reward;     // = next_reward
+    uint8_t* fuse_term;     // = next_term
+    int32_t* leaf_hot;      // [B] ds_hot_index of the stepped state
     // options
     int rescale, use_mixed, max_considered, max_depth;
     float value_scale, maxvisit_init;
@@ -441,10 +450,19 @@ __global__ void __launch_bounds__(256) tree_step_kernel(TreeDev t, int sim, int 
             node = nxt;
         }
         if (lead) {
+            const int dst = nxt == -1 ? sim + 1 : nxt;
             t.sim_parent[g.b] = node;
             t.sim_action[g.b] = action;
-            t.sim_next[g.b] = nxt == -1 ? sim + 1 : nxt;
+            t.sim_next[g.b] = dst;
             t.path_len[g.b] = depth;
+            if (t.fuse_env == 1 + EAZ_ENV_DEEPSEA) {
+                char* base = t.embeddings + nb * static_cast<long>(sizeof(eaz_deepsea_state));
+                const eaz_deepsea_state ns = ds_step(t.fenv, ds_load(base + static_cast<long>(node) * sizeof(eaz_deepsea_state)), action);
+                ds_store(base + static_cast<long>(dst) * sizeof(eaz_deepsea_state), ns);
+                t.fuse_reward[g.b] = ns.reward;       // rewards[b, current_player], single player (deep_sea.py:100-102)
+                t.fuse_term[g.b] = ns.terminated;
+                t.leaf_hot[g.b] = ds_hot_index(t.fenv, ns);
+            }
         }
     }
 }

@@ -59,6 +59,14 @@ def fold(key, tag: int) -> int:
     return int(out.value)
 
 
+def tune(fc_tile: Optional[int] = None, fused_leaf: Optional[int] = None) -> None:
+    """Kernel-selection knobs (include/eaz.h eaz_tune_set); results are identical for every setting."""
+    if fc_tile is not None:
+        check(_lib.load().eaz_tune_set(0, int(fc_tile)))
+    if fused_leaf is not None:
+        check(_lib.load().eaz_tune_set(1, int(fused_leaf)))
+
+
 class Context:
     """One per device (eaz_ctx)."""
 

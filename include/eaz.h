@@ -242,9 +242,17 @@ enum { EAZ_K_TREE = 0, EAZ_K_GATHER = 1, EAZ_K_HASH = 2, EAZ_K_NET = 3, EAZ_K_MI
 EAZ_API int eaz_profile_enable(eaz_search* s, int on);
 /* synchronises the stream; returns total ms and launch count per class since the last reset */
 EAZ_API int eaz_profile_read(eaz_search* s, double ms[EAZ_K_COUNT], int64_t launches[EAZ_K_COUNT], int reset);
-/* layer-1 k-steps (64 rows x 256 columns x 4 k each) the FC kernel actually executed while profiling was enabled: all-zero
+/* layer-1 k-steps (16 rows x 256 columns x 4 k each) the FC kernel actually executed while profiling was enabled: all-zero
  * observation k-steps are skipped exactly, so executed FLOPs <= dense FLOPs */
 EAZ_API int eaz_profile_net_ksteps(eaz_search* s, uint64_t* executed, int reset);
+
+/* Kernel-selection knobs for A/B measurements and for the parity tests (every setting computes identical results).
+ *   EAZ_TUNE_FC_TILE    0 = automatic (16-row tiles while the launch is fully resident, else 64), 16 or 64 = pinned
+ *   EAZ_TUNE_FUSED_LEAF 1 = DeepSea searches created from now on step the environment inside the tree kernel and feed the
+ *                           network the one-hot index (no leaf-gather launch); 0 = separate leaf-gather + dense forward */
+#define EAZ_TUNE_FC_TILE 0
+#define EAZ_TUNE_FUSED_LEAF 1
+EAZ_API int eaz_tune_set(int knob, int value);
 
 #ifdef __cplusplus
 }

@@ -26,3 +26,26 @@ def eaz():
     import e_alphazero_amd as m
 
     return m
+
+
+# Every GPU test runs once per kernel selection (include/eaz.h eaz_tune_set): all of them must give identical results.
+KERNEL_VARIANTS = {
+    "auto-fused": (0, 1),      # 16-row FC tiles, DeepSea leaf step fused into the tree kernel + one-hot forward
+    "tile16-unfused": (16, 0),  # 16-row FC tiles on dense observation rows, separate leaf-gather launch
+    "tile64-unfused": (64, 0),  # 64-row FC tiles, separate leaf-gather launch
+}
+
+
+def pytest_generate_tests(metafunc):
+    if "kernel_variant" in metafunc.fixturenames:
+        metafunc.parametrize("kernel_variant", list(KERNEL_VARIANTS), indirect=True)
+
+
+@pytest.fixture
+def kernel_variant(request):
+    from e_alphazero_amd import engine
+
+    tile, fused = KERNEL_VARIANTS[request.param]
+    engine.tune(fc_tile=tile, fused_leaf=fused)
+    yield request.param
+    engine.tune(fc_tile=0, fused_leaf=1)

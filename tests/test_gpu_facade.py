@@ -5,7 +5,7 @@ import functools
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("kernel_variant")]
 
 
 @pytest.fixture(scope="module")

@@ -7,7 +7,7 @@ import pytest
 
 from helpers import subleq_device_to_oracle, subleq_oracle_to_device, subleq_setup, deepsea_setup
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("kernel_variant")]
 ATOL = 1e-5
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))

@@ -7,7 +7,7 @@ import pytest
 
 from helpers import deepsea_setup, oracle_deepsea, random_states_deepsea
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("kernel_variant")]
 ATOL = 1e-5
 
 INT_FIELDS = ["node_visits", "parents", "action_from_parent", "children_index", "children_visits"]
