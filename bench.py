@@ -311,9 +311,10 @@ def main():
             continue
         if wl["pmc_tag"] and pmc.get("workload") == wl["pmc_tag"]:
             pmc_file = "profiles/" + cand
-            for kname, field in (("eaz::fc16_forward_kernel", "roofline"), ("eaz::leaf_gather_deepsea_kernel", "roofline_gather")):
+            for kname, field in (("eaz::fc16_forward_kernel<2>", "roofline"), ("eaz::fc_forward_kernel", "roofline"),
+                                 ("eaz::leaf_gather_deepsea_kernel", "roofline_gather")):
                 k = pmc["kernels"].get(kname)
-                if k:
+                if k and field not in traffic:
                     traffic[field] = 1024.0 * (k.get("FETCH_SIZE_KB_per_launch", 0.0) + k.get("WRITE_SIZE_KB_per_launch", 0.0))
             break
     if "roofline" in traffic:

@@ -477,7 +477,20 @@ static int hash_launch(eaz_net* n, int B, const uint8_t* obs, float* novelty, ui
 static int g_fc_tile = [] { const char* e = std::getenv("EAZ_FC_TILE"); return e ? std::atoi(e) : 0; }();
 static int g_fused_leaf = [] { const char* e = std::getenv("EAZ_FUSED_LEAF"); return e ? std::atoi(e) : 1; }();
 
+static int g_tree_block = [] { const char* e = std::getenv("EAZ_TREE_BLOCK"); return e ? std::atoi(e) : 64; }();
+static int g_tree_spread = [] { const char* e = std::getenv("EAZ_TREE_SPREAD"); return e ? std::atoi(e) : 0; }();  // 0 = automatic
+
 extern "C" int eaz_tune_set(int knob, int value) {
+    if (knob == EAZ_TUNE_TREE_BLOCK) {
+        ARG_OK(value == 64 || value == 128 || value == 256);
+        g_tree_block = value;
+        return 0;
+    }
+    if (knob == EAZ_TUNE_TREE_SPREAD) {
+        ARG_OK(value == 0 || value == 1 || value == 2 || value == 4 || value == 8);
+        g_tree_spread = value;
+        return 0;
+    }
     if (knob == EAZ_TUNE_FC_TILE) {
         ARG_OK(value == 0 || value == 16 || value == 64);
         g_fc_tile = value;
@@ -760,7 +773,14 @@ extern "C" int eaz_search_begin(eaz_search* s, const float* d_prior_logits, cons
 
 static int tree_step_launch(eaz_search* s, int sim, int mode, hipStream_t st) {
     ProfScope ps(s, EAZ_K_TREE, st);
-#define CALL_STEP(L, P) tree_step_kernel<L, P><<<tree_grid(s), 256, 0, st>>>(s->tree, sim, mode)
+    // automatic: one-wavefront workgroups, and trees spread until the launch has at least one wavefront per CU
+    int spread = g_tree_spread;
+    if (spread <= 0) {
+        spread = 1;
+        while (spread < 8 && static_cast<long>(s->B) * s->lpt * spread < 256L * 64) spread *= 2;
+    }
+    const int tgrid = cdiv(static_cast<long>(s->B) * s->lpt * spread, g_tree_block);
+#define CALL_STEP(L, P) tree_step_kernel<L, P><<<tgrid, g_tree_block, 0, st>>>(s->tree, sim, mode, spread)
     TREE_DISPATCH(s, CALL_STEP);
 #undef CALL_STEP
     LAUNCH_OK();
@@ -1210,6 +1230,11 @@ extern "C" int eaz_random_play(eaz_env* env, int B, int T, uint64_t key, void* d
 // instrumentation
 // ------------------------------------------------------------------------------------------------------------------
 #ifdef EAZ_FC_STAMPS
+extern "C" __attribute__((visibility("default"))) int eaz_diag_tree_stamps(unsigned long long* h_out /* [1024*8] */) {
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_tree_stamps), sizeof(unsigned long long) * 1024 * 8));
+    return 0;
+}
 extern "C" __attribute__((visibility("default"))) int eaz_diag_fc_stamps(unsigned long long* h_out /* [1024*8] */) {
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_fc_stamps), sizeof(unsigned long long) * 1024 * 8));

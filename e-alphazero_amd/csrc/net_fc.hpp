@@ -688,6 +688,7 @@ __global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn i
     const float *b1 = net.b[head * 3], *b2 = net.b[head * 3 + 1], *b3 = net.b[head * 3 + 2];
     const int No = head < 2 ? 1 : net.A;
 
+    EAZ_STAMP(0);
     floatx4 acc[4];
     unsigned long long executed = 0;
     if constexpr (SRC == 2) {
@@ -736,11 +737,13 @@ __global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn i
         store_hidden16(H1, acc, b1, n0, r, kq);
     }
     __syncthreads();  // H1 complete; region 2 (observation chunk) is dead from here on
+    EAZ_STAMP(1);
 
     // ---------------- layer 2: [16 x 256] x [256 x 256], dense ----------------
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
     mma16_block<false>(acc, H1, ~0ull, W2, kFcH, 0, col, r, kq);
+    EAZ_STAMP(2);
     // layer-3 weights of the narrow heads: B operand of wave 0's MFMA chain (column r of W3, zero beyond No), all 64 loads in
     // flight while H2 is being written
     float w3[kFcH / 4];
@@ -751,6 +754,7 @@ __global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn i
     }
     store_hidden16(H2, acc, b2, n0, r, kq);
     __syncthreads();
+    EAZ_STAMP(3);
 
     // ---------------- layer 3 + head activation ----------------
     auto emit = [&](int row, int o, float z) {
@@ -777,6 +781,7 @@ __global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn i
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) emit(4 * kq + reg, r, a3[reg] + bo);
         }
+        EAZ_STAMP(4);
     } else if (No == kFcH) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};

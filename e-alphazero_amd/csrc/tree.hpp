@@ -287,34 +287,79 @@ __device__ __forceinline__ Group<LPT, APL> make_group(int b, int gl, int A) {
 
 enum : int { kTreeExpand = 1, kTreeSelect = 2 };
 
+#ifdef EAZ_FC_STAMPS
+// Diagnostic build only (make diag): shader-clock stamps of thread 0 of every workgroup at the phase boundaries.
+__device__ unsigned long long g_tree_stamps[1024 * 8];
+#define EAZ_TSTAMP(i, extra)                                                                            \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                   \
+            unsigned long long t_;                                                                     \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+            g_tree_stamps[blockIdx.x * 8 + (i)] = t_;                                                  \
+            if ((i) == 4) g_tree_stamps[blockIdx.x * 8 + 5] = (extra);                                 \
+        }                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    } while (0)
+#else
+#define EAZ_TSTAMP(i, extra)
+#endif
+
 // One launch per simulation: [expand + backward of simulation sim-1] then [select of simulation sim].
+// `spread`: every tree owns LPT * spread consecutive lanes of which only the first LPT store (the others mirror them).  The
+// kernel is bound by memory-level parallelism, not by lanes: one wavefront of 2-lane groups walks 32 trees whose rows lie in
+// ~10 different cache lines per level each, so spreading the trees over more wavefronts / CUs (more miss queues) is what
+// shortens a launch (DESIGN.md "tree_step_kernel").
 template <int LPT, int APL>
-__global__ void __launch_bounds__(256) tree_step_kernel(TreeDev t, int sim, int mode) {
+__global__ void __launch_bounds__(256) tree_step_kernel(TreeDev t, int sim, int mode, int spread) {
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = gtid / LPT;
-    const bool live = b < t.B;  // dead groups keep executing (shuffles need every lane) on tree 0 without storing
-    const Group<LPT, APL> g = make_group<LPT, APL>(live ? b : 0, gtid % LPT, t.A);
+    const int slot = LPT * spread;
+    const int b = gtid / slot, sub = gtid - b * slot;
+    const bool live = b < t.B && sub < LPT;  // mirror / dead groups keep executing (shuffles need every lane) without storing
+    const Group<LPT, APL> g = make_group<LPT, APL>(b < t.B ? b : 0, sub % LPT, t.A);
     const int N = t.N, A = t.A;
     const long nb = static_cast<long>(g.b) * N;
     const float beta = t.beta[g.b];
     const bool lead = live && g.gl == 0;
+    EAZ_TSTAMP(0, 0);
 
     if (mode & kTreeExpand) {
         // ---- expand: mctx update_tree_node + topology (A.3) -------------------------------------------------
+        // Every load that depends on the tree id only is issued before anything is consumed (one memory round trip):
+        // the select result, the recorded path's first 8 levels (root first), the recurrent-fn outputs.
+        constexpr int kChunk = 8;
+        const long pb = static_cast<long>(g.b) * t.S;
         const int parent = t.sim_parent[g.b], action = t.sim_action[g.b], nxt = t.sim_next[g.b];
+        const int D = t.path_len[g.b];
+        int p0n[kChunk], p0a[kChunk];
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) {
+            const int d = j < t.S ? j : t.S - 1;
+            p0n[j] = t.path_node[pb + d];
+            p0a[j] = t.path_action[pb + d];
+        }
         float value, var, reward, rvar, disc, lg[APL];
         if (t.fused_rf) {
             // epistemic_recurrent_fn, src/context.py:132-153, on the outputs of the leaf-gather and network kernels
+            float lraw[APL];
+            uint8_t legal[APL];
 #pragma unroll
-            for (int j = 0; j < APL; ++j) lg[j] = g.ok[j] ? t.net_logits[static_cast<long>(g.b) * A + g.act[j]] : 0.0f;
+            for (int j = 0; j < APL; ++j) {
+                const long o = static_cast<long>(g.b) * A + (g.ok[j] ? g.act[j] : 0);
+                lraw[j] = t.net_logits[o];
+                legal[j] = t.next_legal[o];
+            }
+            const bool term = t.next_term[g.b] != 0;
+            const float rw = t.next_reward[g.b], nval = t.net_value[g.b], nube = t.net_ube[g.b], nnov = t.net_novelty[g.b];
+#pragma unroll
+            for (int j = 0; j < APL; ++j) lg[j] = g.ok[j] ? lraw[j] : 0.0f;
             const float m = g.vmax(lg);                                                        // :135
 #pragma unroll
             for (int j = 0; j < APL; ++j)
-                if (g.ok[j]) lg[j] = t.next_legal[static_cast<long>(g.b) * A + g.act[j]] ? lg[j] - m : kF32Min;  // :137
-            const bool term = t.next_term[g.b] != 0;
-            reward = t.next_reward[g.b];                                                       // :139
-            value = term ? 0.0f : t.net_value[g.b];                                            // :140
-            var = term ? 0.0f : ube_combine(t.net_ube[g.b], t.net_novelty[g.b], t.max_u);      // :141 (+ fully_connected.py:92-96)
+                if (g.ok[j]) lg[j] = legal[j] ? lg[j] - m : kF32Min;                           // :137
+            reward = rw;                                                                       // :139
+            value = term ? 0.0f : nval;                                                        // :140
+            var = term ? 0.0f : ube_combine(nube, nnov, t.max_u);                              // :141 (+ fully_connected.py:92-96)
             disc = 1.0f * t.discount;                                                          // :142
             if (t.two_player) disc = disc * -1.0f;                                             // :143
             if (term) disc = 0.0f;                                                             // :144
@@ -323,7 +368,7 @@ __global__ void __launch_bounds__(256) tree_step_kernel(TreeDev t, int sim, int 
             value = t.rf_value[g.b]; var = t.rf_value_var[g.b];
             reward = t.rf_reward[g.b]; rvar = t.rf_reward_var[g.b]; disc = t.rf_discount[g.b];
 #pragma unroll
-            for (int j = 0; j < APL; ++j) lg[j] = g.ok[j] ? t.rf_logits[static_cast<long>(g.b) * A + g.act[j]] : 0.0f;
+            for (int j = 0; j < APL; ++j) lg[j] = t.rf_logits[static_cast<long>(g.b) * A + (g.ok[j] ? g.act[j] : 0)];
         }
 #pragma unroll
         for (int j = 0; j < APL; ++j)
@@ -340,27 +385,34 @@ __global__ void __launch_bounds__(256) tree_step_kernel(TreeDev t, int sim, int 
             t.parents[nb + nxt] = parent;
             t.action_from_parent[nb + nxt] = action;
         }
+        EAZ_TSTAMP(1, 0);
         // ---- backward (A.6) ------------------------------------------------------------------------------------
         // The select of this simulation recorded its root-to-leaf path, so nothing is pointer-chased here: the
-        // statistics of up to 8 ancestors are fetched with independent loads (one memory round trip per chunk instead of
-        // two per level), then folded leaf-to-root in registers.  Every lane computes, the lead lane stores.
+        // statistics of 8 consecutive levels are fetched with independent, unconditional loads (clamped indices: one
+        // memory round trip per chunk), then folded leaf-to-root in registers.  Every lane computes, the lead lane stores.
+        // Paths of <= 8 levels (the common case) use the entries prefetched above.
         float G = value, U = var;                    // leaf_value / leaf variance
         float child_value = value, child_var = var;  // node_values[idx] after its own update
         if (lead) { t.node_values[nb + nxt] = value; t.node_var[nb + nxt] = var; }
-        const int D = t.path_len[g.b];
-        const long pb = static_cast<long>(g.b) * t.S;
-        constexpr int kChunk = 8;
-        for (int d0 = D - 1; d0 >= 0; d0 -= kChunk) {
+        for (int c = (D - 1) / kChunk; c >= 0; --c) {
             int pn[kChunk], pa[kChunk], cnt_i[kChunk], cvis[kChunk];
             float nv[kChunk], nvar[kChunk], er[kChunk], erv[kChunk], ed[kChunk];
+            if (c > 0) {
 #pragma unroll
-            for (int j = 0; j < kChunk; ++j) {
-                const int d = d0 - j;
-                pn[j] = d >= 0 ? t.path_node[pb + d] : 0;
-                pa[j] = d >= 0 ? t.path_action[pb + d] : 0;
+                for (int j = 0; j < kChunk; ++j) {
+                    const int d = c * kChunk + j < t.S ? c * kChunk + j : t.S - 1;
+                    pn[j] = t.path_node[pb + d];
+                    pa[j] = t.path_action[pb + d];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < kChunk; ++j) { pn[j] = p0n[j]; pa[j] = p0a[j]; }
             }
 #pragma unroll
             for (int j = 0; j < kChunk; ++j) {
+                // levels beyond the path hold stale or unwritten entries: clamp, load, ignore
+                pn[j] = pn[j] < 0 ? 0 : (pn[j] >= N ? N - 1 : pn[j]);
+                pa[j] = pa[j] < 0 ? 0 : (pa[j] >= A ? A - 1 : pa[j]);
                 const long ca = (nb + pn[j]) * A + pa[j];
                 cnt_i[j] = t.node_visits[nb + pn[j]];
                 nv[j] = t.node_values[nb + pn[j]];
@@ -373,32 +425,34 @@ __global__ void __launch_bounds__(256) tree_step_kernel(TreeDev t, int sim, int 
             // all reads of this chunk complete before the lead lane's stores below (same addresses, other lanes)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 #pragma unroll
-            for (int j = 0; j < kChunk; ++j) {
-                const int d = d0 - j;
-                if (d < 0) break;
-                // the edge expanded by this very launch was stored by the lead lane a moment ago: take it from registers
-                const float r = d == D - 1 ? reward : er[j], rv = d == D - 1 ? rvar : erv[j], dd = d == D - 1 ? disc : ed[j];
-                const long ca = (nb + pn[j]) * A + pa[j];
-                const float cnt = static_cast<float>(cnt_i[j]);
-                G = r + dd * G;
-                U = rv + (dd * dd) * U;
-                const float pv = (nv[j] * cnt + G) / (cnt + 1.0f);
-                const float pvar = (nvar[j] * cnt + U) / (cnt + 1.0f);
-                if (lead) {
-                    t.node_values[nb + pn[j]] = pv;
-                    t.node_var[nb + pn[j]] = pvar;
-                    t.node_visits[nb + pn[j]] = cnt_i[j] + 1;
-                    t.children_values[ca] = child_value;
-                    t.children_var[ca] = child_var;
-                    t.children_visits[ca] = cvis[j] + 1;
+            for (int j = kChunk - 1; j >= 0; --j) {
+                const int d = c * kChunk + j;
+                if (d < D) {
+                    // the edge expanded by this very launch was stored by the lead lane a moment ago: take it from registers
+                    const float r = d == D - 1 ? reward : er[j], rv = d == D - 1 ? rvar : erv[j], dd = d == D - 1 ? disc : ed[j];
+                    const long ca = (nb + pn[j]) * A + pa[j];
+                    const float cnt = static_cast<float>(cnt_i[j]);
+                    G = r + dd * G;
+                    U = rv + (dd * dd) * U;
+                    const float pv = (nv[j] * cnt + G) / (cnt + 1.0f);
+                    const float pvar = (nvar[j] * cnt + U) / (cnt + 1.0f);
+                    if (lead) {
+                        t.node_values[nb + pn[j]] = pv;
+                        t.node_var[nb + pn[j]] = pvar;
+                        t.node_visits[nb + pn[j]] = cnt_i[j] + 1;
+                        t.children_values[ca] = child_value;
+                        t.children_var[ca] = child_var;
+                        t.children_visits[ca] = cvis[j] + 1;
+                    }
+                    child_value = pv;
+                    child_var = pvar;
                 }
-                child_value = pv;
-                child_var = pvar;
             }
         }
         // make the lead lane's stores visible to the other lanes of the group before select re-reads the rows
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
+    EAZ_TSTAMP(2, 0);
 
     if (mode & kTreeSelect) {
         // ---- simulate (A.4) ----------------------------------------------------------------------------------
@@ -449,6 +503,7 @@ __global__ void __launch_bounds__(256) tree_step_kernel(TreeDev t, int sim, int 
             if (nxt == -1 || depth >= t.max_depth) break;
             node = nxt;
         }
+        EAZ_TSTAMP(3, 0);
         if (lead) {
             const int dst = nxt == -1 ? sim + 1 : nxt;
             t.sim_parent[g.b] = node;
@@ -464,6 +519,7 @@ __global__ void __launch_bounds__(256) tree_step_kernel(TreeDev t, int sim, int 
                 t.leaf_hot[g.b] = ds_hot_index(t.fenv, ns);
             }
         }
+        EAZ_TSTAMP(4, static_cast<unsigned long long>(depth));
     }
 }
 

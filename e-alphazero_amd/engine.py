@@ -59,12 +59,12 @@ def fold(key, tag: int) -> int:
     return int(out.value)
 
 
-def tune(fc_tile: Optional[int] = None, fused_leaf: Optional[int] = None) -> None:
+def tune(fc_tile: Optional[int] = None, fused_leaf: Optional[int] = None, tree_block: Optional[int] = None,
+         tree_spread: Optional[int] = None) -> None:
     """Kernel-selection knobs (include/eaz.h eaz_tune_set); results are identical for every setting."""
-    if fc_tile is not None:
-        check(_lib.load().eaz_tune_set(0, int(fc_tile)))
-    if fused_leaf is not None:
-        check(_lib.load().eaz_tune_set(1, int(fused_leaf)))
+    for knob, v in ((0, fc_tile), (1, fused_leaf), (2, tree_block), (3, tree_spread)):
+        if v is not None:
+            check(_lib.load().eaz_tune_set(knob, int(v)))
 
 
 class Context:

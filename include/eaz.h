@@ -252,6 +252,11 @@ EAZ_API int eaz_profile_net_ksteps(eaz_search* s, uint64_t* executed, int reset)
  *                           network the one-hot index (no leaf-gather launch); 0 = separate leaf-gather + dense forward */
 #define EAZ_TUNE_FC_TILE 0
 #define EAZ_TUNE_FUSED_LEAF 1
+/*   EAZ_TUNE_TREE_BLOCK  threads per workgroup of tree_step_kernel (64, 128, 256)
+ *   EAZ_TUNE_TREE_SPREAD lanes per tree = lanes-per-tree x spread (1, 2, 4, 8): fewer trees per wavefront, more wavefronts;
+ *                        0 = automatic (spread until the launch has one wavefront per CU) */
+#define EAZ_TUNE_TREE_BLOCK 2
+#define EAZ_TUNE_TREE_SPREAD 3
 EAZ_API int eaz_tune_set(int knob, int value);
 
 #ifdef __cplusplus

@@ -15,7 +15,7 @@ env = engine.EnvHandle.deepsea(G, am, device=0)
 net = engine.FCNet(env.ctx, G * G, 256, 2, params, hstate)
 ref = None
 for name, (tile, fused) in {"auto-fused": (0, 1), "tile16-unfused": (16, 0), "tile64-unfused": (64, 0)}.items():
-    engine.tune(fc_tile=tile, fused_leaf=fused)
+    engine.tune(fc_tile=tile, fused_leaf=fused, tree_block=64, tree_spread=0)
     search = engine.Search(env, net, B, S, discount=0.997)
     states = env.init(B, key=0)
     search.selfplay(states, 2, key=0)
