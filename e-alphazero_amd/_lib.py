@@ -78,6 +78,7 @@ SIGNATURES = {
     "eaz_profile_read": [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), _i],
     "eaz_profile_net_ksteps": [_vp, C.POINTER(C.c_uint64), _i],
     "eaz_tune_set": [_i, _i],
+    "eaz_profile_replay": [_vp, _i, _i, C.POINTER(C.c_double), _vp],
 }
 
 _lib = None

@@ -231,6 +231,14 @@ extern "C" int eaz_env_info(const eaz_env* env, int* kind, int* num_actions, int
 
 // mode: 0 step, 1 auto-reset step, 2 init.  src/dst: plain [B] batches.
 // mover_reward (optional): rewards[b, current_player before the step] of the new states
+// environments per one-wavefront workgroup of subleq_step_kernel: spread until the launch has a workgroup per CU
+static int subleq_envs_per_wg(int B) {
+    int epw = 64;
+    while (epw > 8 && cdiv(B, epw) < 256) epw /= 2;
+    return epw;
+}
+static int subleq_lds_bytes(int W) { return W == 16 ? 0 : 2 * 64 * W; }
+
 static int env_step_launch(eaz_env* env, int B, const void* in, const int32_t* action, Key key, int mode, void* out,
                            void* out_copy, hipStream_t st, const Key* d_key = nullptr, float* mover_reward = nullptr) {
     if (B <= 0) return 0;
@@ -246,8 +254,10 @@ static int env_step_launch(eaz_env* env, int B, const void* in, const int32_t* a
             LAUNCH_OK();
         }
     } else if (env->dev.kind == EAZ_ENV_SUBLEQ) {
-        subleq_step_kernel<<<cdiv(B, 64), 192, 192 * env->dev.W, st>>>(env->dev, src, dst, action, B, mode, key, d_key,
-                                                                         static_cast<char*>(out_copy), mover_reward, nullptr, nullptr);
+        const int epw = subleq_envs_per_wg(B);
+        subleq_step_kernel<<<cdiv(B, epw), 64, subleq_lds_bytes(env->dev.W), st>>>(env->dev, src, dst, action, B, mode, key, d_key,
+                                                                                  static_cast<char*>(out_copy), mover_reward, nullptr, nullptr,
+                                                                                  epw, 256);
         LAUNCH_OK();
     } else {
         connect4_step_kernel<<<cdiv(B, 256), 256, 0, st>>>(env->dev, src, dst, action, B, mode, key, d_key, mover_reward, nullptr, nullptr);
@@ -694,6 +704,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     DALLOC(t.beta, B); DALLOC(t.root_invalid, static_cast<size_t>(B) * A); DALLOC(t.root_gumbel, static_cast<size_t>(B) * A);
     t.state_bytes = env->dev.state_bytes;
     DALLOC(t.embeddings, bn * t.state_bytes);
+    HIP_OK(hipMemset(t.embeddings, 0, bn * t.state_bytes));
     DALLOC(t.sim_parent, B); DALLOC(t.sim_action, B); DALLOC(t.sim_next, B);
     DALLOC(t.path_node, static_cast<size_t>(B) * s->S); DALLOC(t.path_action, static_cast<size_t>(B) * s->S); DALLOC(t.path_len, B);
     // sequential-halving table
@@ -841,9 +852,11 @@ static int recurrent_launch(eaz_search* s, hipStream_t st) {
         } else {
             StateRef src{s->tree.embeddings, s->tree.sim_parent, s->N};
             StateRef dst{s->tree.embeddings, s->tree.sim_next, s->N};
-            subleq_step_kernel<<<cdiv(B, 64), 192, 192 * env->dev.W, st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0},
-                                                                             nullptr, nullptr, s->d_next_reward, s->d_next_term,
-                                                                             s->d_next_legal);
+            // embedding slots 1.. are only ever written here and the allocation starts zeroed: bytes >= W of `memory` stay zero
+            const int epw = subleq_envs_per_wg(B);
+            subleq_step_kernel<<<cdiv(B, epw), 64, subleq_lds_bytes(env->dev.W), st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0},
+                                                                                      nullptr, nullptr, s->d_next_reward, s->d_next_term,
+                                                                                      s->d_next_legal, epw, (env->dev.W + 15) & ~15);
             LAUNCH_OK();
             obs_emit_kernel<<<cdiv(static_cast<long>(B) * 64, 256), 256, 0, st>>>(env->dev, dst, B, s->d_obs);
             LAUNCH_OK();
@@ -1256,6 +1269,38 @@ extern "C" int eaz_profile_net_ksteps(eaz_search* s, uint64_t* executed, int res
     HIP_OK(hipMemcpy(&v, s->net->d_kstep_storage, sizeof v, hipMemcpyDeviceToHost));
     *executed = v;
     if (reset) HIP_OK(hipMemset(s->net->d_kstep_storage, 0, sizeof v));
+    return 0;
+}
+
+extern "C" int eaz_profile_replay(eaz_search* s, int cls, int iters, double* ms_total, void* stream) {
+    ARG_OK(s && ms_total && iters > 0 && (cls == EAZ_K_NET || cls == EAZ_K_GATHER));
+    HIP_OK(hipSetDevice(s->ctx->device));
+    hipStream_t st = S(stream);
+    const bool fused = s->fuse_leaf != 0;
+    if (cls == EAZ_K_GATHER && (fused || s->env->dev.kind != EAZ_ENV_DEEPSEA))
+        return fail("eaz_profile_replay: the standalone leaf gather exists for unfused DeepSea searches only");
+    HeadList hl{3, {0, 1, s->opts.exploration ? 3 : 2, 0}};
+    NetOut o{s->opts.exploration ? nullptr : s->d_exploit, s->opts.exploration ? s->d_explore : nullptr, s->d_v, s->d_u};
+    auto once = [&]() -> int {
+        if (cls == EAZ_K_NET) return fused ? fc_onehot_launch(s->net, s->B, s->d_leaf_hot, s->d_novelty, o, hl, st) : fc_launch(s->net, s->B, s->d_obs, o, hl, st);
+        leaf_gather_deepsea_kernel<<<cdiv(static_cast<long>(s->B) * 64, 256), 256, 0, st>>>(s->env->dev, s->tree, s->d_obs, s->d_next_reward,
+                                                                                          s->d_next_term, s->d_next_legal);
+        LAUNCH_OK();
+        return 0;
+    };
+    for (int i = 0; i < 3; ++i) { int rc = once(); if (rc) return rc; }
+    hipEvent_t a, b;
+    HIP_OK(hipEventCreate(&a));
+    HIP_OK(hipEventCreate(&b));
+    HIP_OK(hipEventRecord(a, st));
+    for (int i = 0; i < iters; ++i) { int rc = once(); if (rc) return rc; }
+    HIP_OK(hipEventRecord(b, st));
+    HIP_OK(hipEventSynchronize(b));
+    float t = 0.0f;
+    HIP_OK(hipEventElapsedTime(&t, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms_total = t;
     return 0;
 }
 

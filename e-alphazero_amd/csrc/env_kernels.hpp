@@ -90,27 +90,34 @@ __global__ void __launch_bounds__(256) leaf_gather_deepsea_kernel(EnvDev e, Tree
 }
 
 // ---- Subleq -----------------------------------------------------------------------------------------------------
-// One thread per (environment, test case): 64 environments x 3 test cases per 192-thread workgroup.  Each thread
-// interprets the program on a private copy of the memory in LDS (W bytes), <= 200 cycles (subleq.py:19,297-299).
-// mode as deepsea_step_kernel.  src/dst may alias (in-place real step) or be tree embedding slots (leaf gather).
-__global__ void __launch_bounds__(192) subleq_step_kernel(EnvDev e, StateRef src, StateRef dst, const int32_t* action, int B,
-                                                          int mode, Key key_arg, const Key* key_ptr, char* out_copy,
-                                                          float* next_reward, uint8_t* next_term, uint8_t* next_legal) {
+// One lane per environment, `envs_per_wg` (<= 64) environments per one-wavefront workgroup: the kernel's duration is the
+// longest interpreter run of a wavefront, so the environments are spread over as many wavefronts / CUs as the launch has room
+// for (eaz_api.hip).  The three test cases (subleq.py:511 vmap) run one after the other and stop at the first failing one:
+// `solved` is the AND of the three results (:525) and only test case 0 feeds the state (`input_after` / `output_after`,
+// :526-533), so a failed case makes the rest irrelevant -- exact, and two thirds of the interpreter work for the typical
+// (unsolved) program.  Each run is <= 200 cycles (subleq.py:19,297-299) with an exact early exit for programs that have entered
+// a cycle (subleq_simulate).  word_size 16 keeps the program memory in one 64-bit register; other sizes use 2*W bytes of LDS per
+// lane.  mode as deepsea_step_kernel.  src/dst may alias (in-place real step) or be tree embedding slots (leaf gather).
+// mem_copy: bytes of `memory` copied from src to dst when they differ (256, or W rounded up to 16 when the bytes above W of
+// every dst slot are known to be zero: tree embeddings).
+__global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src, StateRef dst, const int32_t* action, int B,
+                                                         int mode, Key key_arg, const Key* key_ptr, char* out_copy,
+                                                         float* next_reward, uint8_t* next_term, uint8_t* next_legal,
+                                                         int envs_per_wg, int mem_copy) {
     const Key key = key_ptr ? *key_ptr : key_arg;  // device-resident key: lets a captured hipGraph serve every real step
-    extern __shared__ __attribute__((aligned(16))) uint8_t lmem[];  // 192 * W
-    __shared__ uint8_t s_correct[192];
-    __shared__ uint16_t s_in_after[64][8], s_out_after[64][8];
+    extern __shared__ __attribute__((aligned(16))) uint8_t lmem[];  // word_size != 16: 2 * 64 * W (working memory + snapshot)
     const int W = e.W;
-    const int el = threadIdx.x / 3, c = threadIdx.x - el * 3;
-    const int b = blockIdx.x * 64 + el;
-    const bool live = b < B;
-    const eaz_subleq_state* sp = live ? reinterpret_cast<const eaz_subleq_state*>(state_ptr(src, b, e.state_bytes)) : nullptr;
-    eaz_subleq_state* dp = live ? reinterpret_cast<eaz_subleq_state*>(state_ptr(dst, b, e.state_bytes)) : nullptr;
+    const int el = threadIdx.x;
+    const int b = blockIdx.x * envs_per_wg + el;
+    const bool live = el < envs_per_wg && b < B;
+    if (!live) return;
+    const eaz_subleq_state* sp = reinterpret_cast<const eaz_subleq_state*>(state_ptr(src, b, e.state_bytes));
+    eaz_subleq_state* dp = reinterpret_cast<eaz_subleq_state*>(state_ptr(dst, b, e.state_bytes));
 
     // ---- decide what this environment does (pgx wrapper A.1, auto_reset selfplay.py:66-71, _step subleq.py:671-677)
     bool do_init = false, noop = false, finish = false, run = false;
     int step_count = 0, task = 0, act = 0;
-    if (live) {
+    {
         const bool done = mode != 2 && (sp->terminated | sp->truncated);
         do_init = mode == 2 || (mode == 1 && done);
         if (do_init) {
@@ -131,61 +138,78 @@ __global__ void __launch_bounds__(192) subleq_step_kernel(EnvDev e, StateRef src
             else run = true;
         }
     }
-    uint8_t* mem = lmem + static_cast<long>(threadIdx.x) * W;
-    uint16_t tin[8], tout[8], outv[8];
-    bool correct = false;
+    uint16_t tin[8], tout[8], outv[8], ex_in[8], ex_out[8], in_after[8], out_after[8];
+    bool all_correct = false;
     if (run) {
-        if (do_init) { for (int i = 0; i < W; ++i) mem[i] = 0; }
-        else {
-            for (int i = 0; i < W; i += 4) *reinterpret_cast<uint32_t*>(mem + i) = *reinterpret_cast<const uint32_t*>(sp->memory + i);
-            const int idx = step_count - 1;  // subleq.py:654
-            if (idx >= 0 && idx < W) mem[idx] = static_cast<uint8_t>(act);
+        const int idx = step_count - 1;  // subleq.py:654
+        unsigned long long prog16 = 0;   // word_size 16: the program as sixteen nibbles
+        if (W == 16) {
+            if (!do_init) {
+                const uint4 mv = *reinterpret_cast<const uint4*>(sp->memory);
+                const uint32_t wsrc[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    prog16 |= static_cast<unsigned long long>((wsrc[i >> 2] >> (8 * (i & 3))) & 15u) << (4 * i);
+                if (idx >= 0 && idx < W) prog16 = (prog16 & ~(15ull << (4 * idx))) | (static_cast<unsigned long long>(act & 15) << (4 * idx));
+            }
         }
-        subleq_test_case(task, c, W, tin, tout);
-        uint16_t ex_in[8];
+        all_correct = true;
+        for (int c = 0; c < 3 && all_correct; ++c) {
+            subleq_test_case(task, c, W, tin, tout);
+            if (c == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ex_in[i] = tin[i];
-        correct = subleq_simulate(W, mem, tin, tout, outv);
-        if (c == 0) {
+                for (int i = 0; i < 8; ++i) { ex_in[i] = tin[i]; ex_out[i] = tout[i]; }
+            }
+            bool correct;
+            if (W == 16) {
+                MemReg16 mem{prog16, 0ull};
+                correct = subleq_simulate(W, mem, tin, tout, outv);
+            } else {
+                MemLds mem{lmem + static_cast<long>(el) * W, lmem + static_cast<long>(64 + el) * W, W};
+                if (do_init) { for (int i = 0; i < W; i += 4) *reinterpret_cast<uint32_t*>(mem.m + i) = 0u; }
+                else {
+                    for (int i = 0; i < W; i += 4) *reinterpret_cast<uint32_t*>(mem.m + i) = *reinterpret_cast<const uint32_t*>(sp->memory + i);
+                    if (idx >= 0 && idx < W) mem.m[idx] = static_cast<uint8_t>(act);
+                }
+                correct = subleq_simulate(W, mem, tin, tout, outv);
+            }
+            if (c == 0) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { s_in_after[el][i] = tin[i]; s_out_after[el][i] = outv[i]; }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { tin[i] = ex_in[i]; }  // keep example_input for the state write below
+                for (int i = 0; i < 8; ++i) { in_after[i] = tin[i]; out_after[i] = outv[i]; }
+            }
+            all_correct = correct;
         }
     }
-    s_correct[threadIdx.x] = correct ? 1 : 0;
-    __syncthreads();
-    if (!live || c != 0) return;
 
-    // ---- assemble the new state (thread c == 0 of each environment) -------------------------------------------
+    // ---- assemble the new state --------------------------------------------------------------------------------
     const bool copy_mem = reinterpret_cast<const void*>(sp) != reinterpret_cast<const void*>(dp);
     float reward;
     uint8_t terminated, solved;
     if (run) {
-        solved = s_correct[threadIdx.x] & s_correct[threadIdx.x + 1] & s_correct[threadIdx.x + 2];  // subleq.py:525
+        solved = all_correct ? 1 : 0;                                                                 // subleq.py:525
         reward = solved ? 1.0f : 0.0f;                                                                // :535-537
         terminated = do_init ? 0 : sp->terminated;  // _step never sets terminated on this branch (:661-669)
         if (do_init) {
             for (int i = 0; i < 256; i += 16) *reinterpret_cast<uint4*>(dp->memory + i) = make_uint4(0, 0, 0, 0);
         } else {
             if (copy_mem)
-                for (int i = 0; i < 256; i += 16) *reinterpret_cast<uint4*>(dp->memory + i) = *reinterpret_cast<const uint4*>(sp->memory + i);
+                for (int i = 0; i < mem_copy; i += 16) *reinterpret_cast<uint4*>(dp->memory + i) = *reinterpret_cast<const uint4*>(sp->memory + i);
             const int idx = step_count - 1;
             if (idx >= 0 && idx < W) dp->memory[idx] = static_cast<uint8_t>(act);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            dp->ex_in[i] = tin[i];
-            dp->ex_out[i] = tout[i];
-            dp->ex_in_after[i] = s_in_after[el][i];
-            dp->ex_out_after[i] = s_out_after[el][i];
+            dp->ex_in[i] = ex_in[i];
+            dp->ex_out[i] = ex_out[i];
+            dp->ex_in_after[i] = in_after[i];
+            dp->ex_out_after[i] = out_after[i];
         }
     } else {
         solved = sp->solved;
         reward = 0.0f;                       // terminal no-op (A.1) or subleq.py:673
         terminated = finish ? 1 : sp->terminated;
         if (copy_mem) {
-            for (int i = 0; i < 256; i += 16) *reinterpret_cast<uint4*>(dp->memory + i) = *reinterpret_cast<const uint4*>(sp->memory + i);
+            for (int i = 0; i < mem_copy; i += 16) *reinterpret_cast<uint4*>(dp->memory + i) = *reinterpret_cast<const uint4*>(sp->memory + i);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 dp->ex_in[i] = sp->ex_in[i]; dp->ex_out[i] = sp->ex_out[i];

@@ -145,50 +145,150 @@ __device__ __forceinline__ void subleq_test_case(int task, int c, int W, uint16_
 
 // subleq.py:156-395 simulate.  `mem` is a private, mutable copy of the program (W bytes, LDS or scratch).
 // Returns correct (:394); in/out hold input_after / output_after on return.
-__device__ __forceinline__ bool subleq_simulate(int W, uint8_t* mem, uint16_t in[8], const uint16_t tout[8], uint16_t out[8]) {
-    const int AMAX = W - 4, AIN = W - 3, AOUT = W - 2;  // :162-165
+// Eight uint16 values (test input / expected output / produced output) packed into two 64-bit registers: element i lives in
+// bits 16*(i&3) of (i < 4 ? lo : hi).  Indexing by the run-time output cursor, the whole-array comparison of subleq.py:341 and the
+// one-element shift of :333-338 become a handful of integer ops instead of dynamically indexed register arrays.
+struct Pack8 {
+    unsigned long long lo, hi;
+};
+__device__ __forceinline__ Pack8 pack8(const uint16_t v[8]) {
+    Pack8 p{0ull, 0ull};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) out[i] = static_cast<uint16_t>(W);  // :382
+    for (int i = 0; i < 4; ++i) {
+        p.lo |= static_cast<unsigned long long>(v[i]) << (16 * i);
+        p.hi |= static_cast<unsigned long long>(v[4 + i]) << (16 * i);
+    }
+    return p;
+}
+__device__ __forceinline__ void unpack8(const Pack8& p, uint16_t v[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i] = static_cast<uint16_t>(p.lo >> (16 * i));
+        v[4 + i] = static_cast<uint16_t>(p.hi >> (16 * i));
+    }
+}
+__device__ __forceinline__ bool pack8_eq(const Pack8& a, const Pack8& b) { return a.lo == b.lo && a.hi == b.hi; }
+
+// Program memory of one interpreter run.  MemLds: W bytes in LDS + W bytes for the periodicity snapshot (any word size).
+// MemReg16: word_size 16 -- every word is < 16, so the whole memory is sixteen nibbles of ONE 64-bit register (no LDS round
+// trips on the interpreter's critical path; the reference's experiments use word_size 16, slurm_experiment_submitter.py:196).
+struct MemLds {
+    uint8_t* m;
+    uint8_t* snap;
+    int W;
+    __device__ __forceinline__ int get(int i) const { return m[i]; }
+    static constexpr bool kWordsInRange = false;  // bytes of a hand-made state may exceed W
+    __device__ __forceinline__ void set_if(bool cond, int i, int v) { if (cond) m[i] = static_cast<uint8_t>(v); }
+    __device__ __forceinline__ void snapshot() {
+        for (int i = 0; i < W; i += 4) *reinterpret_cast<uint32_t*>(snap + i) = *reinterpret_cast<const uint32_t*>(m + i);
+    }
+    __device__ __forceinline__ bool same() const {
+        bool eq = true;
+        for (int i = 0; i < W && eq; i += 4) eq = *reinterpret_cast<const uint32_t*>(m + i) == *reinterpret_cast<const uint32_t*>(snap + i);
+        return eq;
+    }
+};
+struct MemReg16 {
+    unsigned long long m, s;
+    __device__ __forceinline__ int get(int i) const { return static_cast<int>((m >> (4 * i)) & 15ull); }
+    static constexpr bool kWordsInRange = true;  // nibbles
+    __device__ __forceinline__ void set_if(bool cond, int i, int v) {
+        const unsigned long long n = (m & ~(15ull << (4 * i))) | (static_cast<unsigned long long>(v) << (4 * i));
+        m = cond ? n : m;
+    }
+    __device__ __forceinline__ void snapshot() { s = m; }
+    __device__ __forceinline__ bool same() const { return s == m; }
+};
+
+// subleq.py:297-398 `simulate`.
+//
+// Exact early exit for non-terminating programs: the machine state (memory, cursor, remaining input, produced output, output
+// cursor) is snapshotted at cycles 1, 2, 4, 8, ... (Brent); when the state equals the snapshot, the run is periodic with period
+// p = cycles - snapshot cycle and nothing but the cycle counter changes from here on, so whole periods are skipped
+// (cycles += floor((200 - cycles) / p) * p) and the last (200 - cycles) mod p cycles are interpreted normally.  The result is the
+// state the reference reaches after exactly MAX_CYCLE_COUNT = 200 cycles (:19).
+template <class Mem>
+__device__ __forceinline__ bool subleq_simulate(int W, Mem& mem, uint16_t in_arr[8], const uint16_t tout_arr[8], uint16_t out_arr[8]) {
+    const int AMAX = W - 4, AIN = W - 3, AOUT = W - 2;  // :162-165
+    const unsigned long long w4 = 0x0001000100010001ull * static_cast<unsigned long long>(W);
+    Pack8 in = pack8(in_arr);
+    const Pack8 tout = pack8(tout_arr);
+    Pack8 out{w4, w4};  // :382
     int out_cursor = 0, cur = 0, cycles = 0;
     bool halt = false, error = false;
+    // Brent snapshot
+    Pack8 s_in = in, s_out = out;
+    int s_cur = -1, s_oc = 0, s_cycle = 0, next_snap = 1;
+    bool skipped = false;
+    // The cycle body is written with selects instead of branches: lanes run different programs, and every divergent branch
+    // costs the wavefront an exec-mask save/restore whether or not a lane takes it.
     while (!error && !halt && cycles < 200) {  // :297-299, MAX_CYCLE_COUNT :19
         cycles += 1;
-        if (cur + 2 >= W) { error = true; continue; }  // :364-370
-        const int a = mem[cur], b = mem[cur + 1], c = mem[cur + 2];
+        const bool oob = cur + 2 >= W;  // :364-370: error, nothing else changes
+        const bool ok = !oob;
+        const int cc = oob ? 0 : cur;
+        const int a = mem.get(cc), b = mem.get(cc + 1), c = mem.get(cc + 2);
         // read_memory :187-232 (both reads see the pre-advance input state)
-        int ra = 0, rb = 0;
-        bool acc = false, err = false;
-        if (a <= AMAX) ra = mem[a];
-        else if (a == AIN) { if (in[0] >= W) err = true; else { ra = in[0]; acc = true; } }
-        if (b <= AMAX) rb = mem[b];
-        else if (b == AIN) { if (in[0] >= W) err = true; else { rb = in[0]; acc = true; } }
-        const int value = pymod(ra - rb, W);  // :322
+        const int in0 = static_cast<int>(in.lo & 0xFFFFu);
+        const bool in_ok = in0 < W;
+        const bool a_mem = a <= AMAX, b_mem = b <= AMAX, uses_in = (a == AIN) || (b == AIN);
+        const int ma = mem.get(a_mem ? a : 0), mb = mem.get(b_mem ? b : 0);
+        const int ra = a_mem ? ma : ((a == AIN && in_ok) ? in0 : 0);
+        const int rb = b_mem ? mb : ((b == AIN && in_ok) ? in0 : 0);
+        const bool acc = ok && uses_in && in_ok;
+        // :322 (ra - rb) mod W.  Words are < W, so one conditional add is the whole modulo; the general form (an integer division)
+        // only runs for out-of-range bytes of a hand-made state
+        int value = ra - rb;
+        value += value < 0 ? W : 0;
+        if constexpr (!Mem::kWordsInRange) {
+            if (value < 0 || value >= W) value = pymod(ra - rb, W);
+        }
         // write_memory :243-295
-        bool modified = false;
-        if (a <= AMAX) mem[a] = static_cast<uint8_t>(value);
-        else if (a == AOUT) {
-            if (out_cursor >= 8) err = true;
-            else { out[out_cursor] = static_cast<uint16_t>(value); out_cursor += 1; modified = true; }
+        const bool wr_out = a == AOUT, out_full = out_cursor >= 8;
+        const bool err = (uses_in && !in_ok) || (wr_out && out_full);
+        const bool modified = ok && wr_out && !out_full;
+        mem.set_if(ok && a_mem, a, value);
+        {
+            const int sh = 16 * (out_cursor & 3);
+            const unsigned long long clr = ~(0xFFFFull << sh), ins = static_cast<unsigned long long>(value) << sh;
+            const unsigned long long lo2 = (out.lo & clr) | ins, hi2 = (out.hi & clr) | ins;
+            out.lo = (modified && out_cursor < 4) ? lo2 : out.lo;
+            out.hi = (modified && out_cursor >= 4) ? hi2 : out.hi;
+            out_cursor += modified ? 1 : 0;
         }
         const bool jump = (value == 0) || (2 * value >= W);  // :329
-        cur = jump ? c : cur + 3;                            // :330
-        if (acc) {                                           // :333-338
-#pragma unroll
-            for (int i = 0; i < 7; ++i) in[i] = in[i + 1];
-            in[7] = static_cast<uint16_t>(W);
+        cur = oob ? cur : (jump ? c : cur + 3);              // :330
+        {                                                    // :333-338 roll by one, pad with W
+            const unsigned long long lo2 = (in.lo >> 16) | (in.hi << 48), hi2 = (in.hi >> 16) | (static_cast<unsigned long long>(W) << 48);
+            in.lo = acc ? lo2 : in.lo;
+            in.hi = acc ? hi2 : in.hi;
         }
-        bool all_eq = true;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) all_eq = all_eq && (out[i] == tout[i]);
+        const bool all_eq = pack8_eq(out, tout);
         // :340-345 `(execute_jump & c > ADDRESS_MAX)` == `(execute_jump & c) > ADDRESS_MAX` (Python precedence): {0,1} > W-4
-        halt = (((jump ? 1 : 0) & c) > AMAX) || all_eq;
+        halt = ok && ((((jump ? 1 : 0) & c) > AMAX) || all_eq);
         const int oc = (out_cursor - 1) & 7;  // -1 wraps to the last element (jnp negative index); masked by `modified`
-        error = err || (modified && (out[oc] != tout[oc]));  // :346-350
+        const unsigned long long diff = oc < 4 ? (out.lo ^ tout.lo) : (out.hi ^ tout.hi);
+        error = oob || err || (modified && ((diff >> (16 * (oc & 3))) & 0xFFFFull) != 0);  // :346-350
+        // ---- periodicity (exact, see above) ----
+        const bool watching = !skipped && !error && !halt;
+        bool hit = (static_cast<int>(watching) & static_cast<int>(cur == s_cur) & static_cast<int>(out_cursor == s_oc) &
+                    static_cast<int>(pack8_eq(in, s_in)) & static_cast<int>(pack8_eq(out, s_out))) != 0;
+        if constexpr (Mem::kWordsInRange) hit = (static_cast<int>(hit) & static_cast<int>(mem.same())) != 0;
+        else hit = hit && mem.same();
+        if (hit) {
+            const int p = cycles - s_cycle;
+            cycles += ((200 - cycles) / p) * p;
+            skipped = true;
+        }
+        if (watching && !hit && cycles == next_snap) {
+            mem.snapshot();
+            s_cur = cur; s_oc = out_cursor; s_in = in; s_out = out; s_cycle = cycles;
+            next_snap *= 2;
+        }
     }
-    bool all_eq = true;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) all_eq = all_eq && (out[i] == tout[i]);
-    return !error && all_eq;
+    unpack8(in, in_arr);
+    unpack8(out, out_arr);
+    return !error && pack8_eq(out, tout);
 }
 
 // subleq.py:26-56 / :63-98 encoders: byte (row-word v, column j) of the observation

@@ -384,6 +384,12 @@ class Search:
     def profile(self, on: bool):
         check(_lib.load().eaz_profile_enable(self.h, int(on)))
 
+    def profile_replay(self, kernel_class: str, iters: int = 200) -> float:
+        """Average duration (ms) of the last simulation's network forward / leaf gather, launched `iters` times back to back."""
+        ms = C.c_double()
+        check(_lib.load().eaz_profile_replay(self.h, _lib.K_NAMES.index(kernel_class), iters, C.byref(ms), _stream()))
+        return ms.value / iters
+
     def profile_read(self, reset: bool = True) -> dict:
         ms = (C.c_double * 5)()
         n = (C.c_int64 * 5)()

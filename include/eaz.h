@@ -246,6 +246,11 @@ EAZ_API int eaz_profile_read(eaz_search* s, double ms[EAZ_K_COUNT], int64_t laun
  * observation k-steps are skipped exactly, so executed FLOPs <= dense FLOPs */
 EAZ_API int eaz_profile_net_ksteps(eaz_search* s, uint64_t* executed, int reset);
 
+/* Kernel duration without the launch gap an event pair around a single launch includes: the network forward (EAZ_K_NET) or
+ * the standalone DeepSea leaf gather (EAZ_K_GATHER, unfused searches) of the LAST simulation is launched `iters` times back to
+ * back on `stream` inside ONE event pair; *ms_total / iters is what rocprofv3 reports as the kernel's average duration. */
+EAZ_API int eaz_profile_replay(eaz_search* s, int kernel_class, int iters, double* ms_total, void* stream);
+
 /* Kernel-selection knobs for A/B measurements and for the parity tests (every setting computes identical results).
  *   EAZ_TUNE_FC_TILE    0 = automatic (16-row tiles while the launch is fully resident, else 64), 16 or 64 = pinned
  *   EAZ_TUNE_FUSED_LEAF 1 = DeepSea searches created from now on step the environment inside the tree kernel and feed the
