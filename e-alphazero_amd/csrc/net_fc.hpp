@@ -49,6 +49,13 @@ __global__ void __launch_bounds__(256) ube_combine_kernel(float* ube, const floa
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// __builtin_amdgcn_sched_barrier mask used around the MFMA groups of the ResNet kernel: VALU (0x2), SALU (0x4) and LDS (0x80)
+// instructions may move across, vector-memory loads and MFMAs may not -- the weight prefetch stays in front of the MFMAs it
+// overlaps with, while address arithmetic and operand reads still fill the MFMA shadow.  (Measured on the FC kernels the same
+// pinning LOSES: with 12 waves per CU the compiler's just-in-time loads are hidden by the other waves, and eight loads issued at
+// once by every wave only add queueing -- fc16 26.8 -> 32.4 us -- so the FC loops are left to the scheduler.)
+constexpr int kSchedPin = 0x2 | 0x4 | 0x80;
+
 constexpr int kFcM = 64;      // batch rows per workgroup
 constexpr int kFcKC = 1024;   // layer-1 inputs staged per barrier (uint8 tile [KC][68]); = 4 mask blocks of 256
 constexpr int kFcLD = 68;     // leading dimension of the K-major LDS tiles: 64 rows + 4 pad (floats for H1/H2, bytes for the obs tile)
