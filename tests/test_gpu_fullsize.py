@@ -1,0 +1,148 @@
+"""GPU parity at BASELINE.json's FULL sizes (C2 DeepSea-32 B=4096 S=64; C3 Subleq-16 B=4096 S=64; C4 connect_four B=8192 S=200).
+
+The oracle cannot run a whole full-size batch in seconds, so these tests use what the domain offers:
+  * trees / environments are independent: the full-batch device result, restricted to a random SUBSET of environments, must equal
+    the oracle run on that subset alone (same states, same explicit Gumbel noise);
+  * size-independent invariants of the search tree (visit-count bookkeeping, topology) on every one of the B trees;
+  * determinism (same key -> bit-identical output; captured hipGraph == plain launches).
+Bar: integers bit-exact, floats within 1e-5 (north-star tolerance).
+"""
+import numpy as np
+import pytest
+
+from helpers import deepsea_setup, oracle_deepsea, subleq_device_to_oracle, subleq_setup
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-5
+FLOATS = ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction", "q_values_epistemic_variance")
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+
+    assert t.cuda.is_available(), "GPU tests need a ROCm device"
+    return t
+
+
+def _check_subset(out, ref, idx, state_cmp=None):
+    assert np.array_equal(out["action"][:, idx].cpu().numpy(), ref["action"])
+    dev_states = out["state"][:, idx].cpu().numpy()
+    assert np.array_equal(dev_states if state_cmp is None else state_cmp(dev_states), ref["state"])
+    for k in FLOATS:
+        np.testing.assert_allclose(out[k][:, idx].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
+
+
+def test_c2_selfplay_subset_matches_oracle_and_is_deterministic(oracle, eaz, torch):
+    from e_alphazero_amd import engine
+
+    G, B, S, T, NSUB = 32, 4096, 64, 34, 24  # T > 31: every episode terminates and auto-resets inside the window
+    am, params, state = deepsea_setup(eaz, G, seed=0, fill=0.5)
+    env = engine.EnvHandle.deepsea(G, am, device=0)
+    net = engine.FCNet(env.ctx, G * G, 256, 2, params, state)
+    oenv, onet = oracle_deepsea(oracle, eaz, G, am, params, state)
+    search = engine.Search(env, net, B, S, discount=0.997)
+    gum = oracle.gumbel((5, 6), T * B * 2).reshape(T, B, 2)
+    g_dev = torch.from_numpy(gum).cuda()
+    st = env.init(B, key=0)
+    out = search.selfplay(st, T, key=17, gumbel=g_dev)
+    st2 = env.init(B, key=0)
+    out2 = search.selfplay(st2, T, key=17, gumbel=g_dev)
+    st3 = env.init(B, key=0)
+    out3 = search.selfplay(st3, T, key=17, gumbel=g_dev, use_graph=False)
+    for k in out:
+        assert torch.equal(out[k], out2[k]) and torch.equal(out[k], out3[k]), k
+    idx = np.sort(np.random.default_rng(1).choice(B, NSUB, replace=False))
+    ost = oenv.init(NSUB)
+    ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(17, 0), gumbel=np.ascontiguousarray(gum[:, idx]))
+    _check_subset(out, ref, idx)
+    assert np.array_equal(st[idx].cpu().numpy(), ost)
+    # the window contains whole episodes: rewards only at the last row, and some environment reached the treasure or none did --
+    # either way every stored state is a legal DeepSea state
+    sc = out["state"].cpu().numpy()[..., 0:4].copy().view(np.int32)[..., 0]
+    assert sc.min() >= 0 and sc.max() <= G - 1
+
+
+def test_c2_tree_invariants_on_every_tree(oracle, eaz, torch):
+    from e_alphazero_amd import engine
+
+    G, B, S = 32, 4096, 64
+    am, params, state = deepsea_setup(eaz, G, seed=0, fill=0.5)
+    env = engine.EnvHandle.deepsea(G, am, device=0)
+    net = engine.FCNet(env.ctx, G * G, 256, 2, params, state)
+    search = engine.Search(env, net, B, S, discount=0.997)
+    st = env.init(B, key=0)
+    for t in range(5):  # a few real steps in, so the roots are spread over the grid
+        st = env.step(st, torch.randint(0, 2, (B,), dtype=torch.int32, device="cuda"))
+    ex, xp, v, u, _ = net.forward(env.observe(st))
+    g = torch.from_numpy(oracle.gumbel((8, 9), B * 2).reshape(B, 2)).cuda()
+    search.begin(ex, v, u, st, torch.zeros(B, device="cuda"), None, g)
+    search.run()
+    act, aw = search.finish()
+    d = search.dump()
+    N = S + 1
+    nv, ci, cv, par, afp = d["node_visits"], d["children_index"], d["children_visits"], d["parents"], d["action_from_parent"]
+    assert (nv[:, 0] == S + 1).all() and (cv[:, 0].sum(1) == S).all()          # root: initial visit + one per simulation
+    assert (nv[:, 1:] >= 1).all()                                              # max_depth = S: every simulation expands a new node
+    assert (nv == 1 + cv.sum(2)).all()                                         # visits of a node = its own expansion + its children's
+    b = np.arange(B)[:, None].repeat(N - 1, 1)
+    n = np.arange(1, N)[None, :].repeat(B, 0)
+    assert (par[:, 1:] < n).all() and (par[:, 1:] >= 0).all()                  # nodes are created in simulation order
+    assert (ci[b, par[:, 1:], afp[:, 1:]] == n).all()                          # parent/child links agree
+    assert ((ci == -1) == (cv == 0)).all()                                     # unvisited <=> no child
+    assert (nv[b, par[:, 1:]] > nv[:, 1:]).all()                               # a parent is visited more often than its child
+    s = search.summary()
+    assert torch.equal(s["visit_counts"].sum(1), torch.full((B,), float(S), device="cuda"))
+    np.testing.assert_allclose(aw.sum(1).cpu().numpy(), 1.0, atol=1e-5)
+    assert ((act >= 0) & (act < 2)).all()
+    # the chosen action is one of the most visited ones (Gumbel sequential halving ends on the max-visit set)
+    vc = s["visit_counts"].cpu().numpy()
+    assert (vc[np.arange(B), act.cpu().numpy()] == vc.max(1)).all()
+
+
+def test_c3_selfplay_subset_matches_oracle(oracle, eaz, torch):
+    from e_alphazero_amd import engine
+
+    W, B, S, T, NSUB = 16, 4096, 64, 4, 16
+    dims, params, state = subleq_setup(eaz, W, seed=0, fill=0.5)
+    env = engine.EnvHandle.subleq(W, (1,), True, device=0)
+    net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
+    oenv = oracle.OracleEnv.subleq(W, (1,), True)
+    onet = oracle.OracleNet(dims["in_dim"], 256, W, eaz.params.fc_weight_list(params), hash_off=dims["hash_off"],
+                            hash_len=dims["hash_len"], bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+    search = engine.Search(env, net, B, S, discount=0.97)
+    gum = oracle.gumbel((3, 4), T * B * W).reshape(T, B, W)
+    st = env.init(B, key=0)
+    out = search.selfplay(st, T, key=23, gumbel=torch.from_numpy(gum).cuda())
+    idx = np.sort(np.random.default_rng(2).choice(B, NSUB, replace=False))
+    ost = oenv.init(NSUB)  # one task: init does not depend on the key
+    ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(23, 0), gumbel=np.ascontiguousarray(gum[:, idx]), discount=0.97)
+    _check_subset(out, ref, idx, state_cmp=lambda s: subleq_device_to_oracle(s, W))
+    assert np.array_equal(subleq_device_to_oracle(st[idx].cpu().numpy(), W), ost)
+
+
+def test_c4_selfplay_subset_matches_oracle(oracle, eaz, torch):
+    from e_alphazero_amd import engine
+
+    B, S, T, NSUB, nb = 8192, 200, 1, 6, 5
+    params, state = eaz.params.init_resnet_params(6, 7, 2, 7, 64, nb, seed=0)
+    bs = eaz.params.init_hash_state(fill=0.3, seed=0)[eaz.params.HASH_MODULE]["binary_set"]
+    state[eaz.params.RESNET_HASH_MODULE] = {"binary_set": bs}
+    env = engine.EnvHandle.connect4(device=0)
+    net = engine.ResNet(env.ctx, 6, 7, 2, 7, params, state, num_blocks=nb)
+    oenv = oracle.OracleEnv.connect4()
+    onet = oracle.OracleNet.resnet(6, 7, 2, 7, eaz.params.resnet_array_list(params, state, nb), 64, nb, bitset=bs)
+    search = engine.Search(env, net, B, S, discount=0.997, two_players_game=True)
+    st = env.init(B, key=5)
+    rng = np.random.default_rng(3)
+    for t in range(6):  # mid-game positions
+        st = env.step(st, torch.from_numpy(rng.integers(0, 7, B).astype(np.int32)).cuda())
+    idx = np.sort(rng.choice(B, NSUB, replace=False))
+    ost = st[idx].cpu().numpy().copy()  # identical 80-byte layout on both sides
+    gum = oracle.gumbel((7, 8), T * B * 7).reshape(T, B, 7)
+    out = search.selfplay(st, T, key=29, gumbel=torch.from_numpy(gum).cuda())
+    ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(29, 0), gumbel=np.ascontiguousarray(gum[:, idx]), two_player=True)
+    _check_subset(out, ref, idx)
+    s = search.summary()
+    live = ~torch.from_numpy(oenv.fields(ref["state"][0])["terminated"]).bool()
+    assert torch.equal(s["visit_counts"].sum(1)[idx][live], torch.full((int(live.sum()),), float(S), device="cuda"))
