@@ -115,6 +115,7 @@ struct eaz_search {
     uint8_t *d_term, *d_term2;
     int* d_alive;
     Key* d_step_keys;  // [4]: gumbel, env, sample-visits, sample-improved keys of the current real step
+    struct StepOut* d_step_out;  // destination slots of the current real step's SelfplayOutput (read by the captured graph)
     hipGraphExec_t step_graph;
     const void* graph_states;  // the captured graph is valid for this d_states pointer / these flags
     int graph_flags;
@@ -731,6 +732,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     DALLOC(s->d_root_v, B); DALLOC(s->d_root_u, B); DALLOC(s->d_sum_value, B); DALLOC(s->d_sum_std, B);
     DALLOC(s->d_sum_qvar, static_cast<size_t>(B) * A); DALLOC(s->d_gumbel_stage, static_cast<size_t>(B) * A);
     DALLOC(s->d_step_keys, 4);
+    DALLOC(s->d_step_out, 1);
     DALLOC(s->d_sum_q, static_cast<size_t>(B) * A); DALLOC(s->d_sum_vc, static_cast<size_t>(B) * A); DALLOC(s->d_next_v, B);
     DALLOC(s->d_term, B); DALLOC(s->d_term2, B); DALLOC(s->d_reward_tmp, B); DALLOC(s->d_alive, 1);
     t.next_reward = s->d_next_reward; t.next_term = s->d_next_term; t.next_legal = s->d_next_legal;
@@ -984,8 +986,38 @@ extern "C" int eaz_search_tree_view(eaz_search* s, int id, void** d_ptr, int64_t
 // ------------------------------------------------------------------------------------------------------------------
 // self-play driver (src/selfplay.py:78-149)
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void set_step_keys_kernel(Key* keys, Key k0, Key k1, Key k2, Key k3) {
+// destination slots of SelfplayOutput[t] (selfplay.py:136-143); any pointer may be null
+struct StepOut {
+    float *value_pred, *ube_pred, *root_value, *root_std, *qvar;
+    int32_t* action;
+    char* states;
+};
+
+__global__ void set_step_keys_kernel(Key* keys, Key k0, Key k1, Key k2, Key k3, StepOut* slot, StepOut o) {
     keys[0] = k0; keys[1] = k1; keys[2] = k2; keys[3] = k3;
+    if (slot) *slot = o;
+}
+
+// SelfplayOutput[t]: one launch (the last node of the captured step) instead of seven device-to-device copies per real step;
+// the destinations are read from the device-resident slot that set_step_keys_kernel refreshed for this step
+__global__ void __launch_bounds__(256) selfplay_emit_kernel(int B, int A, int state_bytes, const StepOut* slot, const float* root_v,
+                                                            const float* root_u, const float* sum_value, const float* sum_std,
+                                                            const float* sum_qvar, const int32_t* action, const char* states) {
+    const StepOut o = *slot;
+    const long stride = static_cast<long>(gridDim.x) * blockDim.x, i0 = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    for (long i = i0; i < B; i += stride) {
+        if (o.value_pred) o.value_pred[i] = root_v[i];
+        if (o.ube_pred) o.ube_pred[i] = root_u[i];
+        if (o.root_value) o.root_value[i] = sum_value[i];
+        if (o.root_std) o.root_std[i] = sum_std[i];
+        if (o.action) o.action[i] = action[i];
+    }
+    if (o.qvar)
+        for (long i = i0; i < static_cast<long>(B) * A; i += stride) o.qvar[i] = sum_qvar[i];
+    if (o.states) {
+        const long n16 = static_cast<long>(B) * state_bytes / 16;  // every state blob is a multiple of 16 bytes (include/eaz.h)
+        for (long i = i0; i < n16; i += stride) reinterpret_cast<uint4*>(o.states)[i] = reinterpret_cast<const uint4*>(states)[i];
+    }
 }
 
 enum : int { kFlagUniform = 1, kFlagSampleVisits = 2, kFlagSampleImproved = 4, kFlagExplicitGumbel = 8 };
@@ -1040,6 +1072,11 @@ static int selfplay_step_body(eaz_search* s, const eaz_selfplay_cfg* cfg, int fl
         // real env step with auto-reset (selfplay.py:135), in place
         rc = env_step_launch(env, B, d_states, s->d_action, Key{0, 0}, 1, d_states, nullptr, st, s->d_step_keys + 1);
         if (rc) return rc;
+        const long work = static_cast<long>(B) * (env->dev.state_bytes / 16 > A ? env->dev.state_bytes / 16 : A);
+        selfplay_emit_kernel<<<cdiv(work, 256) < 2048 ? cdiv(work, 256) : 2048, 256, 0, st>>>(
+            B, A, env->dev.state_bytes, s->d_step_out, s->d_root_v, s->d_root_u, s->d_sum_value, s->d_sum_std, s->d_sum_qvar, s->d_action,
+            static_cast<const char*>(d_states));
+        LAUNCH_OK();
     }
     return 0;
 }
@@ -1087,8 +1124,12 @@ extern "C" int eaz_selfplay_run(eaz_search* s, const eaz_selfplay_cfg* cfg, uint
     for (int step = 0; step < cfg->selfplay_steps; ++step) {
         const Key kt = fold(k, kTagStep + static_cast<uint32_t>(step));  // key_seq[t], selfplay.py:147
         const long tb = static_cast<long>(step) * B;
+        const StepOut slot{d_out_value_pred ? d_out_value_pred + tb : nullptr, d_out_ube_pred ? d_out_ube_pred + tb : nullptr,
+                           d_out_root_value ? d_out_root_value + tb : nullptr, d_out_root_std ? d_out_root_std + tb : nullptr,
+                           d_out_qvar ? d_out_qvar + tb * A : nullptr, d_out_action ? d_out_action + tb : nullptr,
+                           d_out_states ? static_cast<char*>(d_out_states) + tb * s->env->dev.state_bytes : nullptr};
         set_step_keys_kernel<<<1, 1, 0, st>>>(s->d_step_keys, fold(kt, kTagGumbel), fold(kt, kTagEnv), fold(kt, kTagSampleVisits),
-                                             fold(kt, kTagSampleImproved));
+                                             fold(kt, kTagSampleImproved), s->d_step_out, slot);
         LAUNCH_OK();
         if (d_gumbel) HIP_OK(hipMemcpyAsync(s->d_gumbel_stage, d_gumbel + tb * A, fb * A, hipMemcpyDeviceToDevice, st));
         int rc;
@@ -1100,15 +1141,7 @@ extern "C" int eaz_selfplay_run(eaz_search* s, const eaz_selfplay_cfg* cfg, uint
             rc = selfplay_step_body(s, cfg, flags, d_states, st);
             if (rc) return rc;
         }
-        // SelfplayOutput[t] (selfplay.py:136-143)
-        if (d_out_value_pred) HIP_OK(hipMemcpyAsync(d_out_value_pred + tb, s->d_root_v, fb, hipMemcpyDeviceToDevice, st));
-        if (d_out_ube_pred) HIP_OK(hipMemcpyAsync(d_out_ube_pred + tb, s->d_root_u, fb, hipMemcpyDeviceToDevice, st));
-        if (d_out_root_value) HIP_OK(hipMemcpyAsync(d_out_root_value + tb, s->d_sum_value, fb, hipMemcpyDeviceToDevice, st));
-        if (d_out_root_std) HIP_OK(hipMemcpyAsync(d_out_root_std + tb, s->d_sum_std, fb, hipMemcpyDeviceToDevice, st));
-        if (d_out_qvar) HIP_OK(hipMemcpyAsync(d_out_qvar + tb * A, s->d_sum_qvar, fb * A, hipMemcpyDeviceToDevice, st));
-        if (d_out_action) HIP_OK(hipMemcpyAsync(d_out_action + tb, s->d_action, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, st));
-        if (d_out_states) HIP_OK(hipMemcpyAsync(static_cast<char*>(d_out_states) + tb * s->env->dev.state_bytes, d_states, sb,
-                                                hipMemcpyDeviceToDevice, st));
+        // SelfplayOutput[t] (selfplay.py:136-143) was written by selfplay_emit_kernel, the last launch of the step body
     }
     if (use_graph) {
         HIP_OK(hipEventRecord(s->ev_out, st));
@@ -1129,7 +1162,7 @@ static int driver_root(eaz_search* s, const void* d_states, float beta, const fl
     env_fields_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->env->dev, static_cast<const char*>(d_states), B, s->d_term, nullptr, nullptr, nullptr,
                                                    s->d_legal, nullptr);
     LAUNCH_OK();
-    set_step_keys_kernel<<<1, 1, 0, st>>>(s->d_step_keys, gkey, Key{0, 0}, Key{0, 0}, Key{0, 0});
+    set_step_keys_kernel<<<1, 1, 0, st>>>(s->d_step_keys, gkey, Key{0, 0}, Key{0, 0}, Key{0, 0}, nullptr, StepOut{});
     LAUNCH_OK();
     root_prep_kernel<<<cdiv(static_cast<long>(B) * A, 256), 256, 0, st>>>(B, A, s->d_root_logits, 0, beta, s->d_legal, d_gumbel, s->d_step_keys,
                                                                           s->opts.gumbel_scale, s->d_root_logits, s->d_root_beta,

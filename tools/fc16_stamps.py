@@ -47,7 +47,8 @@ print(f"   start offset of workgroups (cycles after first): median {np.median(st
 lib.eaz_diag_tree_stamps.argtypes = [C.c_void_p]
 buf = np.zeros(1024 * 8, np.uint64)
 lib.eaz_diag_tree_stamps(buf.ctypes.data)
-ts = buf.reshape(1024, 8)[: (B * 2 + 255) // 256].astype(np.int64)
+ts = buf.reshape(1024, 8)[:256].astype(np.int64)
+ts = ts[ts[:, 4] > ts[:, 0]]
 d = np.diff(ts[:, :5], axis=1)
 print(f"tree_step_kernel<2,1>, simulation 39 (thread 0 of each of {len(ts)} workgroups):")
 for i, n in enumerate(["expand (loads, recurrent fn, stores)", "backward (path fold) + fence", "select (all levels)", "fused env step + stores"]):
