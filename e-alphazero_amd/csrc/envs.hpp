@@ -216,63 +216,78 @@ __device__ __forceinline__ bool subleq_simulate(int W, Mem& mem, uint16_t in_arr
     Pack8 out{w4, w4};  // :382
     int out_cursor = 0, cur = 0, cycles = 0;
     bool halt = false, error = false;
-    // Brent snapshot
-    Pack8 s_in = in, s_out = out;
-    int s_cur = -1, s_oc = 0, s_cycle = 0, next_snap = 1;
+    // Brent snapshot.  `io_epoch` counts the cycles that consumed an input or produced an output: the input only ever shifts
+    // forward and the output cursor only grows, so (in, out, out_cursor) equal their snapshot exactly when the epoch does.
+    int io_epoch = 0, s_epoch = 0;
+    int s_cur = -1, s_cycle = 0, next_snap = 1;
     bool skipped = false;
-    // The cycle body is written with selects instead of branches: lanes run different programs, and every divergent branch
-    // costs the wavefront an exec-mask save/restore whether or not a lane takes it.
+    bool all_eq = pack8_eq(out, tout);  // :341 `all(output == expected)`: changes only in cycles that write the output
+    // The cycle body is written with selects instead of branches (lanes run different programs, and every divergent branch costs
+    // the wavefront an exec-mask save/restore whether or not a lane takes it), with ONE wave-uniform branch: cycles in which no
+    // lane of the wavefront touches the IO addresses -- the common case inside the long-running loops that bound the kernel --
+    // skip the input shift, the output insert and both 128-bit comparisons.
     while (!error && !halt && cycles < 200) {  // :297-299, MAX_CYCLE_COUNT :19
         cycles += 1;
         const bool oob = cur + 2 >= W;  // :364-370: error, nothing else changes
         const bool ok = !oob;
         const int cc = oob ? 0 : cur;
         const int a = mem.get(cc), b = mem.get(cc + 1), c = mem.get(cc + 2);
-        // read_memory :187-232 (both reads see the pre-advance input state)
-        const int in0 = static_cast<int>(in.lo & 0xFFFFu);
-        const bool in_ok = in0 < W;
-        const bool a_mem = a <= AMAX, b_mem = b <= AMAX, uses_in = (a == AIN) || (b == AIN);
+        const bool a_mem = a <= AMAX, b_mem = b <= AMAX;
         const int ma = mem.get(a_mem ? a : 0), mb = mem.get(b_mem ? b : 0);
-        const int ra = a_mem ? ma : ((a == AIN && in_ok) ? in0 : 0);
-        const int rb = b_mem ? mb : ((b == AIN && in_ok) ? in0 : 0);
-        const bool acc = ok && uses_in && in_ok;
-        // :322 (ra - rb) mod W.  Words are < W, so one conditional add is the whole modulo; the general form (an integer division)
-        // only runs for out-of-range bytes of a hand-made state
-        int value = ra - rb;
-        value += value < 0 ? W : 0;
-        if constexpr (!Mem::kWordsInRange) {
-            if (value < 0 || value >= W) value = pymod(ra - rb, W);
-        }
-        // write_memory :243-295
-        const bool wr_out = a == AOUT, out_full = out_cursor >= 8;
-        const bool err = (uses_in && !in_ok) || (wr_out && out_full);
-        const bool modified = ok && wr_out && !out_full;
-        mem.set_if(ok && a_mem, a, value);
-        {
+        const bool uses_in = (a == AIN) || (b == AIN), wr_out = a == AOUT;
+        bool err = false;
+        int value;
+        if (__builtin_amdgcn_ballot_w64(ok && (uses_in || wr_out)) != 0) {
+            // read_memory :187-232 (both reads see the pre-advance input state)
+            const int in0 = static_cast<int>(in.lo & 0xFFFFu);
+            const bool in_ok = in0 < W;
+            const int ra = a_mem ? ma : ((a == AIN && in_ok) ? in0 : 0);
+            const int rb = b_mem ? mb : ((b == AIN && in_ok) ? in0 : 0);
+            const bool acc = ok && uses_in && in_ok;
+            value = ra - rb;  // :322, see below
+            value += value < 0 ? W : 0;
+            if constexpr (!Mem::kWordsInRange) {
+                if (value < 0 || value >= W) value = pymod(ra - rb, W);
+            }
+            // write_memory :243-295 (output port)
+            const bool out_full = out_cursor >= 8;
+            err = (uses_in && !in_ok) || (wr_out && out_full);
+            const bool modified = ok && wr_out && !out_full;
             const int sh = 16 * (out_cursor & 3);
             const unsigned long long clr = ~(0xFFFFull << sh), ins = static_cast<unsigned long long>(value) << sh;
-            const unsigned long long lo2 = (out.lo & clr) | ins, hi2 = (out.hi & clr) | ins;
-            out.lo = (modified && out_cursor < 4) ? lo2 : out.lo;
-            out.hi = (modified && out_cursor >= 4) ? hi2 : out.hi;
+            const unsigned long long olo = (out.lo & clr) | ins, ohi = (out.hi & clr) | ins;
+            out.lo = (modified && out_cursor < 4) ? olo : out.lo;
+            out.hi = (modified && out_cursor >= 4) ? ohi : out.hi;
             out_cursor += modified ? 1 : 0;
+            // :333-338 roll the input by one, pad with W
+            const unsigned long long ilo = (in.lo >> 16) | (in.hi << 48), ihi = (in.hi >> 16) | (static_cast<unsigned long long>(W) << 48);
+            in.lo = acc ? ilo : in.lo;
+            in.hi = acc ? ihi : in.hi;
+            io_epoch += (acc || modified) ? 1 : 0;
+            all_eq = pack8_eq(out, tout);
+            const int oc = (out_cursor - 1) & 7;  // -1 wraps to the last element (jnp negative index); masked by `modified`
+            const unsigned long long diff = oc < 4 ? (out.lo ^ tout.lo) : (out.hi ^ tout.hi);
+            err = err || (modified && ((diff >> (16 * (oc & 3))) & 0xFFFFull) != 0);  // :346-350
+        } else {
+            // no lane reads IN or writes OUT in this cycle: reads of the non-memory addresses return 0 (:187-232)
+            const int ra = a_mem ? ma : 0, rb = b_mem ? mb : 0;
+            value = ra - rb;
+            value += value < 0 ? W : 0;
+            if constexpr (!Mem::kWordsInRange) {
+                if (value < 0 || value >= W) value = pymod(ra - rb, W);
+            }
         }
+        // :322 (ra - rb) mod W: words are < W, so one conditional add is the whole modulo; the general form (an integer division)
+        // only runs for out-of-range bytes of a hand-made state.  write_memory :243-295 (memory)
+        mem.set_if(ok && a_mem, a, value);
         const bool jump = (value == 0) || (2 * value >= W);  // :329
         cur = oob ? cur : (jump ? c : cur + 3);              // :330
-        {                                                    // :333-338 roll by one, pad with W
-            const unsigned long long lo2 = (in.lo >> 16) | (in.hi << 48), hi2 = (in.hi >> 16) | (static_cast<unsigned long long>(W) << 48);
-            in.lo = acc ? lo2 : in.lo;
-            in.hi = acc ? hi2 : in.hi;
-        }
-        const bool all_eq = pack8_eq(out, tout);
         // :340-345 `(execute_jump & c > ADDRESS_MAX)` == `(execute_jump & c) > ADDRESS_MAX` (Python precedence): {0,1} > W-4
         halt = ok && ((((jump ? 1 : 0) & c) > AMAX) || all_eq);
-        const int oc = (out_cursor - 1) & 7;  // -1 wraps to the last element (jnp negative index); masked by `modified`
-        const unsigned long long diff = oc < 4 ? (out.lo ^ tout.lo) : (out.hi ^ tout.hi);
-        error = oob || err || (modified && ((diff >> (16 * (oc & 3))) & 0xFFFFull) != 0);  // :346-350
+        error = oob || err;
         // ---- periodicity (exact, see above) ----
         const bool watching = !skipped && !error && !halt;
-        bool hit = (static_cast<int>(watching) & static_cast<int>(cur == s_cur) & static_cast<int>(out_cursor == s_oc) &
-                    static_cast<int>(pack8_eq(in, s_in)) & static_cast<int>(pack8_eq(out, s_out))) != 0;
+        bool hit = (static_cast<int>(watching) & static_cast<int>(cur == s_cur) & static_cast<int>(io_epoch == s_epoch)) != 0;
         if constexpr (Mem::kWordsInRange) hit = (static_cast<int>(hit) & static_cast<int>(mem.same())) != 0;
         else hit = hit && mem.same();
         if (hit) {
@@ -282,7 +297,7 @@ __device__ __forceinline__ bool subleq_simulate(int W, Mem& mem, uint16_t in_arr
         }
         if (watching && !hit && cycles == next_snap) {
             mem.snapshot();
-            s_cur = cur; s_oc = out_cursor; s_in = in; s_out = out; s_cycle = cycles;
+            s_cur = cur; s_epoch = io_epoch; s_cycle = cycles;
             next_snap *= 2;
         }
     }
