@@ -550,17 +550,15 @@ def _generic_policy(params, rng_key, root, recurrent_fn, S, invalid_actions, max
     return PolicyOutput(action, weights, SearchTree(s))
 
 
-_dummy_nets: dict = {}
-
-
 def _dummy_net(env_h: engine.EnvHandle) -> engine.FCNet:
-    k = id(env_h)
-    if k not in _dummy_nets:
-        rows, cols = env_h.obs_shape
+    # kept on the handle itself (a table keyed by id(env_h) would hand a recycled id the network of a dead environment)
+    net = getattr(env_h, "_dummy_net", None)
+    if net is None:
+        rows, cols = env_h.obs_shape[0], int(np.prod(env_h.obs_shape[1:]))
         p = params_lib.init_fc_params(rows * cols, 256, env_h.num_actions, seed=0)
         hl = (rows * cols) - ((rows * cols) % 4)
-        _dummy_nets[k] = engine.FCNet(env_h.ctx, rows * cols, 256, env_h.num_actions, p, None, hash_len=hl)
-    return _dummy_nets[k]
+        net = env_h._dummy_net = engine.FCNet(env_h.ctx, rows * cols, 256, env_h.num_actions, p, None, hash_len=hl)
+    return net
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -626,10 +626,12 @@ static int dalloc(eaz_search* s, T** p, size_t count) {
     *p = static_cast<T*>(q);
     return 0;
 }
-#define DALLOC(p, count)                    \
-    do {                                    \
-        int rc_ = dalloc(s, &(p), (count)); \
-        if (rc_) return rc_;                \
+extern "C" int eaz_search_destroy(eaz_search* s);
+// only used while eaz_search_create builds `s`: a failed allocation releases everything allocated so far
+#define DALLOC(p, count)                              \
+    do {                                              \
+        int rc_ = dalloc(s, &(p), (count));           \
+        if (rc_) { (void)eaz_search_destroy(s); return rc_; } \
     } while (0)
 
 // dispatch on (lanes per tree, actions per lane)
