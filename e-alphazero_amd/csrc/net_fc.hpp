@@ -622,6 +622,21 @@ __device__ __forceinline__ void mma16_block(floatx4 (&acc)[4], const void* Abase
     }
 }
 
+// One whole 256-input block of layer 1 without the mask machinery: all 64 k-steps, compile-time trip count (the compiler unrolls
+// and schedules it like layer 2).  Used when most k-steps of the block are non-zero anyway: executing an all-zero k-step is
+// exact (fmaf(0, w, acc) == acc), and k-steps beyond in_dim read a clamped (valid) weight row against observation bytes that
+// the staging zero-filled.
+__device__ __forceinline__ void mma16_dense_u8(floatx4 (&acc)[4], const uint8_t* At, const float* W, int K, int k0, int col, int r, int kq) {
+#pragma unroll 8
+    for (int ks = 0; ks < 64; ++ks) {
+        const int kl = 4 * ks + kq, k = k0 + kl;
+        const floatx4 b = *reinterpret_cast<const floatx4*>(W + static_cast<long>(k < K ? k : K - 1) * kFcH + col);
+        const float a = static_cast<float>(At[r * kFcKC + ((((kl >> 4) ^ r)) << 4) + (kl & 15)]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[t], 0, 0, 0);
+    }
+}
+
 // accumulators -> relu(acc + bias) -> hidden tile: lane (r, kq) holds rows 4*kq .. 4*kq+3 of column n0 + 4*r + t
 __device__ __forceinline__ void store_hidden16(float* Ht, const floatx4 (&acc)[4], const float* bias, int n0, int r, int kq) {
 #pragma unroll
@@ -736,8 +751,15 @@ __global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn i
                 const unsigned long long mv = block_mask(&kmask[16 * c], kb);
                 const unsigned long long m = static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(mv))) |
                                              (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(mv >> 32))) << 32);
-                executed += __builtin_popcountll(m);
-                mma16_block<true>(acc, R2 + kb * 256, m, W1, K1, c * kFcKC + kb * 256, col, r, kq);
+                const int k0 = c * kFcKC + kb * 256;
+                const int valid = (K1 - k0 + 3) / 4;  // k-steps of this block that lie inside the observation
+                if (__builtin_popcountll(m) >= 40 || (valid > 0 && valid < 64 && 4 * __builtin_popcountll(m) >= 3 * valid)) {
+                    executed += 64;
+                    mma16_dense_u8(acc, R2 + kb * 256, W1, K1, k0, col, r, kq);
+                } else {
+                    executed += __builtin_popcountll(m);
+                    mma16_block<true>(acc, R2 + kb * 256, m, W1, K1, k0, col, r, kq);
+                }
             }
             if (c + 1 < nchunk1) __syncthreads();  // everyone is done reading chunk c before it is overwritten
         }
