@@ -258,7 +258,7 @@ static int env_step_launch(eaz_env* env, int B, const void* in, const int32_t* a
         const int epw = subleq_envs_per_wg(B);
         subleq_step_kernel<<<cdiv(B, epw), 64, subleq_lds_bytes(env->dev.W), st>>>(env->dev, src, dst, action, B, mode, key, d_key,
                                                                                   static_cast<char*>(out_copy), mover_reward, nullptr, nullptr,
-                                                                                  epw, 256);
+                                                                                  epw, 256, nullptr);
         LAUNCH_OK();
     } else {
         connect4_step_kernel<<<cdiv(B, 256), 256, 0, st>>>(env->dev, src, dst, action, B, mode, key, d_key, mover_reward, nullptr, nullptr);
@@ -858,12 +858,17 @@ static int recurrent_launch(eaz_search* s, hipStream_t st) {
             StateRef dst{s->tree.embeddings, s->tree.sim_next, s->N};
             // embedding slots 1.. are only ever written here and the allocation starts zeroed: bytes >= W of `memory` stay zero
             const int epw = subleq_envs_per_wg(B);
+            // word_size 16 + binary encoding: the step kernel also writes the observation row (no obs_emit launch)
+            const bool fused_obs = g_fused_leaf && env->dev.W == 16 && env->dev.binary && env->dev.obs_dim == 240;
             subleq_step_kernel<<<cdiv(B, epw), 64, subleq_lds_bytes(env->dev.W), st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0},
                                                                                       nullptr, nullptr, s->d_next_reward, s->d_next_term,
-                                                                                      s->d_next_legal, epw, (env->dev.W + 15) & ~15);
+                                                                                      s->d_next_legal, epw, (env->dev.W + 15) & ~15,
+                                                                                      fused_obs ? s->d_obs : nullptr);
             LAUNCH_OK();
-            obs_emit_kernel<<<cdiv(static_cast<long>(B) * 64, 256), 256, 0, st>>>(env->dev, dst, B, s->d_obs);
-            LAUNCH_OK();
+            if (!fused_obs) {
+                obs_emit_kernel<<<cdiv(static_cast<long>(B) * 64, 256), 256, 0, st>>>(env->dev, dst, B, s->d_obs);
+                LAUNCH_OK();
+            }
         }
     }
     return infer_launch(s, s->d_obs, s->d_novelty, o, hl, st);

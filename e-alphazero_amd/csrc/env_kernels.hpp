@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) leaf_gather_deepsea_kernel(EnvDev e, Tree
 __global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src, StateRef dst, const int32_t* action, int B,
                                                          int mode, Key key_arg, const Key* key_ptr, char* out_copy,
                                                          float* next_reward, uint8_t* next_term, uint8_t* next_legal,
-                                                         int envs_per_wg, int mem_copy) {
+                                                         int envs_per_wg, int mem_copy, uint8_t* obs_out) {
     const Key key = key_ptr ? *key_ptr : key_arg;  // device-resident key: lets a captured hipGraph serve every real step
     extern __shared__ __attribute__((aligned(16))) uint8_t lmem[];  // word_size != 16: 2 * 64 * W (working memory + snapshot)
     const int W = e.W;
@@ -235,6 +235,34 @@ __global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src,
     if (next_term) next_term[b] = terminated;
     if (next_legal)
         for (int a = 0; a < e.A; ++a) next_legal[static_cast<long>(b) * e.A + a] = 1;  // all legal (subleq.py:626)
+    if (obs_out) {
+        // word_size 16, binary encoding only (the host passes null otherwise): the 48 x 5 observation (subleq.py:679-707 rows =
+        // memory | input | input_after | output | output_after; :88-98 columns = 4 little-endian bits of v mod 16, then v == 16)
+        // of the state just written, assembled in registers and stored as 15 x 16 bytes -- saves the obs_emit launch per simulation
+        const uint4 mv = *reinterpret_cast<const uint4*>(dp->memory);
+        const uint4* iov = reinterpret_cast<const uint4*>(dp->ex_in);  // ex_in, ex_in_after, ex_out, ex_out_after: 4 x 8 u16
+        const uint32_t mw[4] = {mv.x, mv.y, mv.z, mv.w};
+        uint32_t iw[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const uint4 v = iov[i]; iw[4 * i] = v.x; iw[4 * i + 1] = v.y; iw[4 * i + 2] = v.z; iw[4 * i + 3] = v.w; }
+        uint32_t ow[60];
+#pragma unroll
+        for (int i = 0; i < 60; ++i) ow[i] = 0u;
+#pragma unroll
+        for (int w = 0; w < 48; ++w) {
+            const uint32_t v = w < 16 ? (mw[w >> 2] >> (8 * (w & 3))) & 0xFFu : (iw[(w - 16) >> 1] >> (16 * ((w - 16) & 1))) & 0xFFFFu;
+            const uint32_t m = v & 15u;  // v mod 16 (v <= 16)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const uint32_t byte = j < 4 ? (m >> j) & 1u : static_cast<uint32_t>(v == 16u);
+                const int p = 5 * w + j;
+                ow[p >> 2] |= byte << (8 * (p & 3));
+            }
+        }
+        uint4* dst = reinterpret_cast<uint4*>(obs_out + static_cast<long>(b) * 240);
+#pragma unroll
+        for (int i = 0; i < 15; ++i) dst[i] = make_uint4(ow[4 * i], ow[4 * i + 1], ow[4 * i + 2], ow[4 * i + 3]);
+    }
 }
 
 // ---- connect_four -------------------------------------------------------------------------------------------------
