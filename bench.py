@@ -121,7 +121,7 @@ def build_workload(name, args, device, rank):
         desc = f"Subleq word_size={W} task=1 binary obs, batch={B}/GPU, {S} sims, {T} real steps per selfplay() call, FC H={H} (BASELINE.json configs[2])"
         data = "synthetic (random-init FC net, half-filled novelty set)"
         net_kernel, net_flops = "fc16_forward_kernel", fc_flops_per_eval(in_dim, A, (0, 1, 2)) * B
-        pmc_tag, gather_kernel = None, "subleq_step_kernel + obs_emit_kernel"
+        pmc_tag, gather_kernel = None, "subleq_step_kernel (env step + observation row)"
 
         def oracle(O):
             oenv = O.OracleEnv.subleq(W, (1,), True)
@@ -314,9 +314,11 @@ def main():
     else:
         prof_g = prof
     gbytes = B * (2 * env.state_bytes + env.obs_dim)
-    g_launch = max(prof_g["gather"]["launches"], 1)
-    per_sim = 1 if args.workload == "c2" else 2          # c3/c4: env-step kernel + observation-emit kernel per simulation
-    g_ms = per_sim * prof_g["gather"]["ms"] / g_launch
+    # per SIMULATION: c2 one launch, c3 one (word_size 16: the step kernel also emits the observation) and c4 two (env step +
+    # observation emit)
+    g_sims = prof_g["gather"]["launches"] if args.workload == "c2" else max(T_instr * n_instr * S, 1)
+    per_sim = max(1, round(prof_g["gather"]["launches"] / max(g_sims, 1)))
+    g_ms = prof_g["gather"]["ms"] / max(g_sims, 1)
     gach = gbytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
     # HBM-side traffic per launch from the PMC passes committed under profiles/ (rocprofv3 FETCH_SIZE / WRITE_SIZE cannot be
     # collected from inside this process); only attached when the file was recorded for this workload
