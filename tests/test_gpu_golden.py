@@ -99,6 +99,40 @@ def test_subleq_env_matches_oracle(oracle, eaz, torch, W, binary, tasks):
     assert np.array_equal(subleq_oracle_to_device(ost), st.cpu().numpy())
 
 
+@pytest.mark.parametrize("W,tasks,B", [(16, (1,), 8192), (16, (2, 4, 6), 4096), (32, (1,), 2048), (256, (5,), 512)])
+def test_subleq_interpreter_on_random_programs(oracle, eaz, torch, W, tasks, B):
+    """Stress for the interpreter's exact shortcuts (period skip, IO-free fast path, sequential test cases with early out, the
+    register-resident memory of word_size 16): thousands of uniformly random programs -- tight loops, counting loops that mutate
+    memory for dozens of cycles, input readers, output writers, out-of-range cursors -- must land in exactly the state the
+    literal 200-cycle oracle loop reaches."""
+    from e_alphazero_amd import engine
+    from helpers import ORACLE_SUBLEQ
+
+    env = engine.EnvHandle.subleq(W, tasks, True, device=0)
+    oenv = oracle.OracleEnv.subleq(W, tasks, True)
+    rng = np.random.default_rng(100 + W)
+    ost = oenv.init(B, key=(9, 0))
+    o = ost.view(ORACLE_SUBLEQ).reshape(B)
+    nwords = rng.integers(0, W - 3, B)                         # how many words of the program are already written
+    mem = rng.integers(0, W, (B, 256)).astype(np.int32)
+    # bias some programs towards the IO addresses so that readers / writers / halting programs are common
+    io = rng.random((B, 256)) < 0.15
+    mem[io] = rng.integers(W - 4, W, int(io.sum()))
+    mem[np.arange(256)[None, :] >= nwords[:, None]] = 0
+    o["memory"] = mem
+    o["step_count"] = nwords
+    ost = o.view(np.uint8).reshape(B, -1)
+    st = torch.from_numpy(subleq_oracle_to_device(ost)).cuda()
+    for t in range(3):
+        a = rng.integers(0, W, B).astype(np.int32)
+        st = env.step(st, torch.from_numpy(a).cuda(), key=300 + t)
+        ost = oenv.step(ost, a, key=(300 + t, 0))
+        assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost), f"W={W} t={t}"
+        assert np.array_equal(env.observe(st).cpu().numpy(), oenv.observe(ost))
+    solved = ost.view(ORACLE_SUBLEQ).reshape(B)["solved"]
+    print(f"W={W}: {int(solved.sum())} of {B} random programs solved their task")
+
+
 def test_random_play_matches_oracle(oracle, eaz, torch):
     """uniformrandomplay (selfplay.py:152-170): same keys -> same trajectories."""
     from e_alphazero_amd import engine
