@@ -324,7 +324,7 @@ def main():
     # collected from inside this process); only attached when the file was recorded for this workload
     traffic = {}
     pmc_file = None
-    for cand in ("r01_e_pmc_traffic.json", "r01_b_pmc_traffic.json"):
+    for cand in ("r01_f_pmc_traffic.json", "r01_e_pmc_traffic.json", "r01_b_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", cand)) as f:
                 pmc = json.load(f)
