@@ -37,8 +37,10 @@ def main():
         kernels[k] = e
     json.dump({"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 1 --warmup 0 "
                           "--selfplay-steps 4 --no-cpu-baseline (two separate passes)",
-               "note": "raw counter values in KB (rocprofv3 FETCH_SIZE / WRITE_SIZE); on gfx950 FETCH_SIZE under-counts 16-B-per-lane streaming "
-                       "reads by 2x (MI355X_MICROARCH.md HBM section); other widths uncalibrated, so reads are reported raw",
+               "note": "RAW counter values in KB (rocprofv3 FETCH_SIZE / WRITE_SIZE), two separate passes.  MI355X_MICROARCH.md (HBM): on gfx950 "
+                       "FETCH_SIZE reports exactly half of the bytes of a 16-B-per-lane streaming read -- consumers double it for kernels "
+                       "whose fetches are such streams (bench.py does for the forward kernel's weight loads); WRITE_SIZE is exact for "
+                       "16-B-per-lane stores; other access widths are uncalibrated",
                "workload": tag, "kernels": kernels}, open(out, "w"), indent=1)
     for k, e in kernels.items():
         if "eaz" in k:
