@@ -519,7 +519,7 @@ static int fc_onehot_launch(eaz_net* n, int B, const int32_t* hot, float* novelt
     const int per_xcd = cdiv(cdiv(B, kF16M), 8);
     const int nb = 8 * per_xcd * heads.n;
     const FcIn in{nullptr, hot, novelty, n->dev.ztab};
-    fc16_forward_kernel<2><<<nb + (novelty ? cdiv(B, 256) : 0), 256, kF16LdsBytes, st>>>(n->dev, in, B, o, heads, per_xcd, nb, n->d_kstep_counter);
+    fc16_forward_kernel<2><<<nb + (novelty ? cdiv(B, 256) : 0), 256, f16_lds_bytes(n->dev.A), st>>>(n->dev, in, B, o, heads, per_xcd, nb, n->d_kstep_counter);
     LAUNCH_OK();
     return 0;
 }
@@ -538,8 +538,8 @@ static int fc_launch(eaz_net* n, int B, const uint8_t* obs, const NetOut& o, con
         const bool fast16 = (n->dev.in_dim % 16 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0);
         const FcIn in{obs, nullptr, nullptr, nullptr};
         const int nb = 8 * per_xcd * heads.n;
-        if (fast16) fc16_forward_kernel<0><<<nb, 256, kF16LdsBytes, st>>>(n->dev, in, B, o, heads, per_xcd, nb, n->d_kstep_counter);
-        else fc16_forward_kernel<1><<<nb, 256, kF16LdsBytes, st>>>(n->dev, in, B, o, heads, per_xcd, nb, n->d_kstep_counter);
+        if (fast16) fc16_forward_kernel<0><<<nb, 256, f16_lds_bytes(n->dev.A), st>>>(n->dev, in, B, o, heads, per_xcd, nb, n->d_kstep_counter);
+        else fc16_forward_kernel<1><<<nb, 256, f16_lds_bytes(n->dev.A), st>>>(n->dev, in, B, o, heads, per_xcd, nb, n->d_kstep_counter);
         LAUNCH_OK();
         return 0;
     }

@@ -523,7 +523,11 @@ __global__ void __launch_bounds__(256) hash_kernel(NetDev net, const uint8_t* __
 constexpr int kF16M = 16;
 constexpr int kF16HFloats = kFcH * 16 + (kFcH / 4) * 4;  // K-major [256][16] with a 16-byte skew every 4 k: conflict-free b128 stores
 constexpr int kF16HBytes = kF16HFloats * 4;              // 17 408
-constexpr int kF16LdsBytes = 2 * kF16HBytes + kFcMaskBytes;
+// + layer-3 weights of the narrow heads [256][w3ld], w3ld = actions rounded up to 4 (4 KB for <= 4 actions: 40 KB in all, four
+// workgroups per CU -- the novelty workgroups of the one-hot launch then run beside the three forward workgroups of a CU)
+constexpr int kF16LdsBase = 2 * kF16HBytes + kFcMaskBytes;
+__host__ __device__ inline int f16_w3ld(int A) { return A <= kFcW3Cols ? ((A + 3) & ~3) : 0; }
+__host__ __device__ inline int f16_lds_bytes(int A) { return kF16LdsBase + kFcH * f16_w3ld(A) * 4; }
 static_assert(kF16M * kFcKC <= kF16HBytes, "the observation chunk (16 rows x 1024 inputs, uint8) aliases the H2 tile");
 
 __device__ __forceinline__ int h16_off(int k, int row) { return k * 16 + (k >> 2) * 4 + row; }
@@ -713,6 +717,20 @@ __global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn i
     EAZ_STAMP(0);
     floatx4 acc[4];
     unsigned long long executed = 0;
+    // layer-3 weights of the narrow heads -> LDS [256][16] (zero beyond No), requested first so that the loads fly under layer 1;
+    // thread k stages row k.  (Preloading them into the registers of the layer-3 wave after layer 2 put 64 global loads in front
+    // of the H2 barrier: 8 k cycles per workgroup.)
+    float* W3s = reinterpret_cast<float*>(lds + kF16LdsBase);
+    const int w3ld = f16_w3ld(net.A);  // every head of the launch uses the stride of the widest narrow head
+    const bool narrow = net.A <= kFcW3Cols;
+    if (narrow) {
+        for (int c = 0; c < w3ld; c += 4) {
+            floatx4 wv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wv[i] = c + i < No ? W3[tid * No + c + i] : 0.0f;
+            *reinterpret_cast<floatx4*>(W3s + tid * w3ld + c) = wv;
+        }
+    }
     if constexpr (SRC == 2) {
         // ---------------- layer 1 of a one-hot row: relu(W1[hot] + b1), thread = output column ----------------
         float w[16];
@@ -773,14 +791,6 @@ __global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn i
     for (int t = 0; t < 4; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
     mma16_block<false>(acc, H1, ~0ull, W2, kFcH, 0, col, r, kq);
     EAZ_STAMP(2);
-    // layer-3 weights of the narrow heads: B operand of wave 0's MFMA chain (column r of W3, zero beyond No), all 64 loads in
-    // flight while H2 is being written
-    float w3[kFcH / 4];
-    const bool narrow = No <= 16;
-    if (narrow && wave == 0) {
-#pragma unroll
-        for (int ks = 0; ks < kFcH / 4; ++ks) w3[ks] = r < No ? W3[(4 * ks + kq) * No + r] : 0.0f;
-    }
     store_hidden16(H2, acc, b2, n0, r, kq);
     __syncthreads();
     EAZ_STAMP(3);
@@ -803,8 +813,11 @@ __global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn i
     if (narrow) {
         if (wave != 0) return;
         floatx4 a3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int ks = 0; ks < kFcH / 4; ++ks) a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(H2[h16_off(4 * ks + kq, r)], w3[ks], a3, 0, 0, 0);
+        // lanes beyond the staged columns read column 0: their output columns are never emitted (r < No below)
+        const float* w3p = W3s + kq * w3ld + (r < w3ld ? r : 0);
+#pragma unroll 16
+        for (int ks = 0; ks < kFcH / 4; ++ks)
+            a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(H2[h16_off(4 * ks + kq, r)], w3p[(4 * ks) * w3ld], a3, 0, 0, 0);
         if (r < No) {
             const float bo = b3[r];
 #pragma unroll
@@ -834,7 +847,8 @@ __global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn i
             emit(row, o, z + b3[o]);
         }
     }
-    if (kstep_counter && tid == 0 && executed) atomicAdd(kstep_counter, executed);
+    // narrow heads: only the layer-3 wave gets here; otherwise wave 0 reports for the workgroup
+    if (kstep_counter && lane == 0 && (narrow || wave == 0) && executed) atomicAdd(kstep_counter, executed);
 }
 
 }  // namespace eaz
