@@ -192,7 +192,8 @@ def test_fc_forward_subleq_shapes(oracle, eaz, torch, W, binary, B):
     assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(out, ref)), "FC forward is specified to be bit-exact"
 
 
-@pytest.mark.parametrize("kind,size,B,S,beta", [("deepsea", 8, 64, 16, 0.0), ("subleq", 16, 48, 16, -0.5)])
+@pytest.mark.parametrize("kind,size,B,S,beta", [("deepsea", 8, 64, 16, 0.0), ("subleq", 16, 48, 16, -0.5), ("subleq", 16, 1, 8, 0.0),
+                                                ("subleq", 32, 3, 8, 0.0)])
 def test_evaluate_matches_oracle(oracle, eaz, torch, kind, size, B, S, beta):
     """N2: evaluate driver (src/evaluate.py:13-57): greedy search episodes, per-episode returns and loop trip count."""
     engine, env, net, discount = _build_engine(eaz, kind, size, 7, 0.3)

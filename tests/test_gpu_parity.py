@@ -130,6 +130,8 @@ def test_search_tree_per_simulation(oracle, eaz, torch, G, B, S, beta_max, fill)
     (8, 48, 16, 5, dict(sample_actions=True)),
     (8, 48, 16, 5, dict(sample_from_improved_policy=True, uniform_search_policy=True)),
     (32, 256, 64, 3, {}),
+    (8, 1, 8, 9, {}),      # a single environment
+    (6, 17, 8, 6, {}),     # ragged: B not a multiple of any tile, observation size 36 (not a multiple of 16: byte staging path)
 ])
 def test_selfplay_matches_oracle(oracle, eaz, torch, G, B, S, T, flags):
     am, params, state = deepsea_setup(eaz, G, seed=5, fill=0.25)
