@@ -269,13 +269,17 @@ static int env_step_launch(eaz_env* env, int B, const void* in, const int32_t* a
 }
 
 extern "C" int eaz_env_init(eaz_env* env, int B, uint64_t key, void* d_states, void* stream) {
-    ARG_OK(env && d_states && B >= 0);
+    ARG_OK(env && B >= 0);
+    if (B == 0) return 0;  // an empty batch is a no-op (a zero-element tensor has a null data pointer)
+    ARG_OK(d_states != nullptr);
     return env_step_launch(env, B, nullptr, nullptr, key_from_u64(key), 2, d_states, nullptr, S(stream));
 }
 
 extern "C" int eaz_env_step(eaz_env* env, int B, const void* d_in, const int32_t* d_action, uint64_t key, int autoreset,
                             void* d_out, void* stream) {
-    ARG_OK(env && d_in && d_action && d_out && B >= 0);
+    ARG_OK(env && B >= 0);
+    if (B == 0) return 0;
+    ARG_OK(d_in && d_action && d_out);
     return env_step_launch(env, B, d_in, d_action, key_from_u64(key), autoreset ? 1 : 0, d_out, nullptr, S(stream));
 }
 
@@ -288,13 +292,17 @@ static int obs_launch(eaz_env* env, int B, const void* states, uint8_t* obs, hip
 }
 
 extern "C" int eaz_env_observe(eaz_env* env, int B, const void* d_states, uint8_t* d_obs, void* stream) {
-    ARG_OK(env && d_states && d_obs && B >= 0);
+    ARG_OK(env && B >= 0);
+    if (B == 0) return 0;
+    ARG_OK(d_states && d_obs);
     return obs_launch(env, B, d_states, d_obs, S(stream));
 }
 
 extern "C" int eaz_env_fields(eaz_env* env, int B, const void* d_states, uint8_t* d_term, uint8_t* d_trunc, float* d_reward,
                               int32_t* d_step_count, uint8_t* d_legal, int32_t* d_current_player, void* stream) {
-    ARG_OK(env && d_states && B >= 0);
+    ARG_OK(env && B >= 0);
+    if (B == 0) return 0;  // an empty batch is a no-op (a zero-element tensor has a null data pointer)
+    ARG_OK(d_states != nullptr);
     if (B == 0) return 0;
     env_fields_kernel<<<cdiv(B, 256), 256, 0, S(stream)>>>(env->dev, static_cast<const char*>(d_states), B, d_term, d_trunc,
                                                          d_reward, d_step_count, d_legal, d_current_player);
@@ -560,8 +568,9 @@ static int fc_launch(eaz_net* n, int B, const uint8_t* obs, const NetOut& o, con
 
 extern "C" int eaz_net_forward(eaz_net* n, int B, const uint8_t* d_obs, float* d_exploit, float* d_explore, float* d_value,
                                float* d_ube, float* d_novelty, void* stream) {
-    ARG_OK(n && d_obs && B >= 0);
+    ARG_OK(n && B >= 0);
     if (B == 0) return 0;
+    ARG_OK(d_obs != nullptr);
     float* nov = d_novelty;
     float* tmp = nullptr;
     if (d_ube && !nov) {  // u needs the novelty lookup even when the caller does not want it back
@@ -589,11 +598,15 @@ extern "C" int eaz_net_forward(eaz_net* n, int B, const uint8_t* d_obs, float* d
 }
 
 extern "C" int eaz_hash_lookup(eaz_net* n, int B, const uint8_t* d_obs, uint8_t* d_seen, uint32_t* d_indices, void* stream) {
-    ARG_OK(n && d_obs && B >= 0);
+    ARG_OK(n && B >= 0);
+    if (B == 0) return 0;
+    ARG_OK(d_obs != nullptr);
     return hash_launch(n, B, d_obs, nullptr, d_seen, d_indices, 0, S(stream));
 }
 extern "C" int eaz_hash_update(eaz_net* n, int B, const uint8_t* d_obs, void* stream) {
-    ARG_OK(n && d_obs && B >= 0);
+    ARG_OK(n && B >= 0);
+    if (B == 0) return 0;
+    ARG_OK(d_obs != nullptr);
     return hash_launch(n, B, d_obs, nullptr, nullptr, nullptr, 1, S(stream));
 }
 

@@ -133,6 +133,27 @@ def test_subleq_interpreter_on_random_programs(oracle, eaz, torch, W, tasks, B):
     print(f"W={W}: {int(solved.sum())} of {B} random programs solved their task")
 
 
+def test_empty_batches_are_no_ops(eaz, torch):
+    """B = 0 through the C ABI: every batched entry point accepts an empty batch (null data pointers included)."""
+    from e_alphazero_amd import engine
+
+    env = engine.EnvHandle.deepsea(8, device=0)
+    p = eaz.params.init_fc_params(64, 256, 2, seed=0)
+    net = engine.FCNet(env.ctx, 64, 256, 2, p, eaz.params.init_hash_state())
+    st = env.init(0)
+    assert st.shape == (0, env.state_bytes)
+    st = env.step(st, torch.zeros(0, dtype=torch.int32, device="cuda"))
+    obs = env.observe(st).reshape(0, 64)
+    assert obs.shape[0] == 0
+    assert all(t.shape[0] == 0 for t in net.forward(obs))
+    assert env.fields(st)["terminated"].shape == (0,)
+    net.hash_update(obs)
+    seen, idx = net.hash_lookup(obs)
+    assert seen.shape == (0,)
+    with pytest.raises(eaz.EazError):
+        engine.Search(env, net, 0, 8)  # a search needs at least one tree
+
+
 def test_random_play_matches_oracle(oracle, eaz, torch):
     """uniformrandomplay (selfplay.py:152-170): same keys -> same trajectories."""
     from e_alphazero_amd import engine
