@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase breakdown of fc_forward_kernel from the diagnostic build (make -C e-alphazero_amd/csrc diag; EAZ_LIB=.../libeaz_diag.so).
+"""Phase breakdown of the 64-row fc_forward_kernel from the diagnostic build (make -C e-alphazero_amd/csrc diag; EAZ_LIB=.../libeaz_diag.so).
 Reads the in-kernel s_memtime stamps of the LAST launch and prints the median share of each phase over the workgroups."""
 import ctypes as C
 import os
@@ -15,6 +15,7 @@ import e_alphazero_amd as eaz  # noqa: E402
 from e_alphazero_amd import engine  # noqa: E402
 
 G, B = 32, 4096
+engine.tune(fc_tile=64)  # this tool stamps the 64-row kernel (fc_forward_kernel); fc16_stamps.py / fc16_dense_stamps.py do the 16-row one
 am = (np.random.default_rng(0).random((G, G)) < 0.5).astype(np.uint8)
 params = eaz.params.init_fc_params(G * G, 256, 2, seed=0)
 env = engine.EnvHandle.deepsea(G, am, device=0)
