@@ -124,6 +124,37 @@ def test_search_tree_per_simulation(oracle, eaz, torch, G, B, S, beta_max, fill)
     print(f"tree float fields bit-exact vs oracle: {exact}")
 
 
+@pytest.mark.parametrize("max_depth,rescale,mixed", [(3, True, True), (1, True, True), (5, False, True), (4, True, False)])
+def test_search_depth_limited_and_qtransform_options(oracle, eaz, torch, max_depth, rescale, mixed):
+    """max_depth < S (mctx `max_depth`): simulations that reach the limit re-expand an existing node (visit count + 1, embedding
+    rewritten) -- the path on which the fused DeepSea step writes into a slot that is already occupied -- together with the
+    qtransform switches (rescale_values, use_mixed_value)."""
+    G, B, S = 8, 96, 24
+    am, params, state = deepsea_setup(eaz, G, seed=8, fill=0.3)
+    engine, env, net = _engine(eaz, G, am, params, state)
+    oenv, onet = oracle_deepsea(oracle, eaz, G, am, params, state)
+    blobs = random_states_deepsea(G, B, seed=9)
+    ex, xp, v, u, _ = onet.forward(oenv.observe(blobs))
+    beta = np.zeros(B, np.float32)
+    g = oracle.gumbel((21, 22), B * 2).reshape(B, 2)
+    otree = oracle.OracleTree(oenv, onet, B, S)
+    otree.begin(ex, v, u, blobs, beta, None, g, discount=0.997, rescale=rescale, use_mixed=mixed, max_depth=max_depth)
+    search = engine.Search(env, net, B, S, discount=0.997, rescale_values=rescale, use_mixed_value=mixed, max_depth=max_depth)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    search.begin(cu(ex), cu(v), cu(u), cu(blobs), cu(beta), None, cu(g))
+    for sim in range(S):
+        otree.sim(sim)
+        search.simulate(sim)
+    act, aw = search.finish()
+    oact, oaw = otree.finish()
+    _compare_tree(search, otree, f"max_depth={max_depth}")
+    assert np.array_equal(search.field("embeddings").cpu().numpy(), otree.field("embeddings"))
+    assert np.array_equal(act.cpu().numpy(), oact)
+    np.testing.assert_allclose(aw.cpu().numpy(), oaw, rtol=0, atol=ATOL)
+    nv = search.dump()["node_visits"]
+    assert (nv[:, 1:] > 1).any(), "the depth limit never re-expanded a node: the test does not cover what it claims"
+
+
 @pytest.mark.parametrize("G,B,S,T,flags", [
     (8, 64, 16, 10, {}),
     (8, 64, 16, 6, dict(directed_exploration=True, exploration_beta=1.0)),
