@@ -323,3 +323,23 @@ def test_connect4_selfplay_matches_oracle(oracle, eaz, torch, flags):
     ret, it = engine.Search(env, net, B, S, discount=0.997, two_players_game=True, gumbel_scale=0.0).evaluate(env.init(B, key=5), max_episode_length=50)
     oret, oit = oracle.evaluate(oenv, onet, oenv.init(B, key=(5, 0)), S, discount=0.997, two_player=True, max_episode_length=50)
     assert it == oit and np.array_equal(ret.cpu().numpy(), oret)
+
+
+def test_connect4_evaluate_matches_oracle(oracle, eaz, torch):
+    """N2 on the two-player configuration: evaluate (greedy episodes to the end of the game) on connect_four with the residual
+    network; N1 (reanalyze) is single-player by construction in the reference."""
+    engine, env, net, oenv, onet = _c4_setup(oracle, eaz, 1, seed=6)
+    B, S = 24, 12
+    search = engine.Search(env, net, B, S, discount=0.997, two_players_game=True, gumbel_scale=0.0)
+    st = env.init(B, key=4)
+    ost = oenv.init(B, key=(4, 0))
+    ret, it = search.evaluate(st, exploitation_beta=0.0, max_episode_length=50)
+    oret, oit = oracle.evaluate(oenv, onet, ost, S, discount=0.997, two_player=True, exploitation_beta=0.0, max_episode_length=50)
+    assert it == oit and 7 <= it <= 42
+    assert np.array_equal(ret.cpu().numpy(), oret)
+    assert np.array_equal(st.cpu().numpy(), ost)
+    # reanalyze is single-player in the reference (reanalyze.py:95 squeezes a [B,1] reward): the engine refuses the two-player env
+    _, traj = oracle.random_play(oenv, B, 4, key=(6, 6), want_traj=True)
+    g = torch.zeros(B, 7, device="cuda")
+    with pytest.raises(eaz.EazError, match="single-player"):
+        search.reanalyze(torch.from_numpy(traj[0]).cuda(), torch.from_numpy(traj[1]).cuda(), gumbel=g)
