@@ -55,6 +55,23 @@ def test_no_gpu_means_loud_failure(eaz):
     assert b"hip" in eaz.load_library().eaz_last_error().lower()
 
 
+def test_bench_and_library_fail_loudly_without_a_gpu_or_library(tmp_path):
+    """bench.py exits non-zero with a message instead of falling back to anything; a missing libeaz.so is a hard error."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "ROCm device" in (r.stderr + r.stdout)
+        assert not any(line.startswith("{") for line in r.stdout.splitlines()), "no result line may be printed without a GPU"
+    code = "import e_alphazero_amd as m\ntry:\n    m.load_library()\nexcept m.EazError as e:\n    print('LOUD', e)\n"
+    env = dict(os.environ, EAZ_LIB=str(tmp_path / "missing_libeaz.so"), PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert "LOUD" in r.stdout and "no CPU fallback" in r.stdout.replace("There is no CPU fallback", "no CPU fallback")
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "e-alphazero_amd")
     for dirpath, _, files in os.walk(pkg):
