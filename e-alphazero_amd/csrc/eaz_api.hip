@@ -816,7 +816,7 @@ static int tree_step_launch(eaz_search* s, int sim, int mode, hipStream_t st) {
 }
 
 // forward.apply on a batch of observations: the novelty lookup (hash_kernel, 4 lanes per sample, ~64 workgroups) and the
-// MFMA forward (192-256 workgroups) are independent, so the lookup is forked onto the search's side stream and joined
+// MFMA forward (hundreds of workgroups) are independent, so the lookup is forked onto the search's side stream and joined
 // before the consumer of both (tree expand / root preparation applies ube_combine).
 static int infer_launch(eaz_search* s, const uint8_t* obs, float* novelty, const NetOut& o, const HeadList& hl, hipStream_t st) {
     const int B = s->B;
@@ -1044,7 +1044,8 @@ enum : int { kFlagUniform = 1, kFlagSampleVisits = 2, kFlagSampleImproved = 4, k
 
 // One real step of step_fn (selfplay.py:86-143) on fixed addresses: everything that changes from step to step (keys, explicit
 // root noise, output slots) is read from / written to staging buffers, so the launch sequence can be captured ONCE into a
-// hipGraph and replayed (S+1 network forwards, S+1 tree kernels, ... = 4S+12 launches per real step).
+// hipGraph and replayed (S+1 network forwards, S+1 tree kernels, ...: 2S+13 launches per real step on the fused DeepSea path,
+// 3S-4S+14 otherwise).
 static int selfplay_step_body(eaz_search* s, const eaz_selfplay_cfg* cfg, int flags, void* d_states, hipStream_t st) {
     eaz_env* env = s->env;
     const int B = s->B, A = s->A;

@@ -59,7 +59,8 @@ __global__ void __launch_bounds__(256) deepsea_step_kernel(EnvDev e, const char*
     if (out_copy) ds_store(out_copy + static_cast<long>(b) * sizeof(eaz_deepsea_state), s);
 }
 
-// leaf gather + env.step + observation emit: one wavefront per tree
+// leaf gather + env.step + observation emit: one wavefront per tree (the UNFUSED DeepSea path; by default the tree kernel steps
+// the environment itself and no observation row is written, tree.hpp TreeDev::fuse_env)
 __global__ void __launch_bounds__(256) leaf_gather_deepsea_kernel(EnvDev e, TreeDev t, uint8_t* obs, float* next_reward,
                                                                   uint8_t* next_term, uint8_t* next_legal) {
     const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;

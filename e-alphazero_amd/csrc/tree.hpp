@@ -5,7 +5,8 @@
 //
 // Execution model: a group of LPT (2..64, power of two) consecutive lanes of one wavefront walks ONE tree; each lane
 // owns APL consecutive actions (LPT*APL >= A).  Small action sets therefore pack 64/LPT trees per wavefront
-// (DeepSea: 32 trees per wave); A = 256 uses a full wave with 4 actions per lane.  All per-node vectors
+// (DeepSea: up to 32 trees per wave; the launch spreads them thinner, see tree_step_kernel); A = 256 uses a full wave with 4
+// actions per lane.  All per-node vectors
 // ([A]-sized rows of the [B,N,A] arrays) are read coalesced by the group; float reductions use the fixed
 // butterfly order (lane ^ 1, ^ 2, ...) that the CPU oracle mirrors, so selections are bit-reproducible.
 #pragma once
