@@ -7,6 +7,9 @@
 // rounding per product, k ascending).  Layers 1 and 2 of every head run on that MFMA; layer 3 (out = 1 or A) is a
 // VALU fmaf chain in the same order.  tanh is det_tanh (dmath.hpp).
 //
+// Two kernels with the same numerics: fc16_forward_kernel (16 rows per workgroup, further down; the default whenever its
+// whole grid is resident at once) and fc_forward_kernel (64 rows per workgroup, described here; large batches).
+//
 // Kernel shape: one 256-thread workgroup = 64 batch rows x one head.  The three layers of the head stay on chip:
 //   layer 1: A = observation tile, staged ONCE per 1024 inputs as uint8 into LDS (K-major, 4x4 byte transposes in
 //            registers); B = W1 rows streamed from L2 into registers.  Only k-steps (4 consecutive inputs) in which the
