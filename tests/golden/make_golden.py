@@ -32,6 +32,8 @@ CASES = {
     "c1b_deepsea8_beta": ("deepsea", 8, 48, 16, 6, 2, 0.5, dict(directed_exploration=True, exploration_beta=1.0)),
     "c3r_subleq16": ("subleq", 16, 24, 32, 5, 3, 0.25, {}),                    # configs[2] reduced
     "c3b_subleq16_beta": ("subleq", 16, 24, 32, 4, 4, 0.25, dict(directed_exploration=True, exploration_beta=1.0)),
+    # configs[3] reduced: connect_four, two-player discount, residual network with `size` blocks
+    "c4r_connect4": ("connect4", 1, 12, 16, 6, 5, 0.3, dict(two_player=True)),
 }
 
 
@@ -39,6 +41,12 @@ def build(kind, size, seed, fill):
     if kind == "deepsea":
         am, params, state = deepsea_setup(eaz, size, seed=seed, fill=fill)
         env, net = oracle_deepsea(O, eaz, size, am, params, state)
+        return env, net, 0.997
+    if kind == "connect4":
+        params, state = eaz.params.init_resnet_params(6, 7, 2, 7, 64, size, seed=seed)
+        bs = eaz.params.init_hash_state(fill=fill, seed=seed)[eaz.params.HASH_MODULE]["binary_set"]
+        env = O.OracleEnv.connect4()
+        net = O.OracleNet.resnet(6, 7, 2, 7, eaz.params.resnet_array_list(params, state, size), 64, size, bitset=bs)
         return env, net, 0.997
     dims, params, state = subleq_setup(eaz, size, seed=seed, fill=fill)
     env = O.OracleEnv.subleq(size, (1,), True)
@@ -59,7 +67,7 @@ def main():
         beta = (flags.get("exploration_beta", 0.0) * np.linspace(0, 1, B)).astype(np.float32)
         g = O.gumbel((2000 + seed, 0), B * A).reshape(B, A)
         act, aw, summ, tree = O.search(env, net, st, S, xp if explore else ex, v, u, beta, g, discount=discount,
-                                       use_exploration_logits=explore)
+                                       use_exploration_logits=explore, two_player=bool(flags.get("two_player", False)))
         d = tree.dump()
         data = dict(meta=np.array([size, B, S, T, seed], np.int64), fill=np.float64(fill), discount=np.float32(discount),
                     last_states=st, root_logits=xp if explore else ex, root_value=v, root_var=u, beta=beta, gumbel=g,

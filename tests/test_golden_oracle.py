@@ -29,7 +29,7 @@ def test_oracle_reproduces_golden(oracle, name):
     assert np.array_equal(st, z["last_states"])
     explore = bool(flags.get("directed_exploration", False))
     act, aw, summ, tree = oracle.search(env, net, st, S, z["root_logits"], z["root_value"], z["root_var"], z["beta"], z["gumbel"],
-                                        discount=discount, use_exploration_logits=explore)
+                                        discount=discount, use_exploration_logits=explore, two_player=bool(flags.get("two_player", False)))
     assert np.array_equal(act, z["search_action"]) and np.array_equal(aw, z["search_action_weights"])
     d = tree.dump()
     for k in MG.TREE_INT + MG.TREE_F32:

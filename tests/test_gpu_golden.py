@@ -30,6 +30,11 @@ def _build_engine(eaz, kind, size, seed, fill):
         env = engine.EnvHandle.deepsea(size, am, device=0)
         net = engine.FCNet(env.ctx, size * size, 256, 2, params, state)
         return engine, env, net, 0.997
+    if kind == "connect4":
+        params, state = eaz.params.init_resnet_params(6, 7, 2, 7, 64, size, seed=seed)
+        state[eaz.params.RESNET_HASH_MODULE] = {"binary_set": eaz.params.init_hash_state(fill=fill, seed=seed)[eaz.params.HASH_MODULE]["binary_set"]}
+        env = engine.EnvHandle.connect4(device=0)
+        return engine, env, engine.ResNet(env.ctx, 6, 7, 2, 7, params, state, num_blocks=size), 0.997
     dims, params, state = subleq_setup(eaz, size, seed=seed, fill=fill)
     env = engine.EnvHandle.subleq(size, (1,), True, device=0)
     net = engine.FCNet(env.ctx, dims["in_dim"], 256, size, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
@@ -38,7 +43,7 @@ def _build_engine(eaz, kind, size, seed, fill):
 
 def _to_oracle_states(kind, size, dev_states):
     a = dev_states.cpu().numpy()
-    return a if kind == "deepsea" else subleq_device_to_oracle(a, size)
+    return subleq_device_to_oracle(a, size) if kind == "subleq" else a
 
 
 @pytest.mark.parametrize("name", sorted(MG.CASES))
@@ -47,7 +52,9 @@ def test_selfplay_and_tree_match_golden(eaz, torch, name):
     z = np.load(os.path.join(HERE, "golden", f"{name}.npz"))
     engine, env, net, discount = _build_engine(eaz, kind, size, seed, fill)
     explore = bool(flags.get("directed_exploration", False))
-    search = engine.Search(env, net, B, S, discount=discount, exploration=explore)
+    flags = dict(flags)
+    two_player = bool(flags.pop("two_player", False))
+    search = engine.Search(env, net, B, S, discount=discount, exploration=explore, two_players_game=two_player)
     st = env.init(B, key=seed)
     out = search.selfplay(st, T, key=1000 + seed, **flags)
     assert np.array_equal(out["action"].cpu().numpy(), z["sp_action"])
