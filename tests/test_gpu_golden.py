@@ -140,6 +140,31 @@ def test_subleq_interpreter_on_random_programs(oracle, eaz, torch, W, tasks, B):
     print(f"W={W}: {int(solved.sum())} of {B} random programs solved their task")
 
 
+@pytest.mark.parametrize("W,B,S", [(32, 12, 12), (64, 10, 10), (128, 9, 8), (256, 8, 8)])
+def test_wide_action_sets_selfplay_matches_oracle(oracle, eaz, torch, W, B, S):
+    """Every lanes-per-tree / actions-per-lane instantiation of the tree kernels (32x1, 64x1, 64x2, 64x4) with the matching FC
+    output widths (VALU fallback, 256-column layer 3) and LDS-resident Subleq memory: Subleq word_size 32 .. 256 self-play."""
+    from e_alphazero_amd import engine
+
+    dims, params, state = subleq_setup(eaz, W, seed=W + 1, fill=0.4)
+    env = engine.EnvHandle.subleq(W, (1, 3), True, device=0)
+    net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
+    oenv = oracle.OracleEnv.subleq(W, (1, 3), True)
+    onet = oracle.OracleNet(dims["in_dim"], 256, W, eaz.params.fc_weight_list(params), hash_off=dims["hash_off"],
+                            hash_len=dims["hash_len"], bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+    search = engine.Search(env, net, B, S, discount=0.97)
+    st = env.init(B, key=7)
+    ost = oenv.init(B, key=(7, 0))
+    assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost)
+    T = 3
+    out = search.selfplay(st, T, key=41)
+    ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(41, 0), discount=0.97)
+    assert np.array_equal(out["action"].cpu().numpy(), ref["action"])
+    assert np.array_equal(subleq_device_to_oracle(out["state"].cpu().numpy(), W), ref["state"])
+    for k in ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction", "q_values_epistemic_variance"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
+
+
 def test_empty_batches_are_no_ops(eaz, torch):
     """B = 0 through the C ABI: every batched entry point accepts an empty batch (null data pointers included)."""
     from e_alphazero_amd import engine
