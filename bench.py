@@ -28,11 +28,22 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+import socket  # noqa: E402
+import subprocess  # noqa: E402
 
-import e_alphazero_amd as eaz  # noqa: E402
-from e_alphazero_amd import engine, pool  # noqa: E402
+# numpy / torch / the engine are imported by run_rank() only: the self-launching parent of `--gpus N` must not touch the GPU
+np = torch = eaz = engine = pool = None
+
+
+def _imports():
+    global np, torch, eaz, engine, pool
+    import numpy as _np
+    import torch as _torch
+
+    import e_alphazero_amd as _eaz
+    from e_alphazero_amd import engine as _engine, pool as _pool
+
+    np, torch, eaz, engine, pool = _np, _torch, _eaz, _engine, _pool
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBPS = 8000.0        # MI355X_MICROARCH.md "HBM3E peak BW"
@@ -147,7 +158,55 @@ def build_workload(name, args, device, rank):
                 net_flops=net_flops, pmc_tag=pmc_tag, gather_kernel=gather_kernel, oracle=oracle)
 
 
-def main():
+def dry_run(args, world, rank):
+    """Everything of the N-rank path that needs no device: process group (gloo), one packed trajectory block per rank with the
+    workload's record layout, the all-gather, the barrier / max-over-ranks timing and the JSON line.  Not a measurement."""
+    import torch as _torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.join(ROOT, "e-alphazero_amd"))
+    import pool as _pool   # the package __init__ loads libeaz.so; the pooling helpers alone need only torch
+
+    w = WORKLOADS[args.workload]
+    B, T = args.batch or w["B"], args.selfplay_steps or w["T"]
+    state_bytes, A = {"c2": (16, 2), "c3": (336, 16), "c4": (80, 7)}[args.workload]
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = _torch.Generator().manual_seed(rank)
+    block = _torch.randint(0, 256, (T, B, _pool.record_bytes(state_bytes, A)), dtype=_torch.uint8, generator=g)
+    gathered = None
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if world > 1:
+            gathered = _pool.all_gather_trajectories(block, out=gathered)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ok = True
+    if world > 1:
+        tmax = _torch.tensor([dt], dtype=_torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        pooled = _pool.pooled_batch_major(gathered)           # [world * B, T, R], src/main.py:383-385
+        ok = tuple(pooled.shape) == (world * B, T, block.shape[2]) and bool(_torch.equal(pooled[rank * B:(rank + 1) * B], block.permute(1, 0, 2)))
+    if rank == 0:
+        print(json.dumps({"metric": w["metric"], "value": None, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (dry run)",
+                          "config": {"workload": f"dry run of {args.workload}", "global_batch": B * world,
+                                     "parallelism": f"batch-sharded x{world}, gloo all-gather of trajectories" if world > 1 else "single process"},
+                          "dry_run": "launch path + trajectory all-gather only, no device work: not a measurement",
+                          "pooled_block_ok": ok}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("dry run: pooled trajectory block mismatch")
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -159,13 +218,73 @@ def main():
     ap.add_argument("--selfplay-steps", type=int, default=0)
     ap.add_argument("--hash-fill", type=float, default=0.5, help="fraction of the novelty bit-set that is set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short C3 / C4 passes appended to the default C2 run")
     ap.add_argument("--cpu-sample-batch", type=int, default=0)
     ap.add_argument("--cpu-sample-steps", type=int, default=0)
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no device work: argument handling, the self-launch of N ranks, process-group set-up, the trajectory "
+                         "all-gather (gloo) and the JSON line only; `value` is null (used by the CPU test of the N > 1 path)")
+    return ap.parse_args(argv)
 
+
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start N fresh rank processes (one per GPU) with the torchrun environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and wait for them.  Runs before this process has imported torch
+    or touched the GPU; the ranks are children (never an exec of a process that initialised HIP).  Rank 0 prints the JSON line."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:   # a rank failed: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(self_launch(args.gpus, argv))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']} (launch with "
+                         f"--nproc-per-node {args.gpus}, or without torchrun: bench.py starts the ranks itself)")
+    run_rank(args)
+
+
+def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    _imports()
     ndev = torch.cuda.device_count()
     if ndev == 0:
         raise SystemExit("bench.py needs a ROCm device: the engine has no CPU path")
@@ -176,7 +295,6 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:

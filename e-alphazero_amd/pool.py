@@ -2,9 +2,13 @@
 (src/main.py:383-385) before `buffer_fn.add`.
 
 Self-play shards embarrassingly (one process per GPU, no collective inside the search); after each selfplay() call
-every rank contributes its [T, B_local, ...] block and receives the pooled [T, world * B_local, ...] block with ONE
+every rank contributes its [T, B_local, R] block and receives every rank's block, [world, T, B_local, R], with ONE
 all-gather (RCCL over xGMI on MI355X, gloo in the CPU tests).  All SelfplayOutput fields are packed into a single
 uint8 record per (t, b) so that it is one collective, not six.
+
+Landing layout: the reference's pmap output is [devices, T, B_local, ...] and `jnp.concatenate(jnp.swapaxes(x, 1, 2))`
+(src/main.py:383-385) hands flashbax the batch-major sequence block [devices * B_local, T, ...], device-major along the batch
+axis.  `pooled_batch_major` is that view of the all-gather output; `pooled_view` is the time-major [T, world * B_local, R] one.
 """
 from __future__ import annotations
 
@@ -44,20 +48,34 @@ def unpack(block: torch.Tensor, state_bytes: int, num_actions: int) -> dict:
 
 
 def all_gather_trajectories(block: torch.Tensor, out: torch.Tensor | None = None, group=None) -> torch.Tensor:
-    """block: uint8 [T, B, R] of this rank -> pooled uint8 [T, world*B, R] (rank-major along the batch axis, like the
-    reference's `states.reshape(B_total, T, ...)` over devices)."""
+    """block: uint8 [T, B, R] of this rank -> uint8 [world, T, B, R]: the blocks of all ranks, rank-major (the layout of the
+    reference's pmap output, [devices, T, B_local, ...]).  `out` (same shape) is reused when given."""
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     T, B, R = block.shape
     if out is None:
         out = torch.empty(world, T, B, R, dtype=torch.uint8, device=block.device)
+    assert tuple(out.shape) == (world, T, B, R) and out.dtype == torch.uint8 and out.is_contiguous(), "all_gather_trajectories: `out` must be a contiguous uint8 [world, T, B, R]"
     # concatenation-along-dim-0 form: accepted by both the RCCL and the gloo backend
     dist.all_gather_into_tensor(out.view(world * T, B, R), block, group=group)
     return out
 
 
 def pooled_view(gathered: torch.Tensor) -> torch.Tensor:
-    """[world, T, B, R] -> [T, world*B, R]"""
+    """[world, T, B, R] -> time-major [T, world*B, R]"""
     W, T, B, R = gathered.shape
     return gathered.permute(1, 0, 2, 3).reshape(T, W * B, R)
+
+
+def pooled_batch_major(gathered: torch.Tensor) -> torch.Tensor:
+    """[world, T, B, R] -> [world*B, T, R]: `jnp.concatenate(jnp.swapaxes(x, 1, 2))` of src/main.py:383-385, the sequence
+    layout the replay buffer is fed with (rank-major along the batch axis)."""
+    W, T, B, R = gathered.shape
+    return gathered.permute(0, 2, 1, 3).reshape(W * B, T, R)
+
+
+def unpack_batch_major(block: torch.Tensor, state_bytes: int, num_actions: int) -> dict:
+    """uint8 [B_total, T, R] -> SelfplayOutput dict of [B_total, T, ...] tensors."""
+    out = unpack(block.permute(1, 0, 2), state_bytes, num_actions)
+    return {k: v.transpose(0, 1).contiguous() for k, v in out.items()}

@@ -1,0 +1,57 @@
+"""bench.py's N > 1 entry: `python bench.py --gpus N` (the driver's form) must start N ranks itself when it is not already
+running under torchrun, before anything touches the GPU, and rank 0 must report n_gpus = N.  Runs on CPU through --dry-run
+(launch path + gloo process group + the trajectory all-gather; no device work, `value` null)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    return env
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"expected exactly one JSON line, got {len(lines)}:\n{stdout}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("n", [1, 2])
+def test_self_launch_reports_n_gpus(n):
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--steps", "2", "--warmup", "0", "--dry-run", "--batch", "8",
+                        "--selfplay-steps", "3"], env=_clean_env(), capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = _json_line(r.stdout)
+    assert res["n_gpus"] == n and res["steps"] == 2 and res["value"] is None and res["pooled_block_ok"] is True
+    assert res["config"]["global_batch"] == 8 * n and res["scaling"] == "weak"
+
+
+@pytest.mark.timeout(180)
+def test_torchrun_environment_is_honoured():
+    """Under torchrun (WORLD_SIZE set) bench.py must not fan out again, and --gpus must agree with the world size."""
+    env = dict(_clean_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "1", "--dry-run", "--batch", "4"], env=env,
+                       capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _json_line(r.stdout)["n_gpus"] == 1
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--steps", "1", "--dry-run", "--batch", "4"], env=env,
+                       capture_output=True, text=True, timeout=170)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+@pytest.mark.timeout(180)
+def test_failed_rank_fails_the_launch():
+    """A rank that dies must take the launch down with a non-zero exit code instead of leaving the others in a collective."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--dry-run", "--batch", "-1"], env=_clean_env(),
+                       capture_output=True, text=True, timeout=170)
+    assert r.returncode != 0

@@ -40,6 +40,13 @@ def _worker(rank, world, port, T, B, SB, A, q):
         ref = _fake_output(r, T, B, SB, A)
         for k, v in ref.items():
             ok &= bool(torch.equal(pooled[k][:, r * B:(r + 1) * B], v))
+    # replay landing layout (src/main.py:383-385): [world * B, T, ...], rank-major along the batch axis
+    bm = pool.unpack_batch_major(pool.pooled_batch_major(gathered), SB, A)
+    for r in range(world):
+        ref = _fake_output(r, T, B, SB, A)
+        for k, v in ref.items():
+            ok &= bool(torch.equal(bm[k][r * B:(r + 1) * B], v.transpose(0, 1)))
+    ok &= tuple(bm["state"].shape) == (world * B, T, SB) and tuple(bm["action"].shape) == (world * B, T)
     q.put((rank, ok, tuple(pooled["state"].shape)))
     dist.barrier()
     dist.destroy_process_group()
