@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EAZ_LIB", os.path.join(_HERE, "libeaz.so"))  # EAZ_LIB: diagnostic builds only
 
-K_NAMES = ("tree", "gather", "hash", "net", "misc")
+K_NAMES = ("tree", "gather", "hash", "net", "misc", "search")
 
 
 class SearchOpts(C.Structure):

@@ -16,6 +16,7 @@
 #include "net_fc.hpp"
 #include "net_resnet.hpp"
 #include "search_kernels.hpp"
+#include "search_persist.hpp"
 
 using namespace eaz;
 
@@ -72,6 +73,7 @@ struct eaz_net {
     float* d_b[12];
     size_t bitset_bytes;
     uint32_t* d_ztab;                     // NetDev::ztab storage
+    uint32_t* d_hot_index;                // NetDev::hot_index storage
     unsigned long long* d_kstep_counter;  // executed layer-1 k-steps (profiling only; nullptr = off)
     unsigned long long* d_kstep_storage;
 };
@@ -120,6 +122,12 @@ struct eaz_search {
     const void* graph_states;  // the captured graph is valid for this d_states pointer / these flags
     int graph_flags;
     int pending_expand;  // simulation whose expand+backward has not run yet (-1: none)
+    // persistent search (search_persist.hpp): one launch runs all S simulations of 16 trees per workgroup in LDS
+    int persist_ok;      // DeepSea + FC network + 2 actions + the trees of a workgroup fit into LDS
+    int persist_lds;     // dynamic LDS bytes of that launch
+    int clear_pending;   // eaz_search_begin left the global tree arrays uncleared (the persistent kernel rewrites all of them)
+    int sims_done;       // simulations run since eaz_search_begin
+    unsigned long long* d_stamps;
 };
 
 extern "C" int eaz_ctx_create(int device, eaz_ctx** out) {
@@ -365,6 +373,29 @@ extern "C" int eaz_net_create_fc(eaz_ctx* ctx, int in_dim, int hidden, int num_a
         HIP_OK(hipMalloc(&n->d_ztab, zt.size() * sizeof(uint32_t)));
         HIP_OK(hipMemcpy(n->d_ztab, zt.data(), zt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         n->dev.ztab = n->d_ztab;
+        // get_indices() (hashes.py:199-229) of every one-hot row: lane q holds the stripe with the 1.0f (bitcast, :207) at position n1,
+        // the other lanes see zero stripes only; merge (:184-187), + stripe count (:226), avalanche (:190-197), top hash_bits (:229)
+        const uint32_t P3 = 0xC2B2AE3Du;
+        auto rotl = [](uint32_t x, int r) { return (x << r) | (x >> (32 - r)); };
+        std::vector<uint32_t> hi(static_cast<size_t>(in_dim));
+        for (int h = 0; h < in_dim; ++h) {
+            uint32_t acc[4];
+            for (int i = 0; i < 4; ++i) acc[i] = zt[static_cast<size_t>(i) * (L + 1) + L];
+            const int hh = h - hash_off;
+            if (hh >= 0 && hh < hash_len) {
+                const int q = hh / L, n1 = hh - q * L;
+                uint32_t x = rotl(zt[static_cast<size_t>(q) * (L + 1) + n1] + 0x3F800000u * P2, 13) * P1;
+                for (int k = n1 + 1; k < L; ++k) x = rotl(x, 13) * P1;
+                acc[q] = x;
+            }
+            uint32_t v = rotl(acc[0], 1) + rotl(acc[1], 7) + rotl(acc[2], 12) + rotl(acc[3], 18);
+            v += static_cast<uint32_t>(L);
+            v ^= v >> 15; v *= P2; v ^= v >> 13; v *= P3; v ^= v >> 16;
+            hi[h] = hash_bits >= 32 ? v : v >> (32 - hash_bits);
+        }
+        HIP_OK(hipMalloc(&n->d_hot_index, hi.size() * sizeof(uint32_t)));
+        HIP_OK(hipMemcpy(n->d_hot_index, hi.data(), hi.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        n->dev.hot_index = n->d_hot_index;
     }
     if (in_dim > 256 * kFcMaxBlocks) return fail("observation size %d exceeds the FC kernel's limit %d", in_dim, 256 * kFcMaxBlocks);
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_forward_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFcLdsBytes));
@@ -392,6 +423,7 @@ extern "C" int eaz_net_create_resnet(eaz_ctx* ctx, int H, int W, int Cin, int C,
     n->ctx = ctx;
     n->kind = 1;
     n->d_ztab = nullptr;
+    n->d_hot_index = nullptr;
     std::memset(&n->dev, 0, sizeof n->dev);
     std::memset(&n->rdev, 0, sizeof n->rdev);
     for (int l = 0; l < 12; ++l) { n->d_w[l] = nullptr; n->d_b[l] = nullptr; }
@@ -455,6 +487,7 @@ extern "C" int eaz_net_destroy(eaz_net* n) {
     for (int l = 0; l < 12; ++l) { if (n->d_w[l]) (void)hipFree(n->d_w[l]); if (n->d_b[l]) (void)hipFree(n->d_b[l]); }
     (void)hipFree(n->dev.bitset);
     if (n->d_ztab) (void)hipFree(n->d_ztab);
+    if (n->d_hot_index) (void)hipFree(n->d_hot_index);
     (void)hipFree(n->d_kstep_storage);
     delete n;
     return 0;
@@ -498,6 +531,7 @@ static int g_fused_leaf = [] { const char* e = std::getenv("EAZ_FUSED_LEAF"); re
 
 static int g_tree_block = [] { const char* e = std::getenv("EAZ_TREE_BLOCK"); return e ? std::atoi(e) : 64; }();
 static int g_tree_spread = [] { const char* e = std::getenv("EAZ_TREE_SPREAD"); return e ? std::atoi(e) : 0; }();  // 0 = automatic
+static int g_persist = [] { const char* e = std::getenv("EAZ_PERSIST"); return e ? std::atoi(e) : 1; }();
 
 extern "C" int eaz_tune_set(int knob, int value) {
     if (knob == EAZ_TUNE_TREE_BLOCK) {
@@ -508,6 +542,10 @@ extern "C" int eaz_tune_set(int knob, int value) {
     if (knob == EAZ_TUNE_TREE_SPREAD) {
         ARG_OK(value == 0 || value == 1 || value == 2 || value == 4 || value == 8);
         g_tree_spread = value;
+        return 0;
+    }
+    if (knob == EAZ_TUNE_PERSIST) {
+        g_persist = value != 0;
         return 0;
     }
     if (knob == EAZ_TUNE_FC_TILE) {
@@ -696,6 +734,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     s->ctx = ctx; s->env = env; s->net = net; s->opts = *opts;
     s->B = B; s->S = opts->num_simulations; s->N = s->S + 1; s->A = env->dev.A;
     s->prof_on = 0; s->step_graph = nullptr; s->graph_states = nullptr; s->graph_flags = -1; s->pending_expand = -1;
+    s->persist_ok = 0; s->persist_lds = 0; s->clear_pending = 0; s->sims_done = 0; s->d_stamps = nullptr;
     HIP_OK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&s->main, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
@@ -756,6 +795,20 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     t.fuse_env = 0;
     s->fuse_leaf = g_fused_leaf && env->dev.kind == EAZ_ENV_DEEPSEA && net->kind == 0 && net->dev.ztab != nullptr;
     if (s->fuse_leaf) HIP_OK(hipMemset(s->d_next_legal, 1, static_cast<size_t>(B) * A));  // legal_action_mask all true (deep_sea.py:19)
+    {
+        // persistent search: DeepSea + FC net, two actions, node ids / grid coordinates inside the packed LDS fields, and the 16 trees of a
+        // workgroup + the forward tiles inside the CU's 160 KiB
+        const PersistLds L = persist_lds(s->N, s->S, env->dev.G);
+        s->persist_lds = L.total;
+        s->persist_ok = s->fuse_leaf && A == kPsA && s->N < 32768 && env->dev.G < 4096 && net->dev.in_dim == env->dev.G * env->dev.G &&
+                        mc >= 1 && L.total <= 160 * 1024;
+        if (s->persist_ok)
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(search_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+#ifdef EAZ_FC_STAMPS
+        DALLOC(s->d_stamps, 256 * 32);
+        HIP_OK(hipMemset(s->d_stamps, 0, 256 * 32 * sizeof(unsigned long long)));
+#endif
+    }
     *out = s;
     return 0;
 }
@@ -785,9 +838,14 @@ extern "C" int eaz_search_begin(eaz_search* s, const float* d_prior_logits, cons
     hipStream_t st = S(stream);
     {
         ProfScope ps(s, EAZ_K_MISC, st);
-        const long bna = static_cast<long>(s->B) * s->N * s->A;
-        tree_clear_kernel<<<cdiv(bna, 256) < 4096 ? cdiv(bna, 256) : 4096, 256, 0, st>>>(s->tree);
-        LAUNCH_OK();
+        // The persistent kernel rewrites every tree array, so its searches skip the 24 MB clear; a caller that steps the search
+        // simulation by simulation instead gets the (root-preserving) clear from ensure_cleared() before its first tree kernel.
+        s->clear_pending = s->persist_ok && g_persist;
+        if (!s->clear_pending) {
+            const long bna = static_cast<long>(s->B) * s->N * s->A;
+            tree_clear_kernel<<<cdiv(bna, 256) < 4096 ? cdiv(bna, 256) : 4096, 256, 0, st>>>(s->tree, 0);
+            LAUNCH_OK();
+        }
 #define CALL_ROOT(L, P)                                                                                              \
     tree_root_kernel<L, P><<<tree_grid(s), 256, 0, st>>>(s->tree, d_prior_logits, d_value, d_value_var,                \
                                                          static_cast<const char*>(d_root_states), d_beta, d_invalid, d_gumbel)
@@ -796,6 +854,31 @@ extern "C" int eaz_search_begin(eaz_search* s, const float* d_prior_logits, cons
         LAUNCH_OK();
     }
     s->pending_expand = -1;
+    s->sims_done = 0;
+    return 0;
+}
+
+static int ensure_cleared(eaz_search* s, hipStream_t st) {
+    if (!s->clear_pending) return 0;
+    ProfScope ps(s, EAZ_K_MISC, st);
+    const long bna = static_cast<long>(s->B) * s->N * s->A;
+    tree_clear_kernel<<<cdiv(bna, 256) < 4096 ? cdiv(bna, 256) : 4096, 256, 0, st>>>(s->tree, 1);
+    LAUNCH_OK();
+    s->clear_pending = 0;
+    return 0;
+}
+
+static int persist_launch(eaz_search* s, hipStream_t st) {
+    PersistArgs pa;
+    pa.t = s->tree;
+    pa.t.fused_rf = 1;
+    pa.net = s->net->dev;
+    pa.env = s->env->dev;
+    pa.head[0] = 0; pa.head[1] = 1; pa.head[2] = s->opts.exploration ? 3 : 2;  // context.py:132
+    pa.amap_lds = s->env->dev.G * s->env->dev.G <= kPsAmapMax;
+    pa.stamps = s->d_stamps;
+    search_persist_kernel<<<cdiv(s->B, kPsTrees), kPsThreads, s->persist_lds, st>>>(pa);
+    LAUNCH_OK();
     return 0;
 }
 
@@ -890,14 +973,17 @@ static int recurrent_launch(eaz_search* s, hipStream_t st) {
 extern "C" int eaz_search_simulate(eaz_search* s, int sim, void* stream) {
     ARG_OK(s && sim >= 0 && sim < s->S);
     hipStream_t st = S(stream);
+    int rc = ensure_cleared(s, st);
+    if (rc) return rc;
     s->tree.fused_rf = 1;
     s->tree.fuse_env = s->fuse_leaf ? 1 + s->env->dev.kind : 0;
     int mode = kTreeSelect | (s->pending_expand >= 0 ? kTreeExpand : 0);
-    int rc = tree_step_launch(s, sim, mode, st);
+    rc = tree_step_launch(s, sim, mode, st);
     if (rc) return rc;
     rc = recurrent_launch(s, st);
     if (rc) return rc;
     s->pending_expand = sim;
+    s->sims_done += 1;
     return 0;
 }
 
@@ -910,6 +996,15 @@ static int flush_expand(eaz_search* s, hipStream_t st) {
 
 extern "C" int eaz_search_run(eaz_search* s, void* stream) {
     ARG_OK(s != nullptr);
+    if (s->persist_ok && g_persist && s->clear_pending && s->sims_done == 0 && s->pending_expand < 0) {
+        // all S simulations of every tree in one launch, trees resident in LDS (search_persist.hpp)
+        ProfScope ps(s, EAZ_K_SEARCH, S(stream));
+        int rc = persist_launch(s, S(stream));
+        if (rc) return rc;
+        s->clear_pending = 0;
+        s->sims_done = s->S;
+        return 0;
+    }
     for (int sim = 0; sim < s->S; ++sim) {
         int rc = eaz_search_simulate(s, sim, stream);
         if (rc) return rc;
@@ -920,7 +1015,9 @@ extern "C" int eaz_search_run(eaz_search* s, void* stream) {
 extern "C" int eaz_search_finish(eaz_search* s, int32_t* d_action, float* d_action_weights, void* stream) {
     ARG_OK(s != nullptr);
     hipStream_t st = S(stream);
-    int rc = flush_expand(s, st);
+    int rc = ensure_cleared(s, st);
+    if (rc) return rc;
+    rc = flush_expand(s, st);
     if (rc) return rc;
     ProfScope ps(s, EAZ_K_MISC, st);
 #define CALL_FIN(L, P) tree_finish_kernel<L, P><<<tree_grid(s), 256, 0, st>>>(s->tree, d_action, d_action_weights)
@@ -934,7 +1031,9 @@ extern "C" int eaz_search_summary(eaz_search* s, float* d_value, float* d_value_
                                   float* d_visit_counts, float* d_visit_probs, void* stream) {
     ARG_OK(s != nullptr);
     hipStream_t st = S(stream);
-    int rc = flush_expand(s, st);
+    int rc = ensure_cleared(s, st);
+    if (rc) return rc;
+    rc = flush_expand(s, st);
     if (rc) return rc;
     ProfScope ps(s, EAZ_K_MISC, st);
     tree_summary_kernel<<<cdiv(static_cast<long>(s->B) * s->A, 256), 256, 0, st>>>(s->tree, d_value, d_value_std, d_qvalues,
@@ -947,8 +1046,10 @@ extern "C" int eaz_search_select(eaz_search* s, int sim, int32_t* d_parent, int3
     ARG_OK(s && sim >= 0 && sim < s->S);
     hipStream_t st = S(stream);
     if (s->pending_expand >= 0) return fail("eaz_search_select: simulation %d has not been expanded yet", s->pending_expand);
+    int rc = ensure_cleared(s, st);
+    if (rc) return rc;
     s->tree.fuse_env = 0;  // the caller's recurrent_fn steps the environment
-    int rc = tree_step_launch(s, sim, kTreeSelect, st);
+    rc = tree_step_launch(s, sim, kTreeSelect, st);
     if (rc) return rc;
     const size_t n = sizeof(int32_t) * s->B;
     if (d_parent) HIP_OK(hipMemcpyAsync(d_parent, s->tree.sim_parent, n, hipMemcpyDeviceToDevice, st));
@@ -961,6 +1062,10 @@ extern "C" int eaz_search_expand(eaz_search* s, int sim, const float* d_reward, 
                                  const float* d_prior_logits, const float* d_value, const float* d_value_var, void* stream) {
     ARG_OK(s && d_reward && d_reward_var && d_discount && d_prior_logits && d_value && d_value_var);
     TreeDev& t = s->tree;
+    {
+        int rc0 = ensure_cleared(s, S(stream));
+        if (rc0) return rc0;
+    }
     t.fused_rf = 0;
     t.rf_reward = d_reward; t.rf_reward_var = d_reward_var; t.rf_discount = d_discount;
     t.rf_logits = d_prior_logits; t.rf_value = d_value; t.rf_value_var = d_value_var;
@@ -1300,6 +1405,11 @@ extern "C" int eaz_random_play(eaz_env* env, int B, int T, uint64_t key, void* d
 extern "C" __attribute__((visibility("default"))) int eaz_diag_tree_stamps(unsigned long long* h_out /* [1024*8] */) {
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_tree_stamps), sizeof(unsigned long long) * 1024 * 8));
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int eaz_diag_persist_stamps(eaz_search* s, unsigned long long* h_out /* [256*32] */) {
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(h_out, s->d_stamps, sizeof(unsigned long long) * 256 * 32, hipMemcpyDeviceToHost));
     return 0;
 }
 extern "C" __attribute__((visibility("default"))) int eaz_diag_fc_stamps(unsigned long long* h_out /* [1024*8] */) {

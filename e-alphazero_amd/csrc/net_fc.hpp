@@ -4,8 +4,10 @@
 // Numerics contract (DESIGN.md "FC forward"): hk.Linear is y = x @ w + b with, per output element,
 //     acc = +0;  acc = fmaf(x[k], w[k][j], acc) for k = 0..K-1;  y = acc + b[j]
 // which is bit-for-bit what a chain of v_mfma_f32_16x16x4_f32 instructions computes (f32 in, f32 accumulate, one
-// rounding per product, k ascending).  Layers 1 and 2 of every head run on that MFMA; layer 3 (out = 1 or A) is a
-// VALU fmaf chain in the same order.  tanh is det_tanh (dmath.hpp).
+// rounding per product, k ascending).  Layers 1 and 2 of every head are single chains.  Layer 3 (K = 256 hidden units) is FOUR
+// chains, one per quarter of k (the 64 hidden columns a wavefront owns), each from +0, combined as ((c0 + c1) + (c2 + c3)) + b[j]
+// (oracle: o_linear_parts): every wavefront runs the chain over the columns it has just produced instead of one wavefront running
+// a 64-deep dependent MFMA chain while three wait.  tanh is det_tanh (dmath.hpp).
 //
 // Two kernels with the same numerics: fc16_forward_kernel (16 rows per workgroup, further down; the default whenever its
 // whole grid is resident at once) and fc_forward_kernel (64 rows per workgroup, described here; large batches).
@@ -36,6 +38,7 @@ struct NetDev {
     int hash_off, hash_len, hash_bits;
     uint8_t* bitset;  // device, 2^(hash_bits-3) bytes
     const uint32_t* ztab;  // device [4][hash_len/4 + 1]: accumulator of hash lane i after n all-zero stripes (one-hot fast path)
+    const uint32_t* hot_index;  // device [in_dim]: get_indices() of the row that is zero except obs[h] = 1 (hashes.py:162-229)
 };
 
 struct NetOut {
@@ -401,13 +404,19 @@ __global__ void __launch_bounds__(256, 1) fc_forward_kernel(NetDev net, const ui
         }
     };
     if (w3_lds) {
-        floatx4 a3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 8
-        for (int ks = 0; ks < kFcH / 4; ++ks) {
-            const float av = H2[(4 * ks + kq) * kFcLD + 16 * wave + r];
-            const float bv = W3s[(4 * ks + kq) * kFcW3Cols + r];
-            a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, a3, 0, 0, 0);
+        // four independent chains of 16 k-steps (quarters of k), then ((c0 + c1) + (c2 + c3))
+        floatx4 aq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) aq[q] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+        for (int ks = 0; ks < kFcH / 16; ++ks) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 4 * (16 * q + ks) + kq;
+                aq[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(H2[k * kFcLD + 16 * wave + r], W3s[k * kFcW3Cols + r], aq[q], 0, 0, 0);
+            }
         }
+        const floatx4 a3 = (aq[0] + aq[1]) + (aq[2] + aq[3]);
         if (r < No) {
             const float bo = b3[r];
 #pragma unroll
@@ -418,7 +427,28 @@ __global__ void __launch_bounds__(256, 1) fc_forward_kernel(NetDev net, const ui
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[s][t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-        mma_block<false>(acc, H2, ~0ull, W3, kFcH, 0, col, r, kq);
+        {
+            // quarters of k as separate chains: (c0 + c1) + (c2 + c3)
+            floatx4 c1[4][4], t01[4][4];
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                floatx4 (&dst)[4][4] = (q & 1) ? c1 : acc;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dst[s][t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+                mma_block<false>(dst, H2, 0xFFFFull << (16 * q), W3, kFcH, 0, col, r, kq);
+                if (q & 1) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const floatx4 sum = acc[s][t] + c1[s][t];
+                            if (q == 1) t01[s][t] = sum; else acc[s][t] = t01[s][t] + sum;
+                        }
+                }
+            }
+        }
         // only policy heads can have 256 outputs: plain stores (keeps the 64 epilogue sites free of the tanh code)
         float* dst = head == 2 ? out.exploit : out.explore;
 #pragma unroll
@@ -435,10 +465,15 @@ __global__ void __launch_bounds__(256, 1) fc_forward_kernel(NetDev net, const ui
     } else {
         const int row = tid & 63;
         for (int o = wave; o < No; o += 4) {
-            float z = 0.0f;
+            float zq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float z = 0.0f;
 #pragma unroll 16
-            for (int k = 0; k < kFcH; ++k) z = __builtin_fmaf(H2[k * kFcLD + row], W3[static_cast<long>(k) * No + o], z);
-            emit(row, o, z + b3[o]);
+                for (int k = q * (kFcH / 4); k < (q + 1) * (kFcH / 4); ++k) z = __builtin_fmaf(H2[k * kFcLD + row], W3[static_cast<long>(k) * No + o], z);
+                zq[q] = z;
+            }
+            emit(row, o, ((zq[0] + zq[1]) + (zq[2] + zq[3])) + b3[o]);
         }
     }
     EAZ_STAMP(6);
@@ -530,7 +565,9 @@ constexpr int kF16HBytes = kF16HFloats * 4;              // 17 408
 // workgroups per CU -- the novelty workgroups of the one-hot launch then run beside the three forward workgroups of a CU)
 constexpr int kF16LdsBase = 2 * kF16HBytes + kFcMaskBytes;
 __host__ __device__ inline int f16_w3ld(int A) { return A <= kFcW3Cols ? ((A + 3) & ~3) : 0; }
-__host__ __device__ inline int f16_lds_bytes(int A) { return kF16LdsBase + kFcH * f16_w3ld(A) * 4; }
+// + the layer-3 partial sums of the narrow heads: [4 waves][16 rows][w3ld] floats
+__host__ __device__ inline int f16_part_off(int A) { return kF16LdsBase + kFcH * f16_w3ld(A) * 4; }
+__host__ __device__ inline int f16_lds_bytes(int A) { return f16_part_off(A) + 4 * 16 * f16_w3ld(A) * 4; }
 static_assert(kF16M * kFcKC <= kF16HBytes, "the observation chunk (16 rows x 1024 inputs, uint8) aliases the H2 tile");
 
 __device__ __forceinline__ int h16_off(int k, int row) { return k * 16 + (k >> 2) * 4 + row; }
@@ -669,27 +706,13 @@ __global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn i
     const int tid = threadIdx.x;
     if constexpr (SRC == 2) {
         if (static_cast<int>(blockIdx.x) >= n_fc_blocks) {
-            // ---- novelty lookup of one-hot observations (hashes.py:162-229 on a row that is zero except obs[hot] = 1) ----
+            // ---- novelty lookup of one-hot observations (hashes.py:23-38 with the index of hashes.py:162-229 on a row that is zero except
+            // obs[hot] = 1) ----
             const int b = (blockIdx.x - n_fc_blocks) * 256 + tid;
             if (b >= B || !in.novelty) return;
-            const uint32_t P1 = 0x9E3779B1u, P2 = 0x85EBCA77u, P3 = 0xC2B2AE3Du;
-            const int L = net.hash_len >> 2;
-            const int h = in.hot[b] - net.hash_off;
-            const bool inside = h >= 0 && h < net.hash_len;
-            const int q = inside ? h / L : -1, n1 = inside ? h - q * L : 0;
-            uint32_t acc[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = in.ztab[i * (L + 1) + (i == q ? n1 : L)];
-            if (inside) {
-                const uint32_t sel = q == 0 ? acc[0] : (q == 1 ? acc[1] : (q == 2 ? acc[2] : acc[3]));
-                uint32_t a = rotl32(sel + 0x3F800000u * P2, 13) * P1;  // the stripe holding 1.0f (bitcast, hashes.py:207)
-                for (int n = n1 + 1; n < L; ++n) a = xxh_zero_round(a);
-                if (q == 0) acc[0] = a; else if (q == 1) acc[1] = a; else if (q == 2) acc[2] = a; else acc[3] = a;
-            }
-            uint32_t hh = rotl32(acc[0], 1) + rotl32(acc[1], 7) + rotl32(acc[2], 12) + rotl32(acc[3], 18);  // :184-187
-            hh += static_cast<uint32_t>(L);                                                                 // :226
-            hh ^= hh >> 15; hh *= P2; hh ^= hh >> 13; hh *= P3; hh ^= hh >> 16;                             // :190-197
-            const uint32_t index = hh >> (32 - net.hash_bits);                                              // :229
+            int h = in.hot[b];
+            h = h < 0 ? 0 : (h >= net.in_dim ? net.in_dim - 1 : h);
+            const uint32_t index = net.hot_index[h];  // tabulated once per network: the index depends on `hot` only
             const bool seen = net.bitset ? ((net.bitset[index >> 3] >> (index & 7u)) & 1u) != 0 : false;
             in.novelty[b] = (seen ? 0.0f : 1.0f) * net.nov_scale;
             return;
@@ -795,7 +818,9 @@ __global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn i
     mma16_block<false>(acc, H1, ~0ull, W2, kFcH, 0, col, r, kq);
     EAZ_STAMP(2);
     store_hidden16(H2, acc, b2, n0, r, kq);
-    __syncthreads();
+    // narrow heads read back only the columns (and layer-3 weight rows) their own wave wrote: DS operations of a wave execute in order
+    if (net.A <= kFcW3Cols) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else __syncthreads();
     EAZ_STAMP(3);
 
     // ---------------- layer 3 + head activation ----------------
@@ -814,23 +839,51 @@ __global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn i
         }
     };
     if (narrow) {
-        if (wave != 0) return;
+        // every wave: the chain over the 64 hidden columns it owns (quarter `wave` of k), 16 dependent MFMAs; the four partial sums
+        // meet in LDS and wave 0 adds them as ((c0 + c1) + (c2 + c3)) + b
+        float* part = reinterpret_cast<float*>(lds + f16_part_off(net.A));
         floatx4 a3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
         // lanes beyond the staged columns read column 0: their output columns are never emitted (r < No below)
-        const float* w3p = W3s + kq * w3ld + (r < w3ld ? r : 0);
-#pragma unroll 16
-        for (int ks = 0; ks < kFcH / 4; ++ks)
-            a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(H2[h16_off(4 * ks + kq, r)], w3p[(4 * ks) * w3ld], a3, 0, 0, 0);
+        const float* w3p = W3s + (n0 + kq) * w3ld + (r < w3ld ? r : 0);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+            a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(H2[h16_off(n0 + 4 * ks + kq, r)], w3p[(4 * ks) * w3ld], a3, 0, 0, 0);
+        if (r < w3ld) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) part[(wave * 16 + 4 * kq + reg) * w3ld + r] = a3[reg];
+        }
+        __syncthreads();
+        if (wave != 0) return;
         if (r < No) {
             const float bo = b3[r];
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) emit(4 * kq + reg, r, a3[reg] + bo);
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = 4 * kq + reg;
+                const float c0 = part[(0 * 16 + row) * w3ld + r], c1 = part[(1 * 16 + row) * w3ld + r];
+                const float c2 = part[(2 * 16 + row) * w3ld + r], c3 = part[(3 * 16 + row) * w3ld + r];
+                emit(row, r, ((c0 + c1) + (c2 + c3)) + bo);
+            }
         }
         EAZ_STAMP(4);
     } else if (No == kFcH) {
+        {
+            // quarters of k as separate chains: (c0 + c1) + (c2 + c3)
+            floatx4 c1[4], t01[4];
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                floatx4 (&dst)[4] = (q & 1) ? c1 : acc;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-        mma16_block<false>(acc, H2, ~0ull, W3, kFcH, 0, col, r, kq);
+                for (int t = 0; t < 4; ++t) dst[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+                mma16_block<false>(dst, H2, 0xFFFFull << (16 * q), W3, kFcH, 0, col, r, kq);
+                if (q & 1) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const floatx4 sum = acc[t] + c1[t];
+                        if (q == 1) t01[t] = sum; else acc[t] = t01[t] + sum;
+                    }
+                }
+            }
+        }
         float* dst = head == 2 ? out.exploit : out.explore;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -844,14 +897,19 @@ __global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn i
     } else {
         const int row = tid & 15;
         for (int o = tid >> 4; o < No; o += 16) {
-            float z = 0.0f;
+            float zq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float z = 0.0f;
 #pragma unroll 16
-            for (int k = 0; k < kFcH; ++k) z = __builtin_fmaf(H2[h16_off(k, row)], W3[static_cast<long>(k) * No + o], z);
-            emit(row, o, z + b3[o]);
+                for (int k = q * (kFcH / 4); k < (q + 1) * (kFcH / 4); ++k) z = __builtin_fmaf(H2[h16_off(k, row)], W3[static_cast<long>(k) * No + o], z);
+                zq[q] = z;
+            }
+            emit(row, o, ((zq[0] + zq[1]) + (zq[2] + zq[3])) + b3[o]);
         }
     }
-    // narrow heads: only the layer-3 wave gets here; otherwise wave 0 reports for the workgroup
-    if (kstep_counter && lane == 0 && (narrow || wave == 0) && executed) atomicAdd(kstep_counter, executed);
+    // narrow heads: only wave 0 gets here; otherwise wave 0 reports for the workgroup
+    if (kstep_counter && lane == 0 && wave == 0 && executed) atomicAdd(kstep_counter, executed);
 }
 
 }  // namespace eaz

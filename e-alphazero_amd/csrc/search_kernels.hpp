@@ -10,26 +10,32 @@
 namespace eaz {
 
 // mctx instantiate_tree_from_root (A.3): ints -1 / 0, floats 0.  Grid-stride over B*N*A.
-__global__ void __launch_bounds__(256) tree_clear_kernel(TreeDev t) {
+// keep_root: the root node (written by tree_root_kernel before this launch) is left alone -- the deferred clear of a search whose
+// eaz_search_begin skipped it (eaz_api.hip ensure_cleared).
+__global__ void __launch_bounds__(256) tree_clear_kernel(TreeDev t, int keep_root) {
     const long bn = static_cast<long>(t.B) * t.N, bna = bn * t.A;
     const long stride = static_cast<long>(gridDim.x) * blockDim.x;
     for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < bna; i += stride) {
+        // i indexes the [B,N,A] arrays, and (while i < B*N) the [B,N] arrays as well
+        const bool root_row = keep_root && (i / t.A) % t.N == 0;
         t.children_index[i] = -1;
         t.children_visits[i] = 0;
-        t.children_prior_logits[i] = 0.0f;
+        if (!root_row) t.children_prior_logits[i] = 0.0f;
         t.children_values[i] = 0.0f;
         t.children_rewards[i] = 0.0f;
         t.children_discounts[i] = 0.0f;
         t.children_var[i] = 0.0f;
         t.children_reward_var[i] = 0.0f;
         if (i < bn) {
-            t.node_visits[i] = 0;
             t.parents[i] = -1;
             t.action_from_parent[i] = -1;
-            t.raw_values[i] = 0.0f;
-            t.node_values[i] = 0.0f;
-            t.raw_var[i] = 0.0f;
-            t.node_var[i] = 0.0f;
+            if (!(keep_root && i % t.N == 0)) {
+                t.node_visits[i] = 0;
+                t.raw_values[i] = 0.0f;
+                t.node_values[i] = 0.0f;
+                t.raw_var[i] = 0.0f;
+                t.node_var[i] = 0.0f;
+            }
         }
     }
 }

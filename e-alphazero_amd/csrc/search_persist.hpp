@@ -1,0 +1,611 @@
+// search_persist.hpp -- the whole Gumbel-MuZero search of 16 trees in ONE persistent workgroup (DeepSea + FC network, two actions).
+//
+// Reference: emctx search loop [EXT] as called from src/selfplay.py:107-117, with the recurrent fn of
+// src/context.py:117-155 (DeepSea env.step of src/envs/deep_sea.py:59-81, EpistemicFullyConnectedAZNet forward of
+// src/network/fully_connected.py:41-101, XXHash novelty of src/network/hashes.py:162-229).  In the reference the S simulations are one
+// `fori_loop` of one device program; here they are one kernel launch.
+//
+// Why one workgroup can own its trees for all S simulations: trees are independent, and the FC forward works on 16-row tiles -- a
+// workgroup evaluates the network for exactly its own 16 leaves, so there is no hand-off between workgroups at all and the tree
+// statistics never leave LDS (north-star: "one wavefront walking one tree in LDS-resident child-index/visit/prior arrays").
+//
+// Workgroup = 320 threads:
+//   waves 0-3  tree phase: 16 lanes per tree (lane j = level j of the recorded root-to-leaf path); forward: each wave owns 64 output
+//              columns of the hidden layers (v_mfma_f32_16x16x4_f32, one accumulation chain per output = the oracle's fmaf chain)
+//   wave 4     helper: novelty lookup of the 16 leaves, the 256-deep layer-3 chains of head h (VALU fmaf chain, bit-identical to the
+//              MFMA chain) while waves 0-3 run layer 2 of head h+1, the head epilogues (tanh)
+//
+// Per simulation (all in LDS / registers, nothing but the weight stream and 16 W1 rows per head comes from L2):
+//   expand + backward of the previous leaf   lane 0 writes the new node; the path's levels are folded leaf-to-root: every lane computes
+//                                            the discounted return G_d of its own level (serial fmaf order of A.6), then the running-mean
+//                                            updates of all levels are independent
+//   re-score                                 selection inputs of a node change only when the node is on the backed-up path, so the argmax
+//                                            of A.4 is re-evaluated for the D+1 nodes of the path in parallel (one lane per node) and cached
+//                                            as (action, child) per node
+//   select                                   the root-to-leaf walk is a pointer chase through the cached choices (one LDS read per level)
+//   DeepSea env.step of the chosen edge, one-hot index of the child's observation
+//   forward                                  layer 1 = row gather W1[hot] (exact for a one-hot row), layer 2 on MFMA with the W2 stream
+//                                            prefetched 16 k-steps ahead in registers (the stream is cyclic over the three heads, so the
+//                                            first k-steps of the next simulation are already in flight during the tree phase)
+//
+// Numerics: every float operation is the one tree_step_kernel / fc16_forward_kernel perform, in the same order (A = 2: the butterfly
+// sum of two slots is x0 + x1), so the results are bit-identical to the per-simulation kernels and to the CPU oracle.
+#pragma once
+#include "net_fc.hpp"
+#include "tree.hpp"
+
+namespace eaz {
+
+constexpr int kPsTrees = 16;     // trees per workgroup = rows of the forward tile
+constexpr int kPsThreads = 320;  // 4 tree / MFMA waves + 1 helper wave
+constexpr int kPsA = 2;          // actions (DeepSea)
+#ifndef EAZ_PS_EXPERIMENT
+#define EAZ_PS_EXPERIMENT 0
+#endif
+#ifndef EAZ_PS_DEPTH
+#define EAZ_PS_DEPTH 16
+#endif
+constexpr int kPsDepth = EAZ_PS_DEPTH;  // k-steps of the W2 stream in flight per wave (16 or 32; 4 VGPRs each)
+constexpr int kPsARing = 8;             // A operands (LDS) read this many k-steps ahead
+static_assert(64 % kPsDepth == 0 && kPsDepth % kPsARing == 0, "a head's 64 k-steps are whole rounds of kPsDepth");
+
+// node record in LDS (32-bit words)
+enum : int {
+    PR_RAW_VALUE = 0, PR_NODE_VALUE = 1, PR_RAW_VAR = 2, PR_NODE_VAR = 3, PR_NODE_VISITS = 4,
+    PR_INDEX = 5, PR_VISITS = 7, PR_LOGITS = 9, PR_VALUES = 11, PR_REWARDS = 13, PR_DISCOUNTS = 15, PR_VAR = 17,
+    PR_SEL = 19,    // cached selection: action << 16 | (child index & 0xFFFF)
+    PR_STATE = 20,  // DeepSea state, packed (ps_pack)
+    PR_WORDS = 21
+};
+
+struct PersistArgs {
+    TreeDev t;       // options + the global SoA arrays (root in, whole tree out)
+    NetDev net;
+    EnvDev env;
+    int head[3];     // value, ube, policy head ids (0, 1, 2|3)
+    int amap_lds;    // action map staged in LDS (G*G <= kPsAmapMax)
+    unsigned long long* stamps;  // diagnostic builds only
+};
+
+constexpr int kPsAmapMax = 4096;
+constexpr int kPsMiscBytes = 2048;
+
+struct PersistLds {
+    int tstride;                      // words per tree
+    int off_tree, off_h1, off_h2, off_part, off_w3, off_path, off_misc, off_amap, off_table, total;  // byte offsets
+};
+
+__host__ __device__ inline PersistLds persist_lds(int N, int S, int G) {
+    PersistLds L;
+    L.tstride = (N * PR_WORDS) | 1;  // odd: trees start in different banks
+    int o = 0;
+    L.off_h1 = o; o += kF16HBytes;
+    L.off_h2 = o; o += kF16HBytes;
+    L.off_part = o; o += 3 * 4 * kPsTrees * 4 * 4;  // layer-3 partial sums [3 heads][4 waves][16 rows][4 outputs]
+    L.off_w3 = o; o += 3 * kFcH * 4 * 4;
+    L.off_misc = o; o += kPsMiscBytes;
+    L.off_table = o; o += 3 * S * 4;
+    L.off_path = o; o += ((kPsTrees * S * 2) + 15) & ~15;
+    L.off_amap = o; o += (G * G <= kPsAmapMax) ? ((G * G + 15) & ~15) : 0;
+    L.off_tree = o; o += kPsTrees * L.tstride * 4;
+    L.total = (o + 15) & ~15;
+    return L;
+}
+
+// per-tree scalars and forward outputs (LDS, inside the misc block)
+struct PersistMisc {
+    int D[kPsTrees], parent[kPsTrees], action[kPsTrees], dst[kPsTrees], hot[kPsTrees];
+    float o_value[kPsTrees], o_ube[kPsTrees], o_nov[kPsTrees], o_reward[kPsTrees];
+    float o_logit[kPsTrees][kPsA];
+    int o_term[kPsTrees];
+    float beta[kPsTrees];
+    float gumbel[kPsTrees][kPsA];
+    int invalid[kPsTrees][kPsA];
+};
+static_assert(sizeof(PersistMisc) <= kPsMiscBytes, "misc block too small");
+
+// DeepSea state <-> one word: step_count (12 bits) | pos (12) | terminated | truncated | reward == 1
+__device__ __forceinline__ uint32_t ps_pack(const eaz_deepsea_state& s) {
+    return static_cast<uint32_t>(s.step_count & 0xFFF) | (static_cast<uint32_t>(s.pos & 0xFFF) << 12) |
+           (static_cast<uint32_t>(s.terminated != 0) << 24) | (static_cast<uint32_t>(s.truncated != 0) << 25) |
+           (static_cast<uint32_t>(s.reward == 1.0f) << 26);
+}
+__device__ __forceinline__ eaz_deepsea_state ps_unpack(uint32_t w) {
+    eaz_deepsea_state s;
+    s.step_count = static_cast<int>(w & 0xFFF);
+    s.pos = static_cast<int>((w >> 12) & 0xFFF);
+    s.terminated = static_cast<uint8_t>((w >> 24) & 1);
+    s.truncated = static_cast<uint8_t>((w >> 25) & 1);
+    s.reward = ((w >> 26) & 1) ? 1.0f : 0.0f;
+    s.pad[0] = s.pad[1] = 0;
+    return s;
+}
+
+// LDS traffic between the lanes of one wavefront: DS operations of a wave execute in issue order, so only the compiler has to be
+// kept from reordering them
+__device__ __forceinline__ void ps_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#ifdef EAZ_FC_STAMPS
+#define EAZ_PSTAMP(i)                                                                                  \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        if (a.stamps && (threadIdx.x == 0 || threadIdx.x == 256) && blockIdx.x < 256 && sim == a.t.S / 2) { \
+            unsigned long long t_;                                                                     \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+            a.stamps[blockIdx.x * 32 + (threadIdx.x ? 16 : 0) + (i)] = t_;                             \
+        }                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    } while (0)
+#else
+#define EAZ_PSTAMP(i)
+#endif
+
+// mctx seq_halving.score_considered + masked_argmax [EXT] (A.2) with the root noise / mask of this tree in registers
+__device__ __forceinline__ int ps_root_pick(const Group<1, kPsA>& g, const NodeRows<kPsA>& r, const float (&cq)[kPsA], float considered_visit,
+                                            const float (&gum)[kPsA], const int (&inv)[kPsA]) {
+    const float m = g.vmax(r.logits);
+    float sc[kPsA];
+#pragma unroll
+    for (int j = 0; j < kPsA; ++j) {
+        float s = (gum[j] + (r.logits[j] - m)) + cq[j];
+        s = s > -1e9f ? s : -1e9f;
+        s = s + (static_cast<float>(r.visits[j]) == considered_visit ? 0.0f : -kInf);
+        sc[j] = inv[j] ? -kInf : s;
+    }
+    return g.argmax(sc);
+}
+
+__global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const TreeDev& t = a.t;
+    const int N = t.N, S = t.S, B = t.B;
+    const PersistLds L = persist_lds(N, S, a.env.G);
+    float* H1 = reinterpret_cast<float*>(lds + L.off_h1);
+    float* H2 = reinterpret_cast<float*>(lds + L.off_h2);   // every wave reads back only the 64 columns it wrote
+    float* part = reinterpret_cast<float*>(lds + L.off_part);
+    float* W3s = reinterpret_cast<float*>(lds + L.off_w3);  // [3 heads][4 outputs][256 k]
+    PersistMisc& M = *reinterpret_cast<PersistMisc*>(lds + L.off_misc);
+    int* tab = reinterpret_cast<int*>(lds + L.off_table);   // [3][S]
+    uint16_t* path = reinterpret_cast<uint16_t*>(lds + L.off_path);  // [16][S]: node | action << 15
+    uint8_t* amap = lds + L.off_amap;
+    uint32_t* trees = reinterpret_cast<uint32_t*>(lds + L.off_tree);
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const bool helper = wave == 4;
+    const int tree0 = blockIdx.x * kPsTrees;
+    // head order rotated per workgroup: at any moment the CUs of an XCD stream three different W2 matrices from L2 instead of all
+    // hammering the same lines (the order in which the heads are evaluated does not enter any result)
+    int hidv[3];
+#pragma unroll
+    for (int h = 0; h < 3; ++h) hidv[h] = a.head[(h + blockIdx.x) % 3];
+
+    // ---------------------------------------------------------------- prologue ----------------------------------------------------
+    for (int i = tid; i < kPsTrees * L.tstride; i += kPsThreads) trees[i] = 0u;
+    for (int i = tid; i < 3 * S; i += kPsThreads) {
+        const int row = i / S;  // considered-visit sequences for 0, 1, 2 considered actions (rows beyond max_considered are never read)
+        tab[i] = row <= t.max_considered ? t.table[i] : 0;
+    }
+    if (a.amap_lds)
+        for (int i = tid; i < a.env.G * a.env.G; i += kPsThreads) amap[i] = a.env.action_map[i];
+    for (int i = tid; i < 3 * kFcH; i += kPsThreads) {
+        const int h = i / kFcH, k = i - h * kFcH;
+        const int hid = hidv[h], No = hid < 2 ? 1 : kPsA;
+        const float* W3 = a.net.w[hid * 3 + 2];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) W3s[(h * 4 + c) * kFcH + k] = c < No ? W3[k * No + c] : 0.0f;
+    }
+    __syncthreads();
+    if (tid < kPsTrees) {
+        const int i = tid, b = tree0 + i < B ? tree0 + i : B - 1;  // trees beyond the batch mirror the last one and are never written back
+        uint32_t* R = trees + i * L.tstride;
+        for (int n = 0; n < N; ++n) {
+            R[n * PR_WORDS + PR_INDEX] = 0xFFFFFFFFu;
+            R[n * PR_WORDS + PR_INDEX + 1] = 0xFFFFFFFFu;
+        }
+        const long nb = static_cast<long>(b) * N;
+        R[PR_RAW_VALUE] = f2u(t.raw_values[nb]);
+        R[PR_NODE_VALUE] = f2u(t.node_values[nb]);
+        R[PR_RAW_VAR] = f2u(t.raw_var[nb]);
+        R[PR_NODE_VAR] = f2u(t.node_var[nb]);
+        R[PR_NODE_VISITS] = static_cast<uint32_t>(t.node_visits[nb]);
+#pragma unroll
+        for (int c = 0; c < kPsA; ++c) {
+            R[PR_LOGITS + c] = f2u(t.children_prior_logits[nb * kPsA + c]);
+            M.gumbel[i][c] = t.root_gumbel[static_cast<long>(b) * kPsA + c];
+            M.invalid[i][c] = t.root_invalid[static_cast<long>(b) * kPsA + c];
+        }
+        R[PR_STATE] = ps_pack(ds_load(t.embeddings + nb * sizeof(eaz_deepsea_state)));
+        M.beta[i] = t.beta[b];
+        M.D[i] = 0; M.parent[i] = 0; M.action[i] = 0; M.dst[i] = 0; M.hot[i] = 0;
+    }
+
+    const int r = lane & 15, kq = lane >> 4;  // MFMA operand coordinates of this lane
+    const int K1 = a.net.in_dim;
+    __syncthreads();
+
+    // Both roles run the same barrier sequence per simulation:
+    //   S0 hot[] ready | S1 H1(head 0) | S2 H2(0) | S3 H1(1) | S4 H2(1) | S5 H1(2) | S6 H2(2) | S7 all head outputs
+    if (helper) {
+        // =========================================================== helper wave ===========================================================
+        // layer-1 bias of the two heads whose W1 rows this wave gathers (lane = 4 columns)
+        float hb1[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hb1[h][c] = a.net.b[hidv[h + 1] * 3][4 * lane + c];
+        const float* W1g[2] = {a.net.w[hidv[1] * 3] + 4 * lane, a.net.w[hidv[2] * 3] + 4 * lane};
+        __builtin_amdgcn_s_setprio(3);  // the youngest wave of the workgroup loses every issue arbitration against its SIMD partner otherwise
+        for (int sim = 0; sim < S; ++sim) {
+            EAZ_PSTAMP(0);
+            __syncthreads();  // S0
+            // W1 rows of the second head: in flight under layer 2 of the first (waves 0-3 issue nothing but their weight stream there)
+            floatx4 gw[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gw[i] = *reinterpret_cast<const floatx4*>(W1g[0] + static_cast<long>(M.hot[i]) * kFcH);
+            __syncthreads();  // S1
+            EAZ_PSTAMP(4);
+            if (lane < kPsTrees) {
+                // novelty lookup of the one-hot observation (hashes.py:23-38,162-229): the hash index of a row that is zero except
+                // obs[hot] = 1 depends on `hot` only and is tabulated once per network (NetDev::hot_index)
+                const uint32_t index = a.net.hot_index[M.hot[lane]];
+                const bool seen = a.net.bitset ? ((a.net.bitset[index >> 3] >> (index & 7u)) & 1u) != 0 : false;
+                M.o_nov[lane] = (seen ? 0.0f : 1.0f) * a.net.nov_scale;                                     // fully_connected.py:90
+            }
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                __syncthreads();  // S2 / S4 / S6: the partial sums of head h are complete, H1 is free
+                if (h < 2) {
+                    // H1 of head h + 1: relu(W1[hot] + b1) (exactly fmaf(1, w, +0) per column: every other term of the reference's chain
+                    // is fmaf(0, w, acc) = acc)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                        for (int i4 = 0; i4 < 4; ++i4) {
+                            floatx4 o;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float v = __builtin_fmaf(1.0f, gw[4 * i4 + i][c], 0.0f) + hb1[h][c];
+                                o[i] = v > 0.0f ? v : 0.0f;
+                            }
+                            *reinterpret_cast<floatx4*>(H1 + h16_off(4 * lane + c, 4 * i4)) = o;
+                        }
+                    }
+                    __syncthreads();  // S3 / S5: H1 of head h + 1
+                    if (h == 0) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) gw[i] = *reinterpret_cast<const floatx4*>(W1g[1] + static_cast<long>(M.hot[i]) * kFcH);
+                    }
+                }
+                // ---- layer 3, second half + head activation: ((c0 + c1) + (c2 + c3)) + b of the four quarter chains that waves 0-3 ran
+                // over their own hidden columns (o_linear_parts), lane = (row, output) ----
+                {
+                    const int hid = hidv[h], No = hid < 2 ? 1 : kPsA;
+                    const int row = lane & 15, o = lane >> 4;
+                    if (o < No) {
+                        const float* pp = part + (h * 4 * kPsTrees + row) * 4 + o;
+                        const float c0 = pp[0], c1 = pp[kPsTrees * 4], c2 = pp[2 * kPsTrees * 4], c3 = pp[3 * kPsTrees * 4];
+                        const float z = ((c0 + c1) + (c2 + c3)) + a.net.b[hid * 3 + 2][o];
+                        if (hid == 0) M.o_value[row] = det_tanh(z);                                     // fully_connected.py:55
+                        else if (hid == 1) M.o_ube[row] = (0.5f * (det_tanh(z) + 1.0f)) * a.net.max_u;  // :64, :93
+                        else M.o_logit[row][o] = z;                                                     // :68-81
+                    }
+                }
+            }
+            EAZ_PSTAMP(5);
+            __syncthreads();  // S7
+        }
+    } else {
+        // ====================================================== waves 0-3: trees + layers 1-2 ======================================================
+        // lane (r, kq) of wave w owns output columns n0 + 4r .. +3 (n0 = 64 w), k = 4 ks + kq
+        const int n0 = wave * 64, col = n0 + 4 * r;
+        float b2r[3][4];
+        // W2 of the three heads as buffer resources: a refill is ONE buffer_load_dwordx4 with a per-lane byte offset that never changes
+        // (row kq, columns col .. col+3) and the k-step in the scalar offset -- no per-refill address arithmetic on the vector ALU, and
+        // half the address registers of a global_load (the wave issues one refill per four MFMAs and nothing else hides its issue cost)
+        __amdgpu_buffer_rsrc_t W2r[3];
+        const int voff = (kq * kFcH + col) * 4;
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            W2r[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.net.w[hidv[h] * 3 + 1]), 0, kFcH * kFcH * 4, 0x00020000);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b2r[h][c] = a.net.b[hidv[h] * 3 + 1][col + c];
+        }
+        const float* W1p0 = a.net.w[hidv[0] * 3] + tid;  // first head's row gather: thread = column
+        const float b1r0 = a.net.b[hidv[0] * 3][tid];
+        // the W2 stream, kPsDepth k-steps ahead (k-step ks of a head reads rows 4 ks + kq); cyclic over the heads, so the first k-steps of
+        // the next simulation are in flight during the tree phase
+        floatx4 Bq[kPsDepth];
+#pragma unroll
+        for (int i = 0; i < kPsDepth; ++i) Bq[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(W2r[0], voff, i * 4096, 0));
+        EnvDev env = a.env;
+        if (a.amap_lds) env.action_map = amap;
+        // tree lanes: 16 per tree
+        const int ti = tid >> 4, tj = tid & 15;
+        uint32_t* T = trees + ti * L.tstride;
+        uint16_t* P = path + ti * S;
+        const int gb = tree0 + ti < B ? tree0 + ti : B - 1;
+        const Group<1, kPsA> g = make_group<1, kPsA>(gb, 0, kPsA);
+        const float beta = M.beta[ti];
+        const bool need_var = beta != 0.0f;
+
+        for (int sim = 0; sim <= S; ++sim) {
+            EAZ_PSTAMP(0);
+            const int D = M.D[ti], dst = M.dst[ti];
+            if (sim > 0) {
+                // ---- expand: mctx update_tree_node + topology (A.3) with epistemic_recurrent_fn (src/context.py:132-153) ------------
+                const int parent = M.parent[ti], action = M.action[ti];
+                if (tj == 0) {
+                    float lg[kPsA] = {M.o_logit[ti][0], M.o_logit[ti][1]};
+                    const float m = g.vmax(lg);                                                         // :135
+#pragma unroll
+                    for (int c = 0; c < kPsA; ++c) lg[c] = lg[c] - m;                                   // :137 (DeepSea: every action legal)
+                    const bool term = M.o_term[ti] != 0;
+                    const float value = term ? 0.0f : M.o_value[ti];                                    // :140
+                    const float var = term ? 0.0f : ube_combine(M.o_ube[ti], M.o_nov[ti], t.max_u);     // :141
+                    float disc = 1.0f * t.discount;                                                     // :142
+                    if (t.two_player) disc = disc * -1.0f;                                              // :143
+                    if (term) disc = 0.0f;                                                              // :144
+                    uint32_t* Rn = T + dst * PR_WORDS;
+                    Rn[PR_LOGITS] = f2u(lg[0]); Rn[PR_LOGITS + 1] = f2u(lg[1]);
+                    Rn[PR_RAW_VALUE] = f2u(value); Rn[PR_NODE_VALUE] = f2u(value);
+                    Rn[PR_RAW_VAR] = f2u(var); Rn[PR_NODE_VAR] = f2u(var);
+                    Rn[PR_NODE_VISITS] += 1u;
+                    uint32_t* Rp = T + parent * PR_WORDS;
+                    Rp[PR_INDEX + action] = static_cast<uint32_t>(dst);
+                    Rp[PR_REWARDS + action] = f2u(M.o_reward[ti]);                                      // :139
+                    Rp[PR_DISCOUNTS + action] = f2u(disc);
+                }
+                ps_wave_sync();
+                // ---- backward (A.6) ------------------------------------------------------------------------------------------
+                const float leaf_v = u2f(T[dst * PR_WORDS + PR_RAW_VALUE]), leaf_u = u2f(T[dst * PR_WORDS + PR_RAW_VAR]);
+                float Gin = leaf_v, Uin = leaf_u, cvin = leaf_v, cuin = leaf_u;
+                for (int c = (D - 1) >> 4; c >= 0; --c) {
+                    const int d = c * 16 + tj;
+                    const bool valid = d < D;
+                    const int e = P[valid ? d : 0];
+                    const int pn = e & 0x7FFF, pa = e >> 15;
+                    uint32_t* R = T + pn * PR_WORDS;
+                    const float er = u2f(R[PR_REWARDS + pa]), ed = u2f(R[PR_DISCOUNTS + pa]);
+                    const int cnt_i = static_cast<int>(R[PR_NODE_VISITS]), cvis = static_cast<int>(R[PR_VISITS + pa]);
+                    const float nv = u2f(R[PR_NODE_VALUE]), nvar = u2f(R[PR_NODE_VAR]);
+                    const int top = (D - c * 16 < 16 ? D - c * 16 : 16) - 1;  // deepest level of this chunk
+                    float G = Gin, U = Uin;
+#pragma unroll
+                    for (int s = 15; s >= 0; --s) {
+                        const float rs = __shfl(er, s, 16), dd = __shfl(ed, s, 16);
+                        if (s <= top && s >= tj) {
+                            G = rs + dd * G;
+                            U = 0.0f + (dd * dd) * U;  // children_rewards_epistemic_variance == 0 (context.py:149)
+                        }
+                    }
+                    const float cnt = static_cast<float>(cnt_i);
+                    const float pv = (nv * cnt + G) / (cnt + 1.0f);
+                    const float pvar = (nvar * cnt + U) / (cnt + 1.0f);
+                    float cv = __shfl_down(pv, 1, 16), cu = __shfl_down(pvar, 1, 16);  // node value of the level below
+                    if (tj == top) { cv = cvin; cu = cuin; }
+                    if (valid) {
+                        R[PR_NODE_VALUE] = f2u(pv);
+                        R[PR_NODE_VAR] = f2u(pvar);
+                        R[PR_NODE_VISITS] = static_cast<uint32_t>(cnt_i + 1);
+                        R[PR_VALUES + pa] = f2u(cv);
+                        R[PR_VAR + pa] = f2u(cu);
+                        R[PR_VISITS + pa] = static_cast<uint32_t>(cvis + 1);
+                    }
+                    Gin = __shfl(G, 0, 16); Uin = __shfl(U, 0, 16);
+                    cvin = __shfl(pv, 0, 16); cuin = __shfl(pvar, 0, 16);
+                }
+                ps_wave_sync();
+            }
+            EAZ_PSTAMP(1);
+            if (sim == S) break;
+            // ---- re-score the nodes whose selection inputs changed: the path's levels 0 .. D-1 and the (re-)expanded node ---------
+            const int nl = sim > 0 ? D + 1 : 1;
+            for (int l = tj; l < nl; l += 16) {
+                const int node = l < D ? (P[l] & 0x7FFF) : dst;
+                uint32_t* R = T + node * PR_WORDS;
+                NodeRows<kPsA> rw;
+#pragma unroll
+                for (int c = 0; c < kPsA; ++c) {
+                    rw.logits[c] = u2f(R[PR_LOGITS + c]);
+                    rw.values[c] = u2f(R[PR_VALUES + c]);
+                    rw.rewards[c] = u2f(R[PR_REWARDS + c]);
+                    rw.discounts[c] = u2f(R[PR_DISCOUNTS + c]);
+                    rw.visits[c] = static_cast<int>(R[PR_VISITS + c]);
+                    rw.index[c] = static_cast<int>(R[PR_INDEX + c]);
+                    rw.var[c] = need_var ? u2f(R[PR_VAR + c]) : 0.0f;
+                    rw.rvar[c] = 0.0f;
+                }
+                float cq[kPsA];
+                qtransform<1, kPsA>(t, g, rw, u2f(R[PR_RAW_VALUE]), need_var ? u2f(R[PR_RAW_VAR]) : 0.0f, beta, cq);
+                int act;
+                if (node == 0) {
+                    // gumbel_muzero_root_action_selection (A.4)
+                    const int inv[kPsA] = {M.invalid[ti][0], M.invalid[ti][1]};
+                    const float gum[kPsA] = {M.gumbel[ti][0], M.gumbel[ti][1]};
+                    const int nvalid = (1 - (inv[0] != 0)) + (1 - (inv[1] != 0));
+                    int simidx = rw.visits[0] + rw.visits[1];
+                    const int nc = nvalid < t.max_considered ? nvalid : t.max_considered;
+                    simidx = simidx > S - 1 ? S - 1 : simidx;
+                    act = ps_root_pick(g, rw, cq, static_cast<float>(tab[nc * S + simidx]), gum, inv);
+                } else {
+                    // gumbel_muzero_interior_action_selection (A.4)
+                    float x[kPsA], pr[kPsA];
+#pragma unroll
+                    for (int c = 0; c < kPsA; ++c) x[c] = rw.logits[c] + cq[c];
+                    const int sumN = rw.visits[0] + rw.visits[1];
+                    g.softmax(x, pr);
+                    const float den = static_cast<float>(1 + sumN);
+#pragma unroll
+                    for (int c = 0; c < kPsA; ++c) x[c] = pr[c] - static_cast<float>(rw.visits[c]) / den;
+                    act = g.argmax(x);
+                }
+                const int nx = act == 0 ? rw.index[0] : rw.index[1];
+                R[PR_SEL] = (static_cast<uint32_t>(act) << 16) | (static_cast<uint32_t>(nx) & 0xFFFFu);
+            }
+            ps_wave_sync();
+            EAZ_PSTAMP(2);
+            // ---- select (A.4): walk the cached choices; DeepSea env.step of the chosen edge ---------------------------------------
+            if (tj == 0) {
+                int node = 0, depth = 0, act, nx;
+                while (true) {
+                    const uint32_t sw = T[node * PR_WORDS + PR_SEL];
+                    act = static_cast<int>(sw >> 16);
+                    nx = static_cast<int>(static_cast<int16_t>(sw & 0xFFFFu));
+                    P[depth] = static_cast<uint16_t>(node | (act << 15));
+                    depth += 1;
+                    if (nx < 0 || depth >= t.max_depth) break;
+                    node = nx;
+                }
+                const int nd = nx < 0 ? sim + 1 : nx;
+                M.parent[ti] = node; M.action[ti] = act; M.dst[ti] = nd; M.D[ti] = depth;
+                const eaz_deepsea_state ns = ds_step(env, ps_unpack(T[node * PR_WORDS + PR_STATE]), act);  // context.py:125-127
+                T[nd * PR_WORDS + PR_STATE] = ps_pack(ns);
+                M.o_reward[ti] = ns.reward;   // rewards[b, current_player], single player (deep_sea.py:100-102)
+                M.o_term[ti] = ns.terminated;
+                const int hh = ds_hot_index(env, ns);
+                M.hot[ti] = hh < 0 ? 0 : (hh >= K1 ? K1 - 1 : hh);
+            }
+            EAZ_PSTAMP(3);
+            __syncthreads();  // S0: hot[], the leaf's reward / terminated flag
+            // -------------------------------------------------------- forward of the 16 leaves --------------------------------------------
+            {
+                // layer 1 of the first head: relu(W1[hot] + b1), thread = output column
+                float w1n[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) w1n[i] = W1p0[static_cast<long>(M.hot[i]) * kFcH];
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    floatx4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = __builtin_fmaf(1.0f, w1n[4 * i4 + i], 0.0f) + b1r0;
+                        o[i] = v > 0.0f ? v : 0.0f;
+                    }
+                    *reinterpret_cast<floatx4*>(H1 + h16_off(tid, 4 * i4)) = o;
+                }
+            }
+            __syncthreads();  // S1: H1 of head 0
+            EAZ_PSTAMP(4);
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                // ---- layer 2: [16 x 256] x [256 x 256]; the weight stream runs kPsDepth k-steps ahead and on into the next head (next
+                // simulation); A operands come from LDS kPsARing k-steps ahead ----
+                floatx4 acc[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+                EAZ_PSTAMP(6 + 3 * h);
+                const float* Ap = H1 + kq * 16 + r;  // h16_off(4 ks + kq, r) = 68 ks + 16 kq + r
+                float av[kPsARing];
+#pragma unroll
+                for (int i = 0; i < kPsARing; ++i) av[i] = Ap[i * 68];
+                // The round loop is NOT unrolled: with all 192 refill addresses of the three heads loop-invariant the compiler precomputes
+                // and spills them.
+#pragma unroll 1
+                for (int rd = 0; rd < 64 / kPsDepth; ++rd) {
+                    const bool same = rd + 1 < 64 / kPsDepth;  // the refills of the last round belong to the next head
+                    const __amdgpu_buffer_rsrc_t rs = same ? W2r[h] : W2r[h == 2 ? 0 : h + 1];
+                    const int sbase = same ? 4096 * kPsDepth * (rd + 1) : 0;
+                    const float* apn = Ap + (rd * kPsDepth + kPsARing) * 68;  // reads past k-step 63 land in the H2 tiles and are never used
+#pragma unroll
+                    for (int i = 0; i < kPsDepth; ++i) {
+#if EAZ_PS_EXPERIMENT == 2   /* timing experiments of the diagnostic build only (results are wrong): 1 = no weight refills, 2 = no MFMAs */
+                        acc[0][0] += av[i % kPsARing] * Bq[i][0]; acc[1][0] += Bq[i][1]; acc[2][0] += Bq[i][2]; acc[3][0] += Bq[i][3];
+#else
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i % kPsARing], Bq[i][c], acc[c], 0, 0, 0);
+#endif
+#if EAZ_PS_EXPERIMENT != 1
+                        Bq[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sbase + i * 4096, 0));
+#endif
+                        av[i % kPsARing] = apn[i * 68];
+                        __builtin_amdgcn_sched_barrier(0);  // keep every refill right behind the k-step that freed its registers
+                    }
+                }
+                // layer-3 weights of this wave's quarter of k (B operand of the chain below): requested before the H2 round trip
+                float wb[16];
+                {
+                    const float* wpB = W3s + (h * 4 + (r & 3)) * kFcH + n0 + kq;  // W3[n0 + 4 ks + kq][r] (columns >= 4 repeat 0..3 and are dropped)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) wb[q] = wpB[4 * q];
+                }
+                // relu(acc + b2) -> H2: lane (r, kq) holds rows 4 kq .. +3 of column n0 + 4r + c
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    floatx4 o;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const float v = acc[c][reg] + b2r[h][c];
+                        o[reg] = v > 0.0f ? v : 0.0f;
+                    }
+                    *reinterpret_cast<floatx4*>(H2 + h16_off(col + c, 4 * kq)) = o;
+                }
+                // ---- layer 3, first half: the chain over the 64 hidden columns this wave owns (quarter `wave` of k): 16 dependent MFMAs
+                // (k ascending = the oracle's fmaf chain of that quarter).  Only columns written by this wave are read back, so the
+                // transposition through LDS needs no workgroup barrier (DS operations of a wave execute in order). ----
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                {
+                    const float* hpA = H2 + h16_off(n0 + kq, r);  // H2[h16_off(n0 + 4 ks + kq, r)] = hpA[68 ks]
+                    floatx4 a3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(hpA[68 * q], wb[q], a3, 0, 0, 0);
+                    if (r < 4) {
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) part[((h * 4 + wave) * kPsTrees + 4 * kq + reg) * 4 + r] = a3[reg];
+                    }
+                }
+                EAZ_PSTAMP(7 + 3 * h);
+                __syncthreads();  // S2 / S4 / S6
+                if (h < 2) __syncthreads();  // S3 / S5: the helper wrote H1 of head h + 1
+            }
+            EAZ_PSTAMP(5);
+            __syncthreads();  // S7: the heads' outputs
+        }
+    }
+
+    // ---------------------------------------------------------------- write the trees back (mctx SoA layout) -----------------------
+    __syncthreads();
+    int16_t* par = reinterpret_cast<int16_t*>(H1);            // [16][N] parent, then [16][N] action_from_parent (H1/H2 are free now)
+    int16_t* afp = par + kPsTrees * N;
+    for (int i = tid; i < 2 * kPsTrees * N; i += kPsThreads) par[i] = -1;
+    __syncthreads();
+    for (int i = tid; i < kPsTrees * N * kPsA; i += kPsThreads) {
+        const int tr = i / (N * kPsA), rem = i - tr * (N * kPsA), n = rem / kPsA, c = rem - n * kPsA;
+        const int ch = static_cast<int>(trees[tr * L.tstride + n * PR_WORDS + PR_INDEX + c]);
+        if (ch >= 0) { par[tr * N + ch] = static_cast<int16_t>(n); afp[tr * N + ch] = static_cast<int16_t>(c); }
+    }
+    __syncthreads();
+    const int ntree = B - tree0 < kPsTrees ? B - tree0 : kPsTrees;
+    const long nb0 = static_cast<long>(tree0) * N;
+    for (int i = tid; i < ntree * N; i += kPsThreads) {
+        const int tr = i / N, n = i - tr * N;
+        const uint32_t* R = trees + tr * L.tstride + n * PR_WORDS;
+        t.raw_values[nb0 + i] = u2f(R[PR_RAW_VALUE]);
+        t.node_values[nb0 + i] = u2f(R[PR_NODE_VALUE]);
+        t.raw_var[nb0 + i] = u2f(R[PR_RAW_VAR]);
+        t.node_var[nb0 + i] = u2f(R[PR_NODE_VAR]);
+        t.node_visits[nb0 + i] = static_cast<int32_t>(R[PR_NODE_VISITS]);
+        t.parents[nb0 + i] = par[i];
+        t.action_from_parent[nb0 + i] = afp[i];
+        if (n > 0 && R[PR_NODE_VISITS] != 0u) ds_store(t.embeddings + (nb0 + i) * sizeof(eaz_deepsea_state), ps_unpack(R[PR_STATE]));
+    }
+    for (int i = tid; i < ntree * N * kPsA; i += kPsThreads) {
+        const int tr = i / (N * kPsA), rem = i - tr * (N * kPsA), n = rem / kPsA, c = rem - n * kPsA;
+        const uint32_t* R = trees + tr * L.tstride + n * PR_WORDS;
+        const long o = nb0 * kPsA + i;
+        t.children_index[o] = static_cast<int32_t>(R[PR_INDEX + c]);
+        t.children_visits[o] = static_cast<int32_t>(R[PR_VISITS + c]);
+        t.children_prior_logits[o] = u2f(R[PR_LOGITS + c]);
+        t.children_values[o] = u2f(R[PR_VALUES + c]);
+        t.children_rewards[o] = u2f(R[PR_REWARDS + c]);
+        t.children_discounts[o] = u2f(R[PR_DISCOUNTS + c]);
+        t.children_var[o] = u2f(R[PR_VAR + c]);
+        t.children_reward_var[o] = 0.0f;
+    }
+}
+
+}  // namespace eaz

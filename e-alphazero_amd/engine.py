@@ -60,9 +60,9 @@ def fold(key, tag: int) -> int:
 
 
 def tune(fc_tile: Optional[int] = None, fused_leaf: Optional[int] = None, tree_block: Optional[int] = None,
-         tree_spread: Optional[int] = None) -> None:
+         tree_spread: Optional[int] = None, persist: Optional[int] = None) -> None:
     """Kernel-selection knobs (include/eaz.h eaz_tune_set); results are identical for every setting."""
-    for knob, v in ((0, fc_tile), (1, fused_leaf), (2, tree_block), (3, tree_spread)):
+    for knob, v in ((0, fc_tile), (1, fused_leaf), (2, tree_block), (3, tree_spread), (4, persist)):
         if v is not None:
             check(_lib.load().eaz_tune_set(knob, int(v)))
 
@@ -391,8 +391,8 @@ class Search:
         return ms.value / iters
 
     def profile_read(self, reset: bool = True) -> dict:
-        ms = (C.c_double * 5)()
-        n = (C.c_int64 * 5)()
+        ms = (C.c_double * len(_lib.K_NAMES))()
+        n = (C.c_int64 * len(_lib.K_NAMES))()
         check(_lib.load().eaz_profile_read(self.h, ms, n, int(reset)))
         out = {name: dict(ms=ms[i], launches=int(n[i])) for i, name in enumerate(_lib.K_NAMES)}
         ks = C.c_uint64()

@@ -238,7 +238,8 @@ EAZ_API int eaz_reanalyze_run(eaz_search* s, const eaz_reanalyze_cfg* cfg, uint6
 
 /* ---- instrumentation -------------------------------------------------------------------------------------- */
 /* per-kernel-class device time accumulated with hipEvents on the launch stream while profiling is enabled */
-enum { EAZ_K_TREE = 0, EAZ_K_GATHER = 1, EAZ_K_HASH = 2, EAZ_K_NET = 3, EAZ_K_MISC = 4, EAZ_K_COUNT = 5 };
+/* EAZ_K_SEARCH: the persistent search kernel (all simulations of a real step in one launch: tree + env step + network forward) */
+enum { EAZ_K_TREE = 0, EAZ_K_GATHER = 1, EAZ_K_HASH = 2, EAZ_K_NET = 3, EAZ_K_MISC = 4, EAZ_K_SEARCH = 5, EAZ_K_COUNT = 6 };
 EAZ_API int eaz_profile_enable(eaz_search* s, int on);
 /* synchronises the stream; returns total ms and launch count per class since the last reset */
 EAZ_API int eaz_profile_read(eaz_search* s, double ms[EAZ_K_COUNT], int64_t launches[EAZ_K_COUNT], int reset);
@@ -264,6 +265,10 @@ EAZ_API int eaz_profile_replay(eaz_search* s, int kernel_class, int iters, doubl
  *                        0 = automatic (spread until the launch has one wavefront per CU) */
 #define EAZ_TUNE_TREE_BLOCK 2
 #define EAZ_TUNE_TREE_SPREAD 3
+/*   EAZ_TUNE_PERSIST     1 (default) = eaz_search_run of a DeepSea + FC search with two actions whose trees fit into LDS runs all
+ *                        simulations in ONE persistent launch (16 trees per workgroup, csrc/search_persist.hpp); 0 = one tree kernel +
+ *                        one forward per simulation.  eaz_search_simulate always uses the per-simulation kernels. */
+#define EAZ_TUNE_PERSIST 4
 EAZ_API int eaz_tune_set(int knob, int value);
 
 #ifdef __cplusplus

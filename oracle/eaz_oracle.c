@@ -669,29 +669,43 @@ EXPORT void eazo_net_free(ONet* n) {
 EXPORT void eazo_net_set_bitset(ONet* n, const uint8_t* bitset) { n->bitset = bitset; }
 
 /* hk.Linear: y = x @ w + b.  Spec of the build: acc = +0; acc = fmaf(x[k], w[k][j], acc) for k ascending; y = acc + b[j].
- * (This is exactly what one chain of gfx950 f32 MFMA accumulation computes.)  Rows are blocked by 4 so the j loop vectorises. */
-static void o_linear(int B, int K, int N, const float* x, const float* w, const float* bias, float* y, int relu) {
+ * (This is exactly what one chain of gfx950 f32 MFMA accumulation computes.)  Rows are blocked by 4 so the j loop vectorises.
+ *
+ * parts > 1 (the THIRD layer of every FC head, K = linear_layer_size): the k range is cut into `parts` equal contiguous pieces,
+ * each piece is its own fmaf chain from +0, and the pieces are added pairwise in the fixed order ((c0 + c1) + (c2 + c3)) before the
+ * bias -- the four wavefronts of a device workgroup own a quarter of the hidden columns each and every one runs the chain over its
+ * own quarter (DESIGN.md "Numerics contract").  XLA does not specify the reduction order of a dot at all; either
+ * order is within 1e-5 of the float64 restatement (tests/test_oracle_hash_net.py). */
+static void o_linear_parts(int B, int K, int N, const float* x, const float* w, const float* bias, float* y, int relu, int parts) {
+    if (parts < 1 || K % parts != 0 || (parts != 1 && parts != 4)) parts = 1;
+    const int Kp = K / parts;
 #pragma omp parallel for schedule(static)
     for (int r0 = 0; r0 < B; r0 += 4) {
-        float acc[4][O_MAX_A > 256 ? O_MAX_A : 256];
+        float acc[4][4][O_MAX_A > 256 ? O_MAX_A : 256];
         const int rb = B - r0 < 4 ? B - r0 : 4;
-        for (int r = 0; r < rb; ++r)
-            for (int j = 0; j < N; ++j) acc[r][j] = 0.0f;
-        for (int k = 0; k < K; ++k) {
-            const float* wk = w + (size_t)k * N;
-            for (int r = 0; r < rb; ++r) {
-                const float xv = x[(size_t)(r0 + r) * K + k];
-                float* ar = acc[r];
-                for (int j = 0; j < N; ++j) ar[j] = fmaf(xv, wk[j], ar[j]);
+        for (int q = 0; q < parts; ++q) {
+            for (int r = 0; r < rb; ++r)
+                for (int j = 0; j < N; ++j) acc[q][r][j] = 0.0f;
+            for (int k = q * Kp; k < (q + 1) * Kp; ++k) {
+                const float* wk = w + (size_t)k * N;
+                for (int r = 0; r < rb; ++r) {
+                    const float xv = x[(size_t)(r0 + r) * K + k];
+                    float* ar = acc[q][r];
+                    for (int j = 0; j < N; ++j) ar[j] = fmaf(xv, wk[j], ar[j]);
+                }
             }
         }
         for (int r = 0; r < rb; ++r)
             for (int j = 0; j < N; ++j) {
-                float v = acc[r][j] + bias[j];
+                float v = parts == 4 ? (acc[0][r][j] + acc[1][r][j]) + (acc[2][r][j] + acc[3][r][j]) : acc[0][r][j];
+                v = v + bias[j];
                 if (relu) v = v > 0.0f ? v : 0.0f;
                 y[(size_t)(r0 + r) * N + j] = v;
             }
     }
+}
+static void o_linear(int B, int K, int N, const float* x, const float* w, const float* bias, float* y, int relu) {
+    o_linear_parts(B, K, N, x, w, bias, y, relu, 1);
 }
 
 /* EpistemicFullyConnectedAZNet.__call__(x, is_training=False), src/network/fully_connected.py:41-101.
@@ -712,7 +726,7 @@ EXPORT void eazo_net_forward(const ONet* n, int B, const uint8_t* obs, float* ex
         const int No = o_layer_out(n, l + 2);
         o_linear(B, K, H, x, n->w[l], n->b[l], h1, 1);
         o_linear(B, H, H, h1, n->w[l + 1], n->b[l + 1], h2, 1);
-        o_linear(B, H, No, h2, n->w[l + 2], n->b[l + 2], o, 0);
+        o_linear_parts(B, H, No, h2, n->w[l + 2], n->b[l + 2], o, 0, 4);  /* four partial chains, see o_linear_parts */
         if (head == 0) { for (int b = 0; b < B; ++b) v[b] = o_tanhf(o[b]); }                       /* :50-56 */
         else if (head == 1) { for (int b = 0; b < B; ++b) u[b] = 0.5f * (o_tanhf(o[b]) + 1.0f); }  /* :59-65 */
         else memcpy(head == 2 ? exploit : explore, o, (size_t)B * A * sizeof(float));             /* :68-81 */

@@ -155,6 +155,95 @@ def test_search_depth_limited_and_qtransform_options(oracle, eaz, torch, max_dep
     assert (nv[:, 1:] > 1).any(), "the depth limit never re-expanded a node: the test does not cover what it claims"
 
 
+@pytest.mark.parametrize("G,B,S,beta_max,opts,masked", [
+    (8, 64, 16, 0.0, {}, False),
+    (8, 70, 16, 1.0, {}, False),                                       # epistemic twin + ragged last workgroup (70 = 4 * 16 + 6)
+    (32, 300, 64, 0.0, {}, False),                                     # C2's tree shape
+    (32, 48, 64, 0.7, dict(max_depth=6), False),                       # depth limit: re-expansion of existing nodes
+    (8, 33, 24, 0.0, dict(max_depth=1), False),
+    (8, 40, 40, 0.0, dict(rescale=False), True),                       # invalid root actions (incl. rows with every action invalid)
+    (8, 40, 24, 0.5, dict(use_mixed=False, max_considered=1), True),
+    (6, 17, 8, 0.0, dict(two_player=True), False),                     # negated discount (context.py:143)
+    (8, 20, 70, 0.0, {}, False),                                       # S = 70: the trees of a workgroup no longer fit into LDS
+])
+def test_search_run_whole_tree(oracle, eaz, torch, G, B, S, beta_max, opts, masked):
+    """begin -> run (all S simulations in one call) -> finish: every tree field, the embeddings, action and weights against the
+    oracle.  Under the `persist` variant eligible cases are ONE launch of search_persist_kernel (trees in LDS); the other variants
+    (and S = 70) loop the per-simulation kernels -- all of them must agree with the oracle."""
+    am, params, state = deepsea_setup(eaz, G, seed=13, fill=0.4)
+    engine, env, net = _engine(eaz, G, am, params, state)
+    oenv, onet = oracle_deepsea(oracle, eaz, G, am, params, state)
+    blobs = random_states_deepsea(G, B, seed=14)
+    ex, xp, v, u, _ = onet.forward(oenv.observe(blobs))
+    beta = (beta_max * np.linspace(0, 1, B)).astype(np.float32)
+    g = oracle.gumbel((31, 32), B * 2).reshape(B, 2)
+    invalid = None
+    if masked:
+        invalid = (np.random.default_rng(3).random((B, 2)) < 0.3).astype(np.uint8)
+        invalid[0] = 1
+    explore = beta_max > 0
+    logits = xp if explore else ex
+    okw = dict(discount=0.997, use_exploration_logits=explore, rescale=opts.get("rescale", True), use_mixed=opts.get("use_mixed", True),
+               max_considered=opts.get("max_considered", 16), max_depth=opts.get("max_depth", 0), two_player=opts.get("two_player", False))
+    otree = oracle.OracleTree(oenv, onet, B, S)
+    otree.begin(logits, v, u, blobs, beta, invalid, g, **okw)
+    for sim in range(S):
+        otree.sim(sim)
+    search = engine.Search(env, net, B, S, discount=0.997, exploration=explore, rescale_values=okw["rescale"], use_mixed_value=okw["use_mixed"],
+                           max_num_considered_actions=okw["max_considered"], max_depth=okw["max_depth"] or None,
+                           two_players_game=okw["two_player"])
+    cu = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for rep in range(2):  # the second search reuses the (dirty) tree buffers of the first
+        search.begin(cu(logits), cu(v), cu(u), cu(blobs), cu(beta), cu(invalid), cu(g))
+        search.run()
+        act, aw = search.finish()
+        oact, oaw = otree.finish()
+        exact = _compare_tree(search, otree, f"run rep={rep}")
+        emb, oemb = search.field("embeddings").cpu().numpy(), otree.field("embeddings")
+        visited = search.dump()["node_visits"] > 0
+        assert np.array_equal(emb[visited], oemb[visited]), "embeddings of visited nodes differ"
+        assert np.array_equal(act.cpu().numpy(), oact)
+        np.testing.assert_allclose(aw.cpu().numpy(), oaw, rtol=0, atol=ATOL)
+        s_, os_ = search.summary(), otree.summary()
+        for k in os_:
+            np.testing.assert_allclose(s_[k].cpu().numpy(), os_[k], rtol=0, atol=ATOL, err_msg=k)
+    print(f"run(): tree float fields bit-exact vs oracle: {exact}")
+
+
+def test_search_begin_then_stepwise_after_persist_default(oracle, eaz, torch):
+    """With the persistent launch enabled eaz_search_begin skips the tree clear; stepping the same search simulation by simulation
+    (eaz_search_simulate) must then clear lazily without losing the root, also on buffers a previous run() left dirty."""
+    G, B, S = 8, 37, 12
+    am, params, state = deepsea_setup(eaz, G, seed=21, fill=0.4)
+    engine, env, net = _engine(eaz, G, am, params, state)
+    oenv, onet = oracle_deepsea(oracle, eaz, G, am, params, state)
+    blobs = random_states_deepsea(G, B, seed=22)
+    ex, xp, v, u, _ = onet.forward(oenv.observe(blobs))
+    beta = np.zeros(B, np.float32)
+    g = oracle.gumbel((41, 42), B * 2).reshape(B, 2)
+    otree = oracle.OracleTree(oenv, onet, B, S)
+    otree.begin(ex, v, u, blobs, beta, None, g, discount=0.997)
+    for sim in range(S):
+        otree.sim(sim)
+    search = engine.Search(env, net, B, S, discount=0.997)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    args = (cu(ex), cu(v), cu(u), cu(blobs), cu(beta), None, cu(g))
+    search.begin(*args)
+    search.run()
+    search.begin(*args)
+    for sim in range(S):
+        search.simulate(sim)
+    act, _ = search.finish()
+    _compare_tree(search, otree, "stepwise after run")
+    assert np.array_equal(act.cpu().numpy(), otree.finish()[0])
+    search.begin(*args)      # begin -> finish without a single simulation: the root-only tree
+    act0, aw0 = search.finish()
+    otree.begin(ex, v, u, blobs, beta, None, g, discount=0.997)
+    oact0, oaw0 = otree.finish()
+    _compare_tree(search, otree, "root only")
+    assert np.array_equal(act0.cpu().numpy(), oact0)
+
+
 @pytest.mark.parametrize("G,B,S,T,flags", [
     (8, 64, 16, 10, {}),
     (8, 64, 16, 6, dict(directed_exploration=True, exploration_beta=1.0)),
