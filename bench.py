@@ -154,8 +154,10 @@ def build_workload(name, args, device, rank):
             oenv = O.OracleEnv.connect4()
             onet = O.OracleNet.resnet(6, 7, 2, A, eaz.params.resnet_array_list(params, state, nb), num_blocks=nb)
             return oenv, onet, dict(discount=0.997, two_player=True), "connect_four"
+    disc = {"c2": 0.997, "c3": 0.97, "c4": 0.997}[name]
     return dict(w, name=name, B=B, S=S, T=T, A=A, env=env, net=net, search=search, desc=desc, data=data, net_kernel=net_kernel,
-                net_flops=net_flops, pmc_tag=pmc_tag, gather_kernel=gather_kernel, oracle=oracle)
+                net_flops=net_flops, pmc_tag=pmc_tag, gather_kernel=gather_kernel, oracle=oracle, discount=disc, two_player=name == "c4",
+                in_dim=env.obs_dim)
 
 
 def dry_run(args, world, rank):
@@ -310,66 +312,17 @@ def run_rank(args):
             torch.cuda.synchronize()
 
     wl = build_workload(args.workload, args, device, rank)
-    env, search, B, S, T = wl["env"], wl["search"], wl["B"], wl["S"], wl["T"]
-    states = env.init(B, key=rank)
-    outputs = None
-    gathered = None
+    B, S, T = wl["B"], wl["S"], wl["T"]
 
-    def one_step(i):
-        nonlocal outputs, gathered
-        outputs = search.selfplay(states, T, key=(1000 * rank + i), outputs=outputs)
-        if dist is not None:
-            # pool the trajectories of all ranks (replay-buffer landing zone): ONE all-gather of the packed block
-            block = pool.pack(outputs)
-            if rehearsal:
-                gathered = pool.all_gather_trajectories(block.cpu(), out=gathered)
-            else:
-                gathered = pool.all_gather_trajectories(block, out=gathered)
+    # ---- parity gate ("parity asserted before timing"): the engine against the CPU oracle on a 16-environment subset
+    # of the benchmark's inputs (same env / weights / novelty set, the first 16 initial states), rank 0 at N = 1 ----
+    parity = None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        parity = parity_gate(wl, args)
 
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        one_step(-1 - i)
-    if args.warmup == 0:
-        # graph capture, kernel module loading and (N > 1) the all-gather's buffers are one-time set-up: with --warmup 0 run one
-        # single real step through the same path before the clock starts (not a step of the workload: T = 1)
-        search.selfplay(states, 1, key=(1000 * rank + 999))
-        if dist is not None:
-            blk = pool.pack(search.selfplay(states, 1, key=(1000 * rank + 998)))
-            pool.all_gather_trajectories(blk.cpu() if rehearsal else blk)
-    # ---- timed region: EXACTLY K steps in the production configuration (one captured hipGraph per real step) ----
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(i)
-    sync()
-    dt = time.perf_counter() - t0
-    # ---- instrumented pass: the same kernels again with HIP events recorded on the launch stream around every kernel
-    # (event records cannot sit between the nodes of a replayed graph, so this pass uses plain stream launches; kernel
-    # durations are unaffected, only the host-side launch gaps differ).  Feeds `roofline`, never `value`. ----
-    search.profile(True)
-    search.profile_read(reset=True)
-    sync()
-    t1 = time.perf_counter()
-    n_instr = args.steps if args.workload != "c4" else 1
-    T_instr = T if args.workload != "c4" else 1
-    for i in range(n_instr):
-        search.selfplay(states, T_instr, key=(1000 * rank + 500 + i), outputs=outputs if T_instr == T else None, use_graph=False)
-    sync()
-    dt_instr = time.perf_counter() - t1
-    prof = search.profile_read(reset=True)
-    search.profile(False)
-    # kernel duration proper: the last simulation's forward launched 200x back to back inside ONE event pair (an event pair
-    # around a single launch also contains the launch gap, ~4 us; rocprofv3's per-kernel average does not)
-    net_replay_ms = search.profile_replay("net", 200 if args.workload != "c4" else 10)
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
+    main_oracle, main_cpu = wl["oracle"], wl["cpu"]
+    meas = measure(wl, args, rank, dist, rehearsal, dev, steps=args.steps, warmup=args.warmup)
+    dt = meas["dt"]
     env_steps = B * n_gpus * T * args.steps
     value = env_steps / dt if dt > 0 else 0.0
     result = {
@@ -390,100 +343,35 @@ def run_rank(args):
     }
     if rehearsal:
         result["rehearsal"] = f"{world} ranks share {ndev} GPU(s), gloo all-gather through host memory: launch-path check, not a scaling number"
-    # ---- roofline of the dominant kernel (network forward; the three heads self-play reads: value, ube, exploitation) -----
-    # FC: `achieved` counts the FLOPs the kernel EXECUTED: layers 2-3 are dense; in layer 1 every 64x4 observation block that
-    # is entirely zero is skipped (exact: fma(0,w,acc)=acc), so executed <= dense.  `dense_equiv` prices the same launches at
-    # the dense count of SURVEY.md 8(d) (2 * MACs of every layer).  ResNet: dense implicit GEMMs, executed == dense.
-    n_launch = max(prof["net"]["launches"], 1)
-    dense_flops = wl["net_flops"]
-    if wl["net_kernel"] == "fc16_forward_kernel":
-        heads = (0, 1, 2)
-        l23 = sum(2 * (H * H + H * (1 if h < 2 else wl["A"])) for h in heads) * B
-        flops = l23 + prof["net"]["layer1_ksteps"] * (16 * H * 4 * 2) / n_launch   # counter unit: one k-step of a 16-row tile
-    else:
-        flops = dense_flops
-    net_ms = net_replay_ms
-    ach = flops / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0
-    result["roofline"] = {"kernel": wl["net_kernel"], "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                          "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                          "avg_launch_us": 1e3 * net_ms, "avg_launch_us_event_pair_per_launch": 1e3 * prof["net"]["ms"] / n_launch,
-                          "launches": prof["net"]["launches"],
-                          "flops_per_launch": flops, "dense_flops_per_launch": dense_flops,
-                          "dense_equiv_tflops": dense_flops / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0}
-    # leaf gather: algorithmic bytes on the engine's compact layout = parent state + child state + observation row.
-    # C2 production path: the DeepSea step is fused into the tree kernel and the observation row is never materialised
-    # (one-hot index instead), so there is no gather launch; the standalone kernel is measured on a short unfused run
-    # (eaz_tune_set(EAZ_TUNE_FUSED_LEAF, 0)) for the record.
-    gather_note = None
-    if prof["gather"]["launches"] == 0:
-        engine.tune(fused_leaf=0)
-        s2 = engine.Search(env, wl["net"], B, S, discount=0.997)
-        st2 = env.init(B, key=rank)
-        s2.selfplay(st2, 1, key=7, use_graph=False)
-        s2.profile(True)
-        s2.profile_read(reset=True)
-        s2.selfplay(st2, 4, key=8, use_graph=False)
-        torch.cuda.synchronize()
-        prof_g = s2.profile_read(reset=True)
-        prof_g["gather"]["ms"] = s2.profile_replay("gather", 200) * prof_g["gather"]["launches"]   # back-to-back launches, no launch gap
-        del s2
-        engine.tune(fused_leaf=1)
-        gather_note = "standalone kernel of the unfused variant (EAZ_TUNE_FUSED_LEAF=0); the timed path fuses the step into tree_step_kernel"
-    else:
-        prof_g = prof
-    gbytes = B * (2 * env.state_bytes + env.obs_dim)
-    # per SIMULATION: c2 one launch, c3 one (word_size 16: the step kernel also emits the observation) and c4 two (env step +
-    # observation emit)
-    g_sims = prof_g["gather"]["launches"] if args.workload == "c2" else max(T_instr * n_instr * S, 1)
-    per_sim = max(1, round(prof_g["gather"]["launches"] / max(g_sims, 1)))
-    g_ms = prof_g["gather"]["ms"] / max(g_sims, 1)
-    gach = gbytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
-    # HBM-side traffic per launch from the PMC passes committed under profiles/ (rocprofv3 FETCH_SIZE / WRITE_SIZE cannot be
-    # collected from inside this process); only attached when the file was recorded for this workload
-    traffic = {}
-    pmc_file = None
-    for cand in ("r01_f_pmc_traffic.json", "r01_e_pmc_traffic.json", "r01_b_pmc_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", cand)) as f:
-                pmc = json.load(f)
-        except (OSError, ValueError):
-            continue
-        if wl["pmc_tag"] and pmc.get("workload") == wl["pmc_tag"]:
-            pmc_file = "profiles/" + cand
-            for kname, field in (("eaz::fc16_forward_kernel<2>", "roofline"), ("eaz::fc_forward_kernel", "roofline"),
-                                 ("eaz::leaf_gather_deepsea_kernel", "roofline_gather")):
-                k = pmc["kernels"].get(kname)
-                if k and field not in traffic:
-                    # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE tallies a wide coalesced streaming read (16 B per lane) at
-                    # half its bytes -> doubled for the forward kernel, whose fetches are its 16-B-per-lane weight streams;
-                    # WRITE_SIZE is exact for 16-B-per-lane stores.  The gather's reads are single scattered 16-B state loads
-                    # (uncalibrated width): taken raw.
-                    fcorr = 2.0 if field == "roofline" else 1.0
-                    traffic[field] = 1024.0 * (fcorr * k.get("FETCH_SIZE_KB_per_launch", 0.0) + k.get("WRITE_SIZE_KB_per_launch", 0.0))
-            break
-    if "roofline" in traffic:
-        result["roofline"]["traffic"] = traffic["roofline"]
-        result["roofline"]["traffic_source"] = pmc_file + " (2 x FETCH_SIZE [gfx950 16-B/lane correction] + WRITE_SIZE, bytes per launch)"
-    result["roofline_gather"] = {"kernel": wl["gather_kernel"], "bound": "hbm", "achieved": gach, "peak": PEAK_HBM_GBPS,
-                                 "unit": "GB/s", "frac": gach / PEAK_HBM_GBPS, "traffic": None, "avg_launch_us": 1e3 * g_ms,
-                                 "launches": prof_g["gather"]["launches"] // per_sim, "bytes_per_launch": gbytes}
-    if gather_note:
-        result["roofline_gather"]["note"] = gather_note
-    if "roofline_gather" in traffic:
-        result["roofline_gather"]["traffic"] = traffic["roofline_gather"]
-    result["kernel_ms_instrumented_pass"] = {k: round(v["ms"], 3) for k, v in prof.items()}
-    result["instrumented_pass_env_steps_per_s"] = B * T_instr * n_instr / dt_instr
+    result.update(meas["fields"])
+    if parity is not None:
+        result["parity_gate"] = parity
+
+    # ---- the other single-GPU configurations of BASELINE.json, short passes after the timed region (driver-visible C3 / C4 numbers) ----
+    if rank == 0 and n_gpus == 1 and args.workload == "c2" and not args.no_extra and not args.batch and not args.sims:
+        result["extra"] = {}
+        for name, (xs, xw, xt) in (("c3", (2, 1, 0)), ("c4", (1, 1, 2))):
+            xargs = argparse.Namespace(**vars(args))
+            xargs.workload, xargs.selfplay_steps = name, xt
+            wl = meas = None
+            torch.cuda.empty_cache()
+            wl = build_workload(name, xargs, device, rank)
+            meas = measure(wl, xargs, rank, None, False, dev, steps=xs, warmup=xw)
+            result["extra"][name] = dict({"metric": wl["metric"], "value": wl["B"] * wl["T"] * xs / meas["dt"], "unit": "env-steps/s",
+                                          "steps": xs, "warmup": xw, "ms_per_step": 1e3 * meas["dt"] / xs,
+                                          "config": {"workload": wl["desc"]}}, **meas["fields"])
+        wl = meas = None
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload, rank 0 at N = 1 only -------------------
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import eaz_oracle as O
 
-        cb = args.cpu_sample_batch or wl["cpu"][0]
-        ct = args.cpu_sample_steps or wl["cpu"][1]
+        cb = args.cpu_sample_batch or main_cpu[0]
+        ct = args.cpu_sample_steps or main_cpu[1]
         ncores = cpu_share()
         O.lib().eazo_set_num_threads(ncores)
-        oenv, onet, okw, oname = wl["oracle"](O)
+        oenv, onet, okw, oname = main_oracle(O)
         ost = oenv.init(cb)
         c0 = time.perf_counter()
         O.selfplay(oenv, onet, ost, T=ct, S=S, key=(0, 0), **okw)
@@ -495,6 +383,167 @@ def run_rank(args):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def parity_gate(wl, args):
+    """16 environments of the benchmark's inputs through the engine and through the CPU oracle: actions and states must be bit-identical,
+    values within 1e-5 (the north-star tolerance).  Raises before anything is timed if they are not."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import eaz_oracle as O
+
+    nb, nt = 16, 2 if wl["name"] != "c4" else 1
+    S = wl["S"] if wl["name"] != "c4" else 32      # connect_four on the CPU: a shorter search keeps the gate at a few seconds
+    kw = dict(discount=wl["discount"], two_players_game=wl["two_player"])
+    search = engine.Search(wl["env"], wl["net"], nb, S, **kw)
+    st = wl["env"].init(nb, key=0)
+    out = search.selfplay(st, nt, key=4242)
+    torch.cuda.synchronize()
+    oenv, onet, okw, oname = wl["oracle"](O)
+    ost = oenv.init(nb)
+    ref = O.selfplay(oenv, onet, ost, T=nt, S=S, key=engine.key_pair(4242), **okw)
+    ok_int = bool(np.array_equal(out["action"].cpu().numpy(), ref["action"]) and np.array_equal(out["state"].cpu().numpy(), ref["state"])
+                  and np.array_equal(st.cpu().numpy(), ost))
+    err = max(float(np.max(np.abs(out[k].cpu().numpy() - ref[k]))) for k in
+              ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction", "q_values_epistemic_variance"))
+    if not ok_int or not err <= 1e-5:
+        raise SystemExit(f"bench.py parity gate FAILED on {oname}: integer results identical = {ok_int}, max float error = {err:.3g}")
+    del search
+    return {"checked": f"{oname}: {nb} environments x {nt} real steps x {S} simulations, engine vs CPU oracle (in-repo restatement; emctx parity unpinned)",
+            "actions_states_bit_identical": ok_int, "max_abs_float_error": err, "tolerance": 1e-5}
+
+
+def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
+    """warmup + EXACTLY `steps` timed selfplay() calls (barrier + synchronize on both sides, max over ranks), then the instrumented pass
+    that feeds `roofline`.  -> dict(dt, fields)"""
+    env, search, B, S, T, name = wl["env"], wl["search"], wl["B"], wl["S"], wl["T"], wl["name"]
+    states = env.init(B, key=rank)
+    outputs = None
+    gathered = None
+
+    def one_step(i):
+        nonlocal outputs, gathered
+        outputs = search.selfplay(states, T, key=(1000 * rank + i), outputs=outputs)
+        if dist is not None:
+            # pool the trajectories of all ranks (replay-buffer landing zone): ONE all-gather of the packed block
+            block = pool.pack(outputs)
+            if rehearsal:
+                gathered = pool.all_gather_trajectories(block.cpu(), out=gathered)
+            else:
+                gathered = pool.all_gather_trajectories(block, out=gathered)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(warmup):
+        one_step(-1 - i)
+    if warmup == 0:
+        # graph capture, kernel module loading and (N > 1) the all-gather's buffers are one-time set-up: with --warmup 0 run one
+        # single real step through the same path before the clock starts (not a step of the workload: T = 1)
+        search.selfplay(states, 1, key=(1000 * rank + 999))
+        if dist is not None:
+            blk = pool.pack(search.selfplay(states, 1, key=(1000 * rank + 998)))
+            pool.all_gather_trajectories(blk.cpu() if rehearsal else blk)
+    # ---- timed region: EXACTLY K steps in the production configuration (one captured hipGraph per real step) ----
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one_step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    # ---- instrumented pass: the same kernels again with HIP events recorded on the launch stream around every kernel
+    # (event records cannot sit between the nodes of a replayed graph, so this pass uses plain stream launches; kernel
+    # durations are unaffected, only the host-side launch gaps differ).  Feeds `roofline`, never `value`. ----
+    search.profile(True)
+    search.profile_read(reset=True)
+    sync()
+    t1 = time.perf_counter()
+    n_instr = min(steps, 2) if name != "c4" else 1
+    T_instr = T if name != "c4" else 1
+    for i in range(n_instr):
+        search.selfplay(states, T_instr, key=(1000 * rank + 500 + i), outputs=outputs if T_instr == T else None, use_graph=False)
+    sync()
+    dt_instr = time.perf_counter() - t1
+    prof = search.profile_read(reset=True)
+    search.profile(False)
+    persistent = prof["search"]["launches"] > 0
+    fields = {}
+    # ---- roofline of the dominant kernel.  FLOPs counted are the ones the kernel EXECUTES (the three heads self-play reads: value, ube,
+    # one policy head): layers 2-3 dense; layer 1 of a one-hot DeepSea row is a row gather (0 FLOPs, exact: every other term of the
+    # chain is fma(0, w, acc) = acc) and on dense rows only the non-zero 64x4 blocks.  `dense_equiv` prices the same launches at the
+    # dense count of SURVEY.md 8(d) (2 * MACs of every layer).  ResNet: dense implicit GEMMs, executed == dense. ----
+    heads = (0, 1, 2)
+    A = wl["A"]
+    l23 = sum(2 * (H * H + H * (1 if h < 2 else A)) for h in heads) * B
+    dense_flops = wl["net_flops"]
+    if persistent:
+        # search_persist_kernel: ALL S simulations of a real step in one launch (trees in LDS, DeepSea step, S forwards of B leaves)
+        kname = "search_persist_kernel"
+        k_ms = search.profile_replay("search", 20)
+        n_launch = prof["search"]["launches"]
+        flops, dense = S * l23, S * dense_flops
+        pair_us = 1e3 * prof["search"]["ms"] / n_launch
+        algo = f"{S} simulations x {B} leaves x (layers 2-3 of 3 heads = {l23 // B} FLOP per leaf; layer 1 is a one-hot row gather)"
+    else:
+        kname = wl["net_kernel"]
+        k_ms = search.profile_replay("net", 200 if name != "c4" else 10)
+        n_launch = max(prof["net"]["launches"], 1)
+        if kname == "fc16_forward_kernel":
+            # counter unit: one k-step of a 16-row tile; never more than the dense layer 1 (padded k-steps of a partial block are not work)
+            l1 = min(prof["net"]["layer1_ksteps"] * (16 * H * 4 * 2) / n_launch, sum(2 * wl["in_dim"] * H for _ in heads) * B)
+            flops = l23 + l1
+        else:
+            flops = dense_flops
+        dense = dense_flops
+        pair_us = 1e3 * prof["net"]["ms"] / n_launch
+        algo = f"one forward of {B} rows"
+    ach = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    roof = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_us": 1e3 * k_ms,
+            "avg_launch_us_event_pair_per_launch": pair_us, "launches": n_launch, "flops_per_launch": flops, "flops_counted": algo,
+            "dense_flops_per_launch": dense, "dense_equiv_tflops": dense / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0}
+    # HBM-side traffic per launch from the PMC passes committed under profiles/ (rocprofv3 FETCH_SIZE / WRITE_SIZE cannot be collected
+    # from inside this process); only attached when the file was recorded for this workload and this kernel
+    for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
+        try:
+            with open(os.path.join(ROOT, "profiles", cand)) as f:
+                pmc = json.load(f)
+        except (OSError, ValueError):
+            continue
+        k = next((v for kn, v in pmc.get("kernels", {}).items() if kname in kn), None)
+        if wl["pmc_tag"] and pmc.get("workload") == wl["pmc_tag"] and k:
+            # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE tallies a wide coalesced streaming read (16 B per lane) at half its
+            # bytes -> doubled (the kernel's fetches are its 16-B-per-lane weight streams); WRITE_SIZE is exact for 16-B-per-lane stores
+            roof["traffic"] = 1024.0 * (2.0 * k.get("FETCH_SIZE_KB_per_launch", 0.0) + k.get("WRITE_SIZE_KB_per_launch", 0.0))
+            roof["traffic_source"] = f"profiles/{cand} (2 x FETCH_SIZE [gfx950 16-B/lane correction] + WRITE_SIZE, bytes per launch)"
+            break
+    fields["roofline"] = roof
+    # ---- leaf gather (north-star: >= 40 % of the HBM roof on the leaf-gather kernel) ----
+    gbytes = B * (2 * env.state_bytes + env.obs_dim)
+    if prof["gather"]["launches"] == 0:
+        fields["leaf_gather"] = {
+            "status": "retired for this configuration",
+            "why": "DeepSea's env.step is a few integer operations on a 16-byte state: the search kernel steps the chosen edge itself (child state "
+                   "stays in LDS) and hands the forward the flat index of the one-hot observation -- no leaf-gather launch and no observation row "
+                   "exists in the timed path.  At this batch size the standalone kernel of the unfused variant moves 4.3 MB per launch, below "
+                   "launch latency (0.16 of the HBM roof, profiles/r01_f_*); the target is meaningful only for C3 / C4 (extra.c3, extra.c4)"}
+    else:
+        sims = max(T_instr * n_instr * S, 1)
+        g_ms = prof["gather"]["ms"] / sims
+        gach = gbytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
+        fields["roofline_gather"] = {"kernel": wl["gather_kernel"], "bound": "hbm", "achieved": gach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                     "frac": gach / PEAK_HBM_GBPS, "traffic": None, "avg_us_per_simulation": 1e3 * g_ms,
+                                     "bytes_per_simulation": gbytes,
+                                     "note": "event pairs around the env-step (+ observation) launches of one simulation; interpreter / "
+                                             "launch-latency bound, not bandwidth bound (DESIGN.md 4.4)"}
+    fields["kernel_ms_instrumented_pass"] = {k: round(v["ms"], 3) for k, v in prof.items()}
+    fields["instrumented_pass_env_steps_per_s"] = B * T_instr * n_instr / dt_instr
+    return dict(dt=dt, fields=fields)
 
 
 if __name__ == "__main__":

@@ -1437,7 +1437,7 @@ extern "C" int eaz_profile_net_ksteps(eaz_search* s, uint64_t* executed, int res
 }
 
 extern "C" int eaz_profile_replay(eaz_search* s, int cls, int iters, double* ms_total, void* stream) {
-    ARG_OK(s && ms_total && iters > 0 && (cls == EAZ_K_NET || cls == EAZ_K_GATHER));
+    ARG_OK(s && ms_total && iters > 0 && (cls == EAZ_K_NET || cls == EAZ_K_GATHER || cls == EAZ_K_SEARCH));
     HIP_OK(hipSetDevice(s->ctx->device));
     hipStream_t st = S(stream);
     const bool fused = s->fuse_leaf != 0;
@@ -1445,7 +1445,12 @@ extern "C" int eaz_profile_replay(eaz_search* s, int cls, int iters, double* ms_
         return fail("eaz_profile_replay: the standalone leaf gather exists for unfused DeepSea searches only");
     HeadList hl{3, {0, 1, s->opts.exploration ? 3 : 2, 0}};
     NetOut o{s->opts.exploration ? nullptr : s->d_exploit, s->opts.exploration ? s->d_explore : nullptr, s->d_v, s->d_u};
+    if (cls == EAZ_K_SEARCH && !(s->persist_ok && g_persist))
+        return fail("eaz_profile_replay: this search does not run as one persistent launch (EAZ_TUNE_PERSIST, eligibility: eaz.h)");
     auto once = [&]() -> int {
+        // the persistent search re-reads the root that the last eaz_search_begin left in the tree arrays (timing only: the statistics of
+        // node 0 keep the previous launch's totals)
+        if (cls == EAZ_K_SEARCH) return persist_launch(s, st);
         if (cls == EAZ_K_NET) return fused ? fc_onehot_launch(s->net, s->B, s->d_leaf_hot, s->d_novelty, o, hl, st) : fc_launch(s->net, s->B, s->d_obs, o, hl, st);
         leaf_gather_deepsea_kernel<<<cdiv(static_cast<long>(s->B) * 64, 256), 256, 0, st>>>(s->env->dev, s->tree, s->d_obs, s->d_next_reward,
                                                                                           s->d_next_term, s->d_next_legal);

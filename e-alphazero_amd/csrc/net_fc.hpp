@@ -565,9 +565,7 @@ constexpr int kF16HBytes = kF16HFloats * 4;              // 17 408
 // workgroups per CU -- the novelty workgroups of the one-hot launch then run beside the three forward workgroups of a CU)
 constexpr int kF16LdsBase = 2 * kF16HBytes + kFcMaskBytes;
 __host__ __device__ inline int f16_w3ld(int A) { return A <= kFcW3Cols ? ((A + 3) & ~3) : 0; }
-// + the layer-3 partial sums of the narrow heads: [4 waves][16 rows][w3ld] floats
-__host__ __device__ inline int f16_part_off(int A) { return kF16LdsBase + kFcH * f16_w3ld(A) * 4; }
-__host__ __device__ inline int f16_lds_bytes(int A) { return f16_part_off(A) + 4 * 16 * f16_w3ld(A) * 4; }
+__host__ __device__ inline int f16_lds_bytes(int A) { return kF16LdsBase + kFcH * f16_w3ld(A) * 4; }
 static_assert(kF16M * kFcKC <= kF16HBytes, "the observation chunk (16 rows x 1024 inputs, uint8) aliases the H2 tile");
 
 __device__ __forceinline__ int h16_off(int k, int row) { return k * 16 + (k >> 2) * 4 + row; }
@@ -841,7 +839,9 @@ __global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn i
     if (narrow) {
         // every wave: the chain over the 64 hidden columns it owns (quarter `wave` of k), 16 dependent MFMAs; the four partial sums
         // meet in LDS and wave 0 adds them as ((c0 + c1) + (c2 + c3)) + b
-        float* part = reinterpret_cast<float*>(lds + f16_part_off(net.A));
+        // partial sums [16 rows][w3ld] of wave w: in the H2 columns that wave owns (dead once its chain operands are read; 1088 floats apart)
+        float* part = H2;
+        constexpr int kPartStride = 64 * 16 + 16 * 4;  // h16_off(64 w, 0)
         floatx4 a3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
         // lanes beyond the staged columns read column 0: their output columns are never emitted (r < No below)
         const float* w3p = W3s + (n0 + kq) * w3ld + (r < w3ld ? r : 0);
@@ -850,7 +850,7 @@ __global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn i
             a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(H2[h16_off(n0 + 4 * ks + kq, r)], w3p[(4 * ks) * w3ld], a3, 0, 0, 0);
         if (r < w3ld) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) part[(wave * 16 + 4 * kq + reg) * w3ld + r] = a3[reg];
+            for (int reg = 0; reg < 4; ++reg) part[wave * kPartStride + (4 * kq + reg) * w3ld + r] = a3[reg];
         }
         __syncthreads();
         if (wave != 0) return;
@@ -859,8 +859,8 @@ __global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn i
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int row = 4 * kq + reg;
-                const float c0 = part[(0 * 16 + row) * w3ld + r], c1 = part[(1 * 16 + row) * w3ld + r];
-                const float c2 = part[(2 * 16 + row) * w3ld + r], c3 = part[(3 * 16 + row) * w3ld + r];
+                const float c0 = part[row * w3ld + r], c1 = part[kPartStride + row * w3ld + r];
+                const float c2 = part[2 * kPartStride + row * w3ld + r], c3 = part[3 * kPartStride + row * w3ld + r];
                 emit(row, r, ((c0 + c1) + (c2 + c3)) + bo);
             }
         }

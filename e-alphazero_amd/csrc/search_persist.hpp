@@ -47,7 +47,7 @@ constexpr int kPsA = 2;          // actions (DeepSea)
 #endif
 constexpr int kPsDepth = EAZ_PS_DEPTH;  // k-steps of the W2 stream in flight per wave (16 or 32; 4 VGPRs each)
 constexpr int kPsARing = 8;             // A operands (LDS) read this many k-steps ahead
-static_assert(64 % kPsDepth == 0 && kPsDepth % kPsARing == 0, "a head's 64 k-steps are whole rounds of kPsDepth");
+static_assert(64 % kPsDepth == 0 && 64 / kPsDepth >= 2 && kPsDepth % kPsARing == 0, "a head's 64 k-steps are >= 2 whole rounds of kPsDepth");
 
 // node record in LDS (32-bit words)
 enum : int {
@@ -79,7 +79,7 @@ __host__ __device__ inline PersistLds persist_lds(int N, int S, int G) {
     PersistLds L;
     L.tstride = (N * PR_WORDS) | 1;  // odd: trees start in different banks
     int o = 0;
-    L.off_h1 = o; o += kF16HBytes;
+    L.off_h1 = o; o += 2 * kF16HBytes;  // two H1 tiles: the helper fills the next head's while layer 2 reads the current one
     L.off_h2 = o; o += kF16HBytes;
     L.off_part = o; o += 3 * 4 * kPsTrees * 4 * 4;  // layer-3 partial sums [3 heads][4 waves][16 rows][4 outputs]
     L.off_w3 = o; o += 3 * kFcH * 4 * 4;
@@ -159,6 +159,40 @@ __device__ __forceinline__ int ps_root_pick(const Group<1, kPsA>& g, const NodeR
     return g.argmax(sc);
 }
 
+// One round of layer 2: kPsDepth k-steps of four MFMAs each on the prefetched weights Bq, every k-step followed by the refill of its
+// registers (buffer load, k-step in the scalar offset) and of its A-operand slot.  CHAIN: the round also carries the 16 dependent MFMAs
+// of the previous head's layer-3 quarter chain, one per k-step, operands kChRing k-steps ahead.
+constexpr int kChRing = 4;
+template <bool CHAIN>
+__device__ __forceinline__ void ps_round(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDepth], float (&av)[kPsARing], const float* apn,
+                                         __amdgpu_buffer_rsrc_t rs, int voff, int sbase, floatx4& a3, const float* hpA, const float* wpB) {
+    float cha[kChRing], chb[kChRing];
+    if constexpr (CHAIN) {
+#pragma unroll
+        for (int q = 0; q < kChRing; ++q) { cha[q] = hpA[68 * q]; chb[q] = wpB[4 * q]; }
+    }
+#pragma unroll
+    for (int i = 0; i < kPsDepth; ++i) {
+#if EAZ_PS_EXPERIMENT == 2   /* timing experiments of the diagnostic build only (results are wrong): 1 = no weight refills, 2 = no MFMAs */
+        acc[0][0] += av[i % kPsARing] * Bq[i][0]; acc[1][0] += Bq[i][1]; acc[2][0] += Bq[i][2]; acc[3][0] += Bq[i][3];
+#else
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i % kPsARing], Bq[i][c], acc[c], 0, 0, 0);
+#endif
+        if constexpr (CHAIN) {
+            if (i < 16) {
+                a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(cha[i % kChRing], chb[i % kChRing], a3, 0, 0, 0);
+                if (i + kChRing < 16) { cha[i % kChRing] = hpA[68 * (i + kChRing)]; chb[i % kChRing] = wpB[4 * (i + kChRing)]; }
+            }
+        }
+#if EAZ_PS_EXPERIMENT != 1
+        Bq[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sbase + i * 4096, 0));
+#endif
+        av[i % kPsARing] = apn[i * 68];
+        __builtin_amdgcn_sched_barrier(0);  // keep every refill right behind the k-step that freed its registers
+    }
+}
+
 __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const TreeDev& t = a.t;
@@ -229,7 +263,7 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
     __syncthreads();
 
     // Both roles run the same barrier sequence per simulation:
-    //   S0 hot[] ready | S1 H1(head 0) | S2 H2(0) | S3 H1(1) | S4 H2(1) | S5 H1(2) | S6 H2(2) | S7 all head outputs
+    //   S0 hot[] ready | S1 H1(head 0) | S2, S4, S6 layer-3 partial sums of head 0, 1, 2 (+ H1 of the next head) | S7 all head outputs
     if (helper) {
         // =========================================================== helper wave ===========================================================
         // layer-1 bias of the two heads whose W1 rows this wave gathers (lane = 4 columns)
@@ -249,19 +283,12 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
             for (int i = 0; i < 16; ++i) gw[i] = *reinterpret_cast<const floatx4*>(W1g[0] + static_cast<long>(M.hot[i]) * kFcH);
             __syncthreads();  // S1
             EAZ_PSTAMP(4);
-            if (lane < kPsTrees) {
-                // novelty lookup of the one-hot observation (hashes.py:23-38,162-229): the hash index of a row that is zero except
-                // obs[hot] = 1 depends on `hot` only and is tabulated once per network (NetDev::hot_index)
-                const uint32_t index = a.net.hot_index[M.hot[lane]];
-                const bool seen = a.net.bitset ? ((a.net.bitset[index >> 3] >> (index & 7u)) & 1u) != 0 : false;
-                M.o_nov[lane] = (seen ? 0.0f : 1.0f) * a.net.nov_scale;                                     // fully_connected.py:90
-            }
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
-                __syncthreads();  // S2 / S4 / S6: the partial sums of head h are complete, H1 is free
                 if (h < 2) {
-                    // H1 of head h + 1: relu(W1[hot] + b1) (exactly fmaf(1, w, +0) per column: every other term of the reference's chain
-                    // is fmaf(0, w, acc) = acc)
+                    // H1 of head h + 1 into the other tile, under layer 2 of head h: relu(W1[hot] + b1) (exactly fmaf(1, w, +0) per column:
+                    // every other term of the reference's chain is fmaf(0, w, acc) = acc)
+                    float* H1n = H1 + ((h + 1) & 1) * kF16HFloats;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
 #pragma unroll
@@ -272,29 +299,37 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
                                 const float v = __builtin_fmaf(1.0f, gw[4 * i4 + i][c], 0.0f) + hb1[h][c];
                                 o[i] = v > 0.0f ? v : 0.0f;
                             }
-                            *reinterpret_cast<floatx4*>(H1 + h16_off(4 * lane + c, 4 * i4)) = o;
+                            *reinterpret_cast<floatx4*>(H1n + h16_off(4 * lane + c, 4 * i4)) = o;
                         }
                     }
-                    __syncthreads();  // S3 / S5: H1 of head h + 1
-                    if (h == 0) {
+                }
+                if (h == 0 && lane < kPsTrees) {
+                    // novelty lookup of the one-hot observation (hashes.py:23-38,162-229): the hash index of a row that is zero except
+                    // obs[hot] = 1 depends on `hot` only and is tabulated once per network (NetDev::hot_index)
+                    const uint32_t index = a.net.hot_index[M.hot[lane]];
+                    const bool seen = a.net.bitset ? ((a.net.bitset[index >> 3] >> (index & 7u)) & 1u) != 0 : false;
+                    M.o_nov[lane] = (seen ? 0.0f : 1.0f) * a.net.nov_scale;                                 // fully_connected.py:90
+                }
+                __syncthreads();  // S2 / S4 / S6: the partial sums of head h and H1 of head h + 1 are complete
+                if (h == 0) {
+                    // W1 rows of the third head (its H1 tile is the first head's, free from here on)
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) gw[i] = *reinterpret_cast<const floatx4*>(W1g[1] + static_cast<long>(M.hot[i]) * kFcH);
-                    }
+                    for (int i = 0; i < 16; ++i) gw[i] = *reinterpret_cast<const floatx4*>(W1g[1] + static_cast<long>(M.hot[i]) * kFcH);
                 }
-                // ---- layer 3, second half + head activation: ((c0 + c1) + (c2 + c3)) + b of the four quarter chains that waves 0-3 ran
-                // over their own hidden columns (o_linear_parts), lane = (row, output) ----
-                {
-                    const int hid = hidv[h], No = hid < 2 ? 1 : kPsA;
-                    const int row = lane & 15, o = lane >> 4;
-                    if (o < No) {
-                        const float* pp = part + (h * 4 * kPsTrees + row) * 4 + o;
-                        const float c0 = pp[0], c1 = pp[kPsTrees * 4], c2 = pp[2 * kPsTrees * 4], c3 = pp[3 * kPsTrees * 4];
-                        const float z = ((c0 + c1) + (c2 + c3)) + a.net.b[hid * 3 + 2][o];
-                        if (hid == 0) M.o_value[row] = det_tanh(z);                                     // fully_connected.py:55
-                        else if (hid == 1) M.o_ube[row] = (0.5f * (det_tanh(z) + 1.0f)) * a.net.max_u;  // :64, :93
-                        else M.o_logit[row][o] = z;                                                     // :68-81
-                    }
-                }
+            }
+            // ---- layer 3, second half + head activation, all three heads at once: lane = (row, output slot) with slot 0 = value, 1 = ube,
+            // 2-3 = policy logits; ((c0 + c1) + (c2 + c3)) + b of the four quarter chains that waves 0-3 ran over their own hidden
+            // columns (o_linear_parts) ----
+            {
+                const int row = lane & 15, slot = lane >> 4;
+                const int hid = slot < 2 ? slot : a.head[2], o = slot < 2 ? 0 : slot - 2;
+                const int hp = hidv[0] == hid ? 0 : (hidv[1] == hid ? 1 : 2);  // position of that head in this workgroup's order
+                const float* pp = part + (hp * 4 * kPsTrees + row) * 4 + o;
+                const float c0 = pp[0], c1 = pp[kPsTrees * 4], c2 = pp[2 * kPsTrees * 4], c3 = pp[3 * kPsTrees * 4];
+                const float z = ((c0 + c1) + (c2 + c3)) + a.net.b[hid * 3 + 2][o];
+                if (hid == 0) M.o_value[row] = det_tanh(z);                                     // fully_connected.py:55
+                else if (hid == 1) M.o_ube[row] = (0.5f * (det_tanh(z) + 1.0f)) * a.net.max_u;  // :64, :93
+                else M.o_logit[row][o] = z;                                                     // :68-81
             }
             EAZ_PSTAMP(5);
             __syncthreads();  // S7
@@ -322,8 +357,7 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
         floatx4 Bq[kPsDepth];
 #pragma unroll
         for (int i = 0; i < kPsDepth; ++i) Bq[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(W2r[0], voff, i * 4096, 0));
-        EnvDev env = a.env;
-        if (a.amap_lds) env.action_map = amap;
+        const EnvDev& env = a.env;
         // tree lanes: 16 per tree
         const int ti = tid >> 4, tj = tid & 15;
         uint32_t* T = trees + ti * L.tstride;
@@ -374,9 +408,14 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
                     const int cnt_i = static_cast<int>(R[PR_NODE_VISITS]), cvis = static_cast<int>(R[PR_VISITS + pa]);
                     const float nv = u2f(R[PR_NODE_VALUE]), nvar = u2f(R[PR_NODE_VAR]);
                     const int top = (D - c * 16 < 16 ? D - c * 16 : 16) - 1;  // deepest level of this chunk
+                    // deepest level of the four trees of this wavefront: levels beyond it are skipped by a scalar branch
+                    int wtop = __builtin_amdgcn_readlane(top, 0);
+                    { const int t1 = __builtin_amdgcn_readlane(top, 16), t2 = __builtin_amdgcn_readlane(top, 32), t3 = __builtin_amdgcn_readlane(top, 48);
+                      wtop = wtop > t1 ? wtop : t1; wtop = wtop > t2 ? wtop : t2; wtop = wtop > t3 ? wtop : t3; }
                     float G = Gin, U = Uin;
 #pragma unroll
                     for (int s = 15; s >= 0; --s) {
+                        if (s > wtop) continue;
                         const float rs = __shfl(er, s, 16), dd = __shfl(ed, s, 16);
                         if (s <= top && s >= tj) {
                             G = rs + dd * G;
@@ -463,7 +502,24 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
                 }
                 const int nd = nx < 0 ? sim + 1 : nx;
                 M.parent[ti] = node; M.action[ti] = act; M.dst[ti] = nd; M.D[ti] = depth;
-                const eaz_deepsea_state ns = ds_step(env, ps_unpack(T[node * PR_WORDS + PR_STATE]), act);  // context.py:125-127
+                eaz_deepsea_state ns = ps_unpack(T[node * PR_WORDS + PR_STATE]);  // context.py:125-127
+                if (ns.terminated | ns.truncated) {
+                    ns.reward = 0.0f;  // pgx.Env.step on a finished episode: no-op with zero rewards (envs.hpp ds_step)
+                } else {
+                    // ds_step (deep_sea.py:59-81) with the action map in LDS
+                    const int Gd = env.G;
+                    ns.step_count += 1;
+                    int rr = ns.step_count - 1;
+                    rr = rr < 0 ? 0 : (rr > Gd - 1 ? Gd - 1 : rr);
+                    const int flip = (a.amap_lds ? amap[rr * Gd + ns.pos] : env.action_map[rr * Gd + ns.pos]) != 0;  // :62
+                    const int shift = ((act == 0) ^ flip) ? -1 : 1;                                                   // :63
+                    int pos = ns.pos + shift;
+                    pos = pos < 0 ? 0 : (pos > Gd - 1 ? Gd - 1 : pos);                                                // :64
+                    const int term = ns.step_count >= Gd - 1;                                                         // :72
+                    ns.pos = pos;
+                    ns.terminated = static_cast<uint8_t>(term);
+                    ns.reward = (term && pos == Gd - 1) ? 1.0f : 0.0f;                                                // :74-78
+                }
                 T[nd * PR_WORDS + PR_STATE] = ps_pack(ns);
                 M.o_reward[ti] = ns.reward;   // rewards[b, current_player], single player (deep_sea.py:100-102)
                 M.o_term[ti] = ns.terminated;
@@ -494,46 +550,39 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
                 // ---- layer 2: [16 x 256] x [256 x 256]; the weight stream runs kPsDepth k-steps ahead and on into the next head (next
-                // simulation); A operands come from LDS kPsARing k-steps ahead ----
+                // simulation); A operands come from LDS kPsARing k-steps ahead.  The first round of heads 1 and 2 also carries the
+                // layer-3 quarter chain of the head before: 16 dependent MFMAs, one per k-step, hidden between independent ones. ----
                 floatx4 acc[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
                 EAZ_PSTAMP(6 + 3 * h);
-                const float* Ap = H1 + kq * 16 + r;  // h16_off(4 ks + kq, r) = 68 ks + 16 kq + r
+                const float* Ap = H1 + (h & 1) * kF16HFloats + kq * 16 + r;  // h16_off(4 ks + kq, r) = 68 ks + 16 kq + r
                 float av[kPsARing];
 #pragma unroll
                 for (int i = 0; i < kPsARing; ++i) av[i] = Ap[i * 68];
-                // The round loop is NOT unrolled: with all 192 refill addresses of the three heads loop-invariant the compiler precomputes
-                // and spills them.
+                // quarter chain of head h - 1: A = the H2 columns this wave wrote before the barrier, B = W3 rows of its quarter of k
+                floatx4 a3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+                const float* hpA = H2 + h16_off(n0 + kq, r);                                       // H2[h16_off(n0 + 4 ks + kq, r)] = hpA[68 ks]
+                const float* wpB = W3s + ((h > 0 ? h - 1 : 0) * 4 + (r & 3)) * kFcH + n0 + kq;     // W3[n0 + 4 ks + kq][r] (columns >= 4 repeat 0..3, dropped)
+                // first round (peeled: it carries the chain), then the other rounds as a real loop -- with all 192 refill addresses of the
+                // three heads loop-invariant the compiler would precompute and spill them
+                if (h > 0) ps_round<true>(acc, Bq, av, Ap + kPsARing * 68, W2r[h], voff, 4096 * kPsDepth, a3, hpA, wpB);
+                else ps_round<false>(acc, Bq, av, Ap + kPsARing * 68, W2r[h], voff, 4096 * kPsDepth, a3, hpA, wpB);
+                if (h > 0 && r < 4) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) part[(((h - 1) * 4 + wave) * kPsTrees + 4 * kq + reg) * 4 + r] = a3[reg];
+                }
 #pragma unroll 1
-                for (int rd = 0; rd < 64 / kPsDepth; ++rd) {
+                for (int rd = 1; rd < 64 / kPsDepth; ++rd) {
                     const bool same = rd + 1 < 64 / kPsDepth;  // the refills of the last round belong to the next head
                     const __amdgpu_buffer_rsrc_t rs = same ? W2r[h] : W2r[h == 2 ? 0 : h + 1];
                     const int sbase = same ? 4096 * kPsDepth * (rd + 1) : 0;
-                    const float* apn = Ap + (rd * kPsDepth + kPsARing) * 68;  // reads past k-step 63 land in the H2 tiles and are never used
-#pragma unroll
-                    for (int i = 0; i < kPsDepth; ++i) {
-#if EAZ_PS_EXPERIMENT == 2   /* timing experiments of the diagnostic build only (results are wrong): 1 = no weight refills, 2 = no MFMAs */
-                        acc[0][0] += av[i % kPsARing] * Bq[i][0]; acc[1][0] += Bq[i][1]; acc[2][0] += Bq[i][2]; acc[3][0] += Bq[i][3];
-#else
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i % kPsARing], Bq[i][c], acc[c], 0, 0, 0);
-#endif
-#if EAZ_PS_EXPERIMENT != 1
-                        Bq[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sbase + i * 4096, 0));
-#endif
-                        av[i % kPsARing] = apn[i * 68];
-                        __builtin_amdgcn_sched_barrier(0);  // keep every refill right behind the k-step that freed its registers
-                    }
+                    // reads past k-step 63 land in the next tile and are never used
+                    ps_round<false>(acc, Bq, av, Ap + (rd * kPsDepth + kPsARing) * 68, rs, voff, sbase, a3, hpA, wpB);
                 }
-                // layer-3 weights of this wave's quarter of k (B operand of the chain below): requested before the H2 round trip
-                float wb[16];
-                {
-                    const float* wpB = W3s + (h * 4 + (r & 3)) * kFcH + n0 + kq;  // W3[n0 + 4 ks + kq][r] (columns >= 4 repeat 0..3 and are dropped)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) wb[q] = wpB[4 * q];
-                }
-                // relu(acc + b2) -> H2: lane (r, kq) holds rows 4 kq .. +3 of column n0 + 4r + c
+                // relu(acc + b2) -> H2: lane (r, kq) holds rows 4 kq .. +3 of column n0 + 4r + c.  Every wave reads back only the columns it
+                // wrote (the transposition of its D tile into A operands of the quarter chain), so the tile needs no workgroup barrier of its
+                // own: DS operations of a wave execute in order, and the next head's stores come 8 k cycles after the last read-back.
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     floatx4 o;
@@ -544,23 +593,25 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
                     }
                     *reinterpret_cast<floatx4*>(H2 + h16_off(col + c, 4 * kq)) = o;
                 }
-                // ---- layer 3, first half: the chain over the 64 hidden columns this wave owns (quarter `wave` of k): 16 dependent MFMAs
-                // (k ascending = the oracle's fmaf chain of that quarter).  Only columns written by this wave are read back, so the
-                // transposition through LDS needs no workgroup barrier (DS operations of a wave execute in order). ----
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                {
-                    const float* hpA = H2 + h16_off(n0 + kq, r);  // H2[h16_off(n0 + 4 ks + kq, r)] = hpA[68 ks]
-                    floatx4 a3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (h == 2) {
+                    // ---- the last head's quarter chain has no layer 2 to hide under: 16 dependent MFMAs (k ascending = the oracle's fmaf chain
+                    // of that quarter) ----
+                    const float* hpA = H2 + h16_off(n0 + kq, r);
+                    const float* wpB = W3s + (h * 4 + (r & 3)) * kFcH + n0 + kq;
+                    float wb[16];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(hpA[68 * q], wb[q], a3, 0, 0, 0);
+                    for (int q = 0; q < 16; ++q) wb[q] = wpB[4 * q];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    floatx4 z3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) z3 = __builtin_amdgcn_mfma_f32_16x16x4f32(hpA[68 * q], wb[q], z3, 0, 0, 0);
                     if (r < 4) {
 #pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) part[((h * 4 + wave) * kPsTrees + 4 * kq + reg) * 4 + r] = a3[reg];
+                        for (int reg = 0; reg < 4; ++reg) part[((h * 4 + wave) * kPsTrees + 4 * kq + reg) * 4 + r] = z3[reg];
                     }
                 }
                 EAZ_PSTAMP(7 + 3 * h);
-                __syncthreads();  // S2 / S4 / S6
-                if (h < 2) __syncthreads();  // S3 / S5: the helper wrote H1 of head h + 1
+                __syncthreads();  // S2 / S4 / S6: H1 of head h + 1 (helper) visible; after S6 all partial sums are
             }
             EAZ_PSTAMP(5);
             __syncthreads();  // S7: the heads' outputs

@@ -160,6 +160,20 @@ struct Group {
     __device__ __forceinline__ void softmax(const float (&x)[APL], float (&p)[APL]) const {
         const float m = vmax(x);
         float e[APL];
+        if constexpr (LPT == 1 && APL == 2) {
+            // two real actions held by one lane: the larger one's exponent is x - m = +0 and det_exp(+0) is exactly 1.0f (n = 0, r = 0,
+            // polynomial 0 + 1, scale 2^0), so one det_exp serves both -- same bits as the general form below
+            if (ok[0] && ok[1]) {
+                const float lo = x[0] < x[1] ? x[0] : x[1];
+                const float el = det_exp(lo - m);
+                e[0] = x[0] < x[1] ? el : 1.0f;
+                e[1] = x[1] < x[0] ? el : 1.0f;
+                const float s2 = e[0] + e[1];
+                p[0] = e[0] / s2;
+                p[1] = e[1] / s2;
+                return;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < APL; ++j) e[j] = ok[j] ? det_exp(x[j] - m) : 0.0f;
         const float s = sum(e);

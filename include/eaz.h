@@ -248,8 +248,9 @@ EAZ_API int eaz_profile_read(eaz_search* s, double ms[EAZ_K_COUNT], int64_t laun
 EAZ_API int eaz_profile_net_ksteps(eaz_search* s, uint64_t* executed, int reset);
 
 /* Kernel duration without the launch gap an event pair around a single launch includes: the network forward (EAZ_K_NET) or
- * the standalone DeepSea leaf gather (EAZ_K_GATHER, unfused searches) of the LAST simulation is launched `iters` times back to
- * back on `stream` inside ONE event pair; *ms_total / iters is what rocprofv3 reports as the kernel's average duration. */
+ * the standalone DeepSea leaf gather (EAZ_K_GATHER, unfused searches) of the LAST simulation, or the persistent search kernel
+ * (EAZ_K_SEARCH: all simulations from the root of the last eaz_search_begin), is launched `iters` times back to back on `stream`
+ * inside ONE event pair; *ms_total / iters is what rocprofv3 reports as the kernel's average duration. */
 EAZ_API int eaz_profile_replay(eaz_search* s, int kernel_class, int iters, double* ms_total, void* stream);
 
 /* Kernel-selection knobs for A/B measurements and for the parity tests (every setting computes identical results).  They are

@@ -54,13 +54,8 @@ seg("re-score (D+1 nodes, one lane each)", w0[:, 1], w0[:, 2])
 seg("select walk + DeepSea step", w0[:, 2], w0[:, 3])
 seg("barrier S0 + W1 row gather + H1 store + barrier S1", w0[:, 3], w0[:, 4])
 for h in range(3):
-    seg(f"head {h}: layer 2 (256 MFMA per wave)", w0[:, 6 + 3 * h], w0[:, 7 + 3 * h])
+    seg(f"head {h}: layer 2 (256 MFMA per wave) + H2 round trip + quarter chain of layer 3", w0[:, 6 + 3 * h], w0[:, 7 + 3 * h])
     if h < 2:
-        seg(f"head {h}: H2 barrier + H1 store + barrier", w0[:, 7 + 3 * h], w0[:, 6 + 3 * (h + 1)])
+        seg(f"head {h}: barrier", w0[:, 7 + 3 * h], w0[:, 6 + 3 * (h + 1)])
 seg("head 2 done -> all heads' outputs visible (S7)", w0[:, 13], w0[:, 5])
 seg("whole simulation (stamp 0 -> 5)", w0[:, 0], w0[:, 5])
-print("helper wave:")
-for h in range(3):
-    seg(f"layer-3 chain of head {h} (256 fmaf)", hp[:, 6 + 3 * h], hp[:, 7 + 3 * h])
-seg("S1 -> start of chain 0", hp[:, 4], hp[:, 6])
-seg("end of chain 2 -> S7", hp[:, 13], hp[:, 5])
