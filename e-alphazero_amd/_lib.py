@@ -16,6 +16,7 @@ class SearchOpts(C.Structure):
         ("gumbel_scale", C.c_float), ("rescale_values", C.c_int), ("use_mixed_value", C.c_int),
         ("value_scale", C.c_float), ("maxvisit_init", C.c_float), ("discount", C.c_float),
         ("two_players_game", C.c_int), ("exploration", C.c_int),
+        ("epistemic_bonus_after_rescale", C.c_int), ("epistemic_variance_backup", C.c_int),
     ]
 
 
@@ -55,6 +56,7 @@ SIGNATURES = {
     "eaz_net_create_resnet": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _pp],
     "eaz_net_destroy": [_vp],
     "eaz_net_set_weights": [_vp, _vp, _vp, _vp],
+    "eaz_net_set_resnet_weights": [_vp, _vp, _i, _vp],
     "eaz_net_set_bitset": [_vp, _vp, _vp],
     "eaz_net_get_bitset": [_vp, _vp, _vp],
     "eaz_net_forward": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

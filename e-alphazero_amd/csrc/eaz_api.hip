@@ -68,6 +68,7 @@ struct eaz_net {
     int kind;  // 0 = fully connected (fully_connected.py), 1 = residual (resnet.py)
     ResNetDev rdev;
     float* d_rparams;
+    size_t rparams_count;
     NetDev dev;
     float* d_w[12];
     float* d_b[12];
@@ -326,19 +327,8 @@ static void layer_dims(int in_dim, int H, int A, int l, int* k, int* n) {
     *n = (l % 3) < 2 ? H : ((l / 3) < 2 ? 1 : A);
 }
 
-extern "C" int eaz_net_create_fc(eaz_ctx* ctx, int in_dim, int hidden, int num_actions, const float* const* h_w,
-                                 const float* const* h_b, float max_ube, float max_reward_variance, int hash_off,
-                                 int hash_len, int hash_bits, eaz_net** out) {
-    ARG_OK(ctx && out && h_w && h_b && in_dim > 0 && num_actions > 0 && num_actions <= 256);
-    if (hidden != kFcH) return fail("the gfx950 FC kernel is specialised for linear_layer_size = %d (config.py:24), got %d", kFcH, hidden);
-    if (hash_len <= 0 || hash_len % 4 != 0 || hash_off < 0 || hash_off + hash_len > in_dim)
-        return fail("hash slice [%d, %d) invalid: length must be a positive multiple of 4 (hashes.py:210) inside the observation", hash_off, hash_off + hash_len);
-    ARG_OK(hash_bits >= 4 && hash_bits <= 32);
-    HIP_OK(hipSetDevice(ctx->device));
-    eaz_net* n = new eaz_net();
-    n->ctx = ctx;
-    n->kind = 0;
-    n->d_rparams = nullptr;
+static int net_create_fc_impl(eaz_net* n, int in_dim, int hidden, int num_actions, const float* const* h_w, const float* const* h_b,
+                              float max_ube, float max_reward_variance, int hash_off, int hash_len, int hash_bits) {
     std::memset(&n->dev, 0, sizeof n->dev);
     n->dev.in_dim = in_dim; n->dev.H = hidden; n->dev.A = num_actions;
     n->dev.max_u = max_ube; n->dev.nov_scale = max_reward_variance;
@@ -397,37 +387,40 @@ extern "C" int eaz_net_create_fc(eaz_ctx* ctx, int in_dim, int hidden, int num_a
         HIP_OK(hipMemcpy(n->d_hot_index, hi.data(), hi.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         n->dev.hot_index = n->d_hot_index;
     }
-    if (in_dim > 256 * kFcMaxBlocks) return fail("observation size %d exceeds the FC kernel's limit %d", in_dim, 256 * kFcMaxBlocks);
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_forward_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFcLdsBytes));
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_forward_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFcLdsBytes));
     HIP_OK(hipMalloc(&n->d_kstep_storage, 8 * sizeof(unsigned long long)));
     HIP_OK(hipMemset(n->d_kstep_storage, 0, 8 * sizeof(unsigned long long)));
     n->d_kstep_counter = nullptr;
+    return 0;
+}
+
+extern "C" int eaz_net_destroy(eaz_net* n);
+
+extern "C" int eaz_net_create_fc(eaz_ctx* ctx, int in_dim, int hidden, int num_actions, const float* const* h_w,
+                                 const float* const* h_b, float max_ube, float max_reward_variance, int hash_off,
+                                 int hash_len, int hash_bits, eaz_net** out) {
+    ARG_OK(ctx && out && h_w && h_b && in_dim > 0 && num_actions > 0 && num_actions <= 256);
+    if (hidden != kFcH) return fail("the gfx950 FC kernel is specialised for linear_layer_size = %d (config.py:24), got %d", kFcH, hidden);
+    if (hash_len <= 0 || hash_len % 4 != 0 || hash_off < 0 || hash_off + hash_len > in_dim)
+        return fail("hash slice [%d, %d) invalid: length must be a positive multiple of 4 (hashes.py:210) inside the observation", hash_off, hash_off + hash_len);
+    ARG_OK(hash_bits >= 4 && hash_bits <= 32);
+    if (in_dim > 256 * kFcMaxBlocks) return fail("observation size %d exceeds the FC kernel's limit %d", in_dim, 256 * kFcMaxBlocks);
+    HIP_OK(hipSetDevice(ctx->device));
+    eaz_net* n = new eaz_net();  // value-initialised: every pointer null, so a failed creation can be handed to eaz_net_destroy
+    n->ctx = ctx;
+    n->kind = 0;
+    const int rc = net_create_fc_impl(n, in_dim, hidden, num_actions, h_w, h_b, max_ube, max_reward_variance, hash_off, hash_len, hash_bits);
+    if (rc) { (void)eaz_net_destroy(n); return rc; }
     *out = n;
     return 0;
 }
 
-extern "C" int eaz_net_create_resnet(eaz_ctx* ctx, int H, int W, int Cin, int C, int nb, int A, const float* const* a, int n_arrays,
-                                     int hash_bits, eaz_net** out) {
-    ARG_OK(ctx && out && a && H > 0 && W > 0 && A > 0 && A <= 64 && nb >= 0 && nb <= 16);
-    if (C != kRnC) return fail("the gfx950 ResNet kernel is specialised for num_channels = %d (resnet.py:48), got %d", kRnC, C);
-    if (Cin < 1 || Cin > 64 || (Cin & (Cin - 1)) != 0) return fail("input planes must be a power of two <= 64, got %d", Cin);
-    if (n_arrays != 42 + 12 * nb) return fail("expected %d parameter arrays, got %d", 42 + 12 * nb, n_arrays);
-    if ((H * W * Cin) % 4 != 0) return fail("hash input length %d is not a multiple of 4 (hashes.py:210)", H * W * Cin);
-    if (H * W > 42) return fail("board of %d cells exceeds the kernel's 42-cell head buffers", H * W);
-    ARG_OK(hash_bits >= 4 && hash_bits <= 32);
-    HIP_OK(hipSetDevice(ctx->device));
-    std::vector<float> pk;
+// haiku-ordered ResNet arrays (include/eaz.h) -> one packed float buffer + the offsets the kernel reads (ResNetDev).  Pure host work:
+// used by eaz_net_create_resnet and, with identical offsets, by eaz_net_set_resnet_weights (in-place refresh after a learner update).
+static void resnet_pack(const float* const* a, int H, int W, int Cin, int C, int nb, int A, ResNetDev& r, std::vector<float>& pk) {
     auto push = [&](const float* src, size_t cnt) { const int off = static_cast<int>(pk.size()); pk.insert(pk.end(), src, src + cnt); while (pk.size() % 4) pk.push_back(0.0f); return off; };
-    eaz_net* n = new eaz_net();
-    n->ctx = ctx;
-    n->kind = 1;
-    n->d_ztab = nullptr;
-    n->d_hot_index = nullptr;
-    std::memset(&n->dev, 0, sizeof n->dev);
-    std::memset(&n->rdev, 0, sizeof n->rdev);
-    for (int l = 0; l < 12; ++l) { n->d_w[l] = nullptr; n->d_b[l] = nullptr; }
-    ResNetDev& r = n->rdev;
+    std::memset(&r, 0, sizeof r);
     r.H = H; r.W = W; r.Cin = Cin; r.nb = nb; r.A = A; r.P = H * W;
     r.cin_log2 = 0;
     while ((1 << r.cin_log2) < Cin) r.cin_log2++;
@@ -463,9 +456,15 @@ extern "C" int eaz_net_create_resnet(eaz_ctx* ctx, int H, int W, int Cin, int C,
     take_lin(r.P, C, r.lin_w[2], r.lin_b[2]); take_lin(C, 1, r.lin_w[3], r.lin_b[3]);
     take_conv(1, C, 1, r.hc_w[3], r.hc_b[3], nullptr); take_bn(1, r.hbn_mean[3], r.hbn_inv[3], r.hbn_off[3]);
     take_lin(r.P, C, r.lin_w[4], r.lin_b[4]); take_lin(C, 1, r.lin_w[5], r.lin_b[5]);
+}
+
+static int net_create_resnet_impl(eaz_net* n, int H, int W, int Cin, int C, int nb, int A, const float* const* a, int hash_bits) {
+    std::vector<float> pk;
+    resnet_pack(a, H, W, Cin, C, nb, A, n->rdev, pk);
+    n->rparams_count = pk.size();
     HIP_OK(hipMalloc(&n->d_rparams, pk.size() * sizeof(float)));
     HIP_OK(hipMemcpy(n->d_rparams, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
-    r.p = n->d_rparams;
+    n->rdev.p = n->d_rparams;
     n->dev.in_dim = H * W * Cin; n->dev.H = C; n->dev.A = A;
     n->dev.max_u = 1.0f; n->dev.nov_scale = 1.0f;  // resnet.py:63-64
     n->dev.hash_off = 0; n->dev.hash_len = H * W * Cin; n->dev.hash_bits = hash_bits;
@@ -476,7 +475,26 @@ extern "C" int eaz_net_create_resnet(eaz_ctx* ctx, int H, int W, int Cin, int C,
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(resnet_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kRnLdsBytes));
     HIP_OK(hipMalloc(&n->d_kstep_storage, 8 * sizeof(unsigned long long)));
     HIP_OK(hipMemset(n->d_kstep_storage, 0, 8 * sizeof(unsigned long long)));
-    n->d_kstep_counter = nullptr;
+    return 0;
+}
+
+extern "C" int eaz_net_destroy(eaz_net* n);
+
+extern "C" int eaz_net_create_resnet(eaz_ctx* ctx, int H, int W, int Cin, int C, int nb, int A, const float* const* a, int n_arrays,
+                                     int hash_bits, eaz_net** out) {
+    ARG_OK(ctx && out && a && H > 0 && W > 0 && A > 0 && A <= 64 && nb >= 0 && nb <= 16);
+    if (C != kRnC) return fail("the gfx950 ResNet kernel is specialised for num_channels = %d (resnet.py:48), got %d", kRnC, C);
+    if (Cin < 1 || Cin > 64 || (Cin & (Cin - 1)) != 0) return fail("input planes must be a power of two <= 64, got %d", Cin);
+    if (n_arrays != 42 + 12 * nb) return fail("expected %d parameter arrays, got %d", 42 + 12 * nb, n_arrays);
+    if ((H * W * Cin) % 4 != 0) return fail("hash input length %d is not a multiple of 4 (hashes.py:210)", H * W * Cin);
+    if (H * W > 42) return fail("board of %d cells exceeds the kernel's 42-cell head buffers", H * W);
+    ARG_OK(hash_bits >= 4 && hash_bits <= 32);
+    HIP_OK(hipSetDevice(ctx->device));
+    eaz_net* n = new eaz_net();  // value-initialised: every pointer null, so a failed creation can be handed to eaz_net_destroy
+    n->ctx = ctx;
+    n->kind = 1;
+    const int rc = net_create_resnet_impl(n, H, W, Cin, C, nb, A, a, hash_bits);
+    if (rc) { (void)eaz_net_destroy(n); return rc; }
     *out = n;
     return 0;
 }
@@ -485,10 +503,10 @@ extern "C" int eaz_net_destroy(eaz_net* n) {
     if (!n) return 0;
     if (n->d_rparams) (void)hipFree(n->d_rparams);
     for (int l = 0; l < 12; ++l) { if (n->d_w[l]) (void)hipFree(n->d_w[l]); if (n->d_b[l]) (void)hipFree(n->d_b[l]); }
-    (void)hipFree(n->dev.bitset);
+    if (n->dev.bitset) (void)hipFree(n->dev.bitset);
     if (n->d_ztab) (void)hipFree(n->d_ztab);
     if (n->d_hot_index) (void)hipFree(n->d_hot_index);
-    (void)hipFree(n->d_kstep_storage);
+    if (n->d_kstep_storage) (void)hipFree(n->d_kstep_storage);
     delete n;
     return 0;
 }
@@ -502,6 +520,21 @@ extern "C" int eaz_net_set_weights(eaz_net* n, const float* const* h_w, const fl
         HIP_OK(hipMemcpyAsync(n->d_w[l], h_w[l], sizeof(float) * k * m, hipMemcpyHostToDevice, S(stream)));
         HIP_OK(hipMemcpyAsync(n->d_b[l], h_b[l], sizeof(float) * m, hipMemcpyHostToDevice, S(stream)));
     }
+    return 0;
+}
+
+extern "C" int eaz_net_set_resnet_weights(eaz_net* n, const float* const* h_arrays, int n_arrays, void* stream) {
+    ARG_OK(n && h_arrays);
+    if (n->kind != 1) return fail("eaz_net_set_resnet_weights: residual networks only (FC: eaz_net_set_weights)");
+    const ResNetDev& r0 = n->rdev;
+    if (n_arrays != 42 + 12 * r0.nb) return fail("expected %d parameter arrays, got %d", 42 + 12 * r0.nb, n_arrays);
+    ResNetDev r;
+    std::vector<float> pk;
+    resnet_pack(h_arrays, r0.H, r0.W, r0.Cin, kRnC, r0.nb, r0.A, r, pk);
+    if (pk.size() != n->rparams_count) return fail("eaz_net_set_resnet_weights: packed size changed (%zu != %zu)", pk.size(), n->rparams_count);
+    // same buffer, same offsets: kernels already captured into a hipGraph keep reading valid addresses and see the new weights
+    HIP_OK(hipMemcpyAsync(n->d_rparams, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice, S(stream)));
+    HIP_OK(hipStreamSynchronize(S(stream)));  // `pk` is a stack-lifetime staging buffer
     return 0;
 }
 
@@ -773,6 +806,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     t.max_depth = opts->max_depth > 0 ? opts->max_depth : s->S;
     t.value_scale = opts->value_scale; t.maxvisit_init = opts->maxvisit_init;
     t.discount = opts->discount; t.two_player = opts->two_players_game;
+    t.bonus_after = opts->epistemic_bonus_after_rescale != 0; t.var_backup = opts->epistemic_variance_backup != 0;
     // per-simulation workspace
     DALLOC(s->d_obs, static_cast<size_t>(B) * env->dev.obs_dim + 16);
     DALLOC(s->d_novelty, B); DALLOC(s->d_exploit, static_cast<size_t>(B) * A); DALLOC(s->d_explore, static_cast<size_t>(B) * A);
@@ -1340,6 +1374,7 @@ extern "C" int eaz_reanalyze_run(eaz_search* s, const eaz_reanalyze_cfg* cfg, ui
                                  float* d_exploitation_policy_target, int32_t* d_action, void* stream) {
     ARG_OK(s && cfg && d_states && d_next_states && d_value_target && d_ube_target && d_exploration_policy_target && d_exploitation_policy_target);
     if (s->opts.exploration) return fail("reanalyze uses the exploitation recurrent fn (main.py:270-277): create the search with exploration = 0");
+    if (s->env->dev.kind == EAZ_ENV_CONNECT4) return fail("reanalyze: the reference's TD target squeezes a [B,1] reward (reanalyze.py:95), i.e. single-player envs only");
     HIP_OK(hipSetDevice(s->ctx->device));
     hipStream_t st = S(stream);
     const int B = s->B, A = s->A;
@@ -1360,7 +1395,6 @@ extern "C" int eaz_reanalyze_run(eaz_search* s, const eaz_reanalyze_cfg* cfg, ui
         rc = fc_launch(s->net, B, s->d_obs, o, hl, st);
         if (rc) return rc;
     }
-    if (s->env->dev.kind == EAZ_ENV_CONNECT4) return fail("reanalyze: the reference's TD target squeezes a [B,1] reward (reanalyze.py:95), i.e. single-player envs only");
     env_fields_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->env->dev, static_cast<const char*>(d_next_states), B, s->d_term2, nullptr, s->d_reward_tmp,
                                                    nullptr, nullptr, nullptr);
     LAUNCH_OK();
@@ -1386,15 +1420,21 @@ extern "C" int eaz_random_play(eaz_env* env, int B, int T, uint64_t key, void* d
     int32_t* d_act = nullptr;
     HIP_OK(hipMallocAsync(reinterpret_cast<void**>(&d_act), sizeof(int32_t) * B, st));
     const size_t sb = static_cast<size_t>(env->dev.state_bytes) * B;
-    for (int step = 0; step < T; ++step) {
-        const Key kt = fold(k, kTagStep + static_cast<uint32_t>(step));
-        random_action_kernel<<<cdiv(B, 256), 256, 0, st>>>(B, env->dev.A, fold(kt, kTagRandomAction), d_act);
-        LAUNCH_OK();
-        if (d_traj) HIP_OK(hipMemcpyAsync(static_cast<char*>(d_traj) + sb * step, d_states, sb, hipMemcpyDeviceToDevice, st));
-        rc = env_step_launch(env, B, d_states, d_act, fold(kt, kTagEnv), 1, d_states, nullptr, st);
-        if (rc) return rc;
-    }
-    HIP_OK(hipFreeAsync(d_act, st));
+    auto steps = [&]() -> int {
+        for (int step = 0; step < T; ++step) {
+            const Key kt = fold(k, kTagStep + static_cast<uint32_t>(step));
+            random_action_kernel<<<cdiv(B, 256), 256, 0, st>>>(B, env->dev.A, fold(kt, kTagRandomAction), d_act);
+            LAUNCH_OK();
+            if (d_traj) HIP_OK(hipMemcpyAsync(static_cast<char*>(d_traj) + sb * step, d_states, sb, hipMemcpyDeviceToDevice, st));
+            const int rs = env_step_launch(env, B, d_states, d_act, fold(kt, kTagEnv), 1, d_states, nullptr, st);
+            if (rs) return rs;
+        }
+        return 0;
+    };
+    rc = steps();
+    const hipError_t fe = hipFreeAsync(d_act, st);  // also on the error path
+    if (rc) return rc;
+    HIP_OK(fe);
     return 0;
 }
 

@@ -138,7 +138,8 @@ __global__ void __launch_bounds__(256) tree_summary_kernel(TreeDev t, float* val
     const float vc = static_cast<float>(t.children_visits[o + a]);
     const float ftot = static_cast<float>(tot);
     if (visit_counts) visit_counts[i] = vc;
-    if (visit_probs) visit_probs[i] = tot > 0 ? vc / (ftot > 1.0f ? ftot : 1.0f) : 1.0f / static_cast<float>(t.A);
+    // mctx Tree.summary [EXT]: visit_counts / max(total, 1) -- all zeros for a root that has not been searched
+    if (visit_probs) visit_probs[i] = vc / (ftot > 1.0f ? ftot : 1.0f);
 }
 
 // Root preparation of selfplay's step_fn (src/selfplay.py:92-106,113): policy logits (uniform option), per-env beta

@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
                     }
                     const float cnt = static_cast<float>(cnt_i);
                     const float pv = (nv * cnt + G) / (cnt + 1.0f);
-                    const float pvar = (nvar * cnt + U) / (cnt + 1.0f);
+                    const float pvar = var_backup_update(t.var_backup, nvar, cnt, U);
                     float cv = __shfl_down(pv, 1, 16), cu = __shfl_down(pvar, 1, 16);  // node value of the level below
                     if (tj == top) { cv = cvin; cu = cuin; }
                     if (valid) {

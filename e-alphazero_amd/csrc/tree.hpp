@@ -54,7 +54,14 @@ struct TreeDev {
     // options
     int rescale, use_mixed, max_considered, max_depth;
     float value_scale, maxvisit_init;
+    int bonus_after, var_backup;  // eaz_search_opts::epistemic_bonus_after_rescale / epistemic_variance_backup
 };
+
+// running statistic of the variance backup (A.6 twin; include/eaz.h epistemic_variance_backup)
+__device__ __forceinline__ float var_backup_update(int mode, float nvar, float cnt, float U) {
+    if (mode == 0) return (nvar * cnt + U) / (cnt + 1.0f);
+    return ((nvar * cnt) * cnt + U) / ((cnt + 1.0f) * (cnt + 1.0f));
+}
 
 // ---- cross-lane exchange ------------------------------------------------------------------------------------
 // lane ^ MASK exchange.  MASK 1 and 2 are DPP quad permutes (no LDS round trip, ~8 cycles), 4..16 ds_swizzle bit-mask
@@ -246,6 +253,9 @@ __device__ __forceinline__ void qtransform(const TreeDev& t, const Group<LPT, AP
     if (t.use_mixed) value = mixed_value<LPT, APL>(g, raw_value, q, r.visits, probs, sumN);
 #pragma unroll
     for (int j = 0; j < APL; ++j) out[j] = r.visits[j] > 0 ? q[j] : value;
+    float bonus[APL];
+#pragma unroll
+    for (int j = 0; j < APL; ++j) bonus[j] = 0.0f;
     if (beta != 0.0f) {  // x + 0*sqrt(v) == x for finite v >= 0, so the twin is only evaluated when it matters
         float qv[APL];
 #pragma unroll
@@ -255,7 +265,8 @@ __device__ __forceinline__ void qtransform(const TreeDev& t, const Group<LPT, AP
 #pragma unroll
         for (int j = 0; j < APL; ++j) {
             const float cvar = r.visits[j] > 0 ? qv[j] : vvar;
-            out[j] = out[j] + beta * __builtin_sqrtf(cvar);
+            bonus[j] = beta * __builtin_sqrtf(cvar);
+            if (!t.bonus_after) out[j] = out[j] + bonus[j];
         }
     }
     if (t.rescale) {
@@ -264,6 +275,10 @@ __device__ __forceinline__ void qtransform(const TreeDev& t, const Group<LPT, AP
         den = den > 1e-8f ? den : 1e-8f;
 #pragma unroll
         for (int j = 0; j < APL; ++j) out[j] = (out[j] - mn) / den;
+    }
+    if (beta != 0.0f && t.bonus_after) {
+#pragma unroll
+        for (int j = 0; j < APL; ++j) out[j] = out[j] + bonus[j];
     }
     const float scale = (t.maxvisit_init + static_cast<float>(maxN)) * t.value_scale;
 #pragma unroll
@@ -450,7 +465,7 @@ __global__ void __launch_bounds__(256) tree_step_kernel(TreeDev t, int sim, int 
                     G = r + dd * G;
                     U = rv + (dd * dd) * U;
                     const float pv = (nv[j] * cnt + G) / (cnt + 1.0f);
-                    const float pvar = (nvar[j] * cnt + U) / (cnt + 1.0f);
+                    const float pvar = var_backup_update(t.var_backup, nvar[j], cnt, U);
                     if (lead) {
                         t.node_values[nb + pn[j]] = pv;
                         t.node_var[nb + pn[j]] = pvar;

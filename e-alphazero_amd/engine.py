@@ -59,6 +59,19 @@ def fold(key, tag: int) -> int:
     return int(out.value)
 
 
+def fingerprint(arrays) -> bytes:
+    """Content fingerprint of a list of numpy arrays (xxh3-128 of the raw bytes, shapes and dtypes): the staleness test of every
+    host-side weight / state copy that mirrors a pytree the caller may mutate in place."""
+    import xxhash
+
+    h = xxhash.xxh3_128()
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(repr((a.shape, a.dtype.str)).encode())
+        h.update(a.view(np.uint8).reshape(-1))
+    return h.digest()
+
+
 def tune(fc_tile: Optional[int] = None, fused_leaf: Optional[int] = None, tree_block: Optional[int] = None,
          tree_spread: Optional[int] = None, persist: Optional[int] = None) -> None:
     """Kernel-selection knobs (include/eaz.h eaz_tune_set); results are identical for every setting."""
@@ -171,6 +184,8 @@ class EnvHandle:
 class FCNet:
     """eaz_net for EpistemicFullyConnectedAZNet (src/network/fully_connected.py)."""
 
+    hash_module = HASH_MODULE  # haiku module path of the novelty set inside model_state
+
     def __init__(self, ctx: Context, in_dim: int, hidden: int, num_actions: int, params, state=None, max_ube: float = 1.0,
                  max_epistemic_variance_reward: float = 1.0, hash_off: int = 0, hash_len: Optional[int] = None, hash_bits: int = 24):
         self.ctx, self.in_dim, self.hidden, self.num_actions = ctx, in_dim, hidden, num_actions
@@ -184,6 +199,8 @@ class FCNet:
         check(_lib.load().eaz_net_create_fc(ctx.h, in_dim, hidden, num_actions, wp, bp, max_ube, max_epistemic_variance_reward,
                                             hash_off, hash_len, hash_bits, C.byref(h)))
         self.h = h
+        self.params_fp = fingerprint([x for wb in wl for x in wb])
+        self.state_fp = fingerprint([np.zeros(1 << (hash_bits - 3), np.uint8)])
         if state is not None:
             self.set_state(state)
 
@@ -194,17 +211,40 @@ class FCNet:
         bp = (C.c_void_p * 12)(*[b.ctypes.data for _, b in wl])
         check(_lib.load().eaz_net_set_weights(self.h, wp, bp, _stream()))
         torch.cuda.current_stream().synchronize()
+        self.params_fp = fingerprint([x for wb in wl for x in wb])
 
     def set_state(self, state):
-        bs = np.ascontiguousarray(state[HASH_MODULE]["binary_set"], np.uint8)
+        bs = np.ascontiguousarray(state[self.hash_module]["binary_set"], np.uint8)
         assert bs.size == 1 << (self.hash_bits - 3)
         check(_lib.load().eaz_net_set_bitset(self.h, bs.ctypes.data_as(C.c_void_p), _stream()))
         torch.cuda.current_stream().synchronize()
+        self.state_fp = fingerprint([bs])
 
     def get_state(self):
+        """haiku model_state with the device's current bit set (the only state the FC network has)."""
         bs = np.empty(1 << (self.hash_bits - 3), np.uint8)
         check(_lib.load().eaz_net_get_bitset(self.h, bs.ctypes.data_as(C.c_void_p), _stream()))
-        return {HASH_MODULE: {"binary_set": bs}}
+        self.state_fp = fingerprint([bs])
+        return {self.hash_module: {"binary_set": bs}}
+
+    def sync_model(self, params, state) -> bool:
+        """Bring the device copy up to date with (params, state) if their CONTENT differs from what was uploaded last -- the caller may
+        have replaced the pytrees or mutated them in place (the reference re-applies model_params on every call).  Returns True if
+        anything was uploaded."""
+        changed = False
+        pfp = fingerprint(self._param_arrays(params, state))
+        if pfp != self.params_fp:
+            self.set_params(params) if not isinstance(self, ResNet) else self.set_params(params, state)
+            changed = True
+        if state is not None and self.hash_module in state:
+            sfp = fingerprint([np.ascontiguousarray(state[self.hash_module]["binary_set"], np.uint8)])
+            if sfp != self.state_fp:
+                self.set_state(state)
+                changed = True
+        return changed
+
+    def _param_arrays(self, params, state):
+        return [x for wb in fc_weight_list(params) for x in wb]
 
     def forward(self, obs: torch.Tensor):
         """-> (exploitation_logits, exploration_logits, value, value_epistemic_variance, reward_epistemic_variance)"""
@@ -236,20 +276,46 @@ class FCNet:
 class ResNet(FCNet):
     """eaz_net for EpistemicResidualAZNet (src/network/resnet.py) on [H, W, Cin] observations; same methods as FCNet."""
 
+    hash_module = RESNET_HASH_MODULE
+
     def __init__(self, ctx: Context, H: int, W: int, cin: int, num_actions: int, params, state, num_channels: int = 64,
                  num_blocks: int = 5, hash_bits: int = 24):
         self.ctx, self.in_dim, self.hidden, self.num_actions, self.hash_bits = ctx, H * W * cin, num_channels, num_actions, hash_bits
+        self.num_blocks = num_blocks
         arrs = resnet_array_list(params, state, num_blocks)
         self._keep = arrs
         ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         h = C.c_void_p()
         check(_lib.load().eaz_net_create_resnet(ctx.h, H, W, cin, num_channels, num_blocks, num_actions, ptrs, len(arrs), hash_bits, C.byref(h)))
         self.h = h
+        self.params_fp = fingerprint(arrs)
+        self.state_fp = fingerprint([np.zeros(1 << (hash_bits - 3), np.uint8)])
+        self._state = state  # BatchNorm statistics etc.: get_state() hands them back with the device's bit set
         if state is not None and RESNET_HASH_MODULE in state:
-            self.set_state({HASH_MODULE: state[RESNET_HASH_MODULE]})
+            self.set_state(state)
 
-    def set_params(self, params):
-        raise EazError("ResNet weights are packed at creation: create a new ResNet for new weights")
+    def set_params(self, params, state=None):
+        """New weights (and BatchNorm statistics, which live in `state`) into the SAME packed device buffer: searches and captured
+        graphs built on this network keep working and see them (eaz_net_set_resnet_weights)."""
+        state = self._state if state is None else state
+        arrs = resnet_array_list(params, state, self.num_blocks)
+        self._keep = arrs
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        check(_lib.load().eaz_net_set_resnet_weights(self.h, ptrs, len(arrs), _stream()))
+        self.params_fp = fingerprint(arrs)
+        self._state = state
+
+    def get_state(self):
+        """The model_state given last (BatchNorm mean / var EMAs, ...) with 'az_resnet/xxhash32'/binary_set replaced by the device's."""
+        bs = np.empty(1 << (self.hash_bits - 3), np.uint8)
+        check(_lib.load().eaz_net_get_bitset(self.h, bs.ctypes.data_as(C.c_void_p), _stream()))
+        self.state_fp = fingerprint([bs])
+        out = {k: dict(v) for k, v in (self._state or {}).items()}
+        out[RESNET_HASH_MODULE] = {"binary_set": bs}
+        return out
+
+    def _param_arrays(self, params, state):
+        return resnet_array_list(params, self._state if state is None else state, self.num_blocks)
 
 
 class Search:
@@ -258,10 +324,12 @@ class Search:
     def __init__(self, env: EnvHandle, net: FCNet, B: int, num_simulations: int, discount: float = 0.997,
                  two_players_game: bool = False, exploration: bool = False, rescale_values: bool = True,
                  use_mixed_value: bool = True, value_scale: float = 0.1, maxvisit_init: float = 50.0,
-                 max_num_considered_actions: int = 16, gumbel_scale: float = 1.0, max_depth: Optional[int] = None):
+                 max_num_considered_actions: int = 16, gumbel_scale: float = 1.0, max_depth: Optional[int] = None,
+                 epistemic_bonus_after_rescale: bool = False, epistemic_variance_backup: int = 0):
         self.env, self.net, self.B, self.S, self.N, self.A = env, net, B, num_simulations, num_simulations + 1, env.num_actions
         self.opts = SearchOpts(num_simulations, max_depth or 0, max_num_considered_actions, gumbel_scale, int(rescale_values),
-                               int(use_mixed_value), value_scale, maxvisit_init, discount, int(two_players_game), int(exploration))
+                               int(use_mixed_value), value_scale, maxvisit_init, discount, int(two_players_game), int(exploration),
+                               int(epistemic_bonus_after_rescale), int(epistemic_variance_backup))
         h = C.c_void_p()
         check(_lib.load().eaz_search_create(env.ctx.h, env.h, net.h, B, C.byref(self.opts), C.byref(h)))
         self.h = h
@@ -339,6 +407,18 @@ class Search:
         """src/selfplay.py:78-149.  `states` ([B, state_bytes]) is advanced in place; returns SelfplayOutput fields [T,B,..]."""
         B, A, dev = self.B, self.A, self.device
         assert states.shape == (B, self.env.state_bytes) and states.is_contiguous()
+        want = dict(state=((T, B, self.env.state_bytes), torch.uint8), root_value=((T, B), torch.float32),
+                    root_epistemic_std=((T, B), torch.float32), value_prediction=((T, B), torch.float32),
+                    ube_prediction=((T, B), torch.float32), q_values_epistemic_variance=((T, B, A), torch.float32),
+                    action=((T, B), torch.int32))
+        if outputs is not None:
+            # reused output buffers are written by the device with these exact extents
+            for k, (shape, dt) in want.items():
+                t = outputs.get(k)
+                if t is None and k == "action":
+                    continue
+                if t is None or tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != dev:
+                    raise EazError(f"selfplay(outputs=...): `{k}` must be a contiguous {dt} tensor of shape {shape} on {dev}")
         if outputs is None:
             outputs = dict(
                 state=torch.empty(T, B, self.env.state_bytes, dtype=torch.uint8, device=dev),
@@ -350,11 +430,19 @@ class Search:
         cfg = SelfplayCfg(T, int(directed_exploration), exploration_beta, int(uniform_search_policy), int(sample_actions),
                           int(sample_from_improved_policy), int(use_graph))
         g = None if gumbel is None else gumbel.to(torch.float32).contiguous()
+        if g is not None and tuple(g.shape) != (T, B, A):
+            raise EazError(f"selfplay(gumbel=...): expected shape {(T, B, A)}, got {tuple(g.shape)}")
         o = outputs
-        check(_lib.load().eaz_selfplay_run(self.h, C.byref(cfg), as_key(key), _ptr(states), _ptr(g), _ptr(o["state"]),
+        # The captured per-step graph is keyed on the address of the state buffer: the search advances its OWN buffer and copies in / out
+        # (2 x B x state_bytes), so callers that pass a fresh tensor every call (api.selfplay clones last_states) replay the same graph.
+        if getattr(self, "_states_buf", None) is None:
+            self._states_buf = torch.empty(B, self.env.state_bytes, dtype=torch.uint8, device=dev)
+        self._states_buf.copy_(states)
+        check(_lib.load().eaz_selfplay_run(self.h, C.byref(cfg), as_key(key), _ptr(self._states_buf), _ptr(g), _ptr(o["state"]),
                                            _ptr(o["root_value"]), _ptr(o["root_epistemic_std"]), _ptr(o["value_prediction"]),
                                            _ptr(o["ube_prediction"]), _ptr(o["q_values_epistemic_variance"]), _ptr(o.get("action")),
                                            _stream()))
+        states.copy_(self._states_buf)
         return outputs
 
     # -- "next" drivers --------------------------------------------------------------------------------------------

@@ -121,6 +121,9 @@ EAZ_API int eaz_net_create_resnet(eaz_ctx* ctx, int H, int W, int Cin, int num_c
 EAZ_API int eaz_net_destroy(eaz_net* net);
 /* replace weights (after a learner update) -- same layout as eaz_net_create_fc */
 EAZ_API int eaz_net_set_weights(eaz_net* net, const float* const* h_w, const float* const* h_b, void* stream);
+/* the same for a residual network: h_arrays as in eaz_net_create_resnet (same architecture).  The packed device buffer is rewritten in place
+ * (same addresses and offsets), so searches and captured graphs that use this network see the new weights.  Synchronous. */
+EAZ_API int eaz_net_set_resnet_weights(eaz_net* net, const float* const* h_arrays, int n_arrays, void* stream);
 /* haiku state "fc_az_net/xxhash32/binary_set": uint8[2^(bits-3)] (hashes.py:40-43); host copy in/out */
 EAZ_API int eaz_net_set_bitset(eaz_net* net, const uint8_t* h_bitset, void* stream);
 EAZ_API int eaz_net_get_bitset(eaz_net* net, uint8_t* h_bitset, void* stream); /* synchronous */
@@ -146,6 +149,16 @@ typedef struct {
     float discount;
     int two_players_game;
     int exploration; /* use exploration logits inside the tree (context.py:132) */
+    /* The two choices of emctx's epistemic extension that cannot be checked offline (emctx is not vendored and not importable here,
+     * SURVEY.md A.5 / A.6 "(?)"): both are switches, so adopting vectors from a real emctx run is a flag flip, and the oracle
+     * (eazo_search_set_epistemic_variant) and tests/mctx_numpy.py follow the same switches.  With beta == 0 (the reference default,
+     * config.py:38) selection does not depend on either; the variance outputs depend on the second one only.
+     *   epistemic_bonus_after_rescale  0 (default): completed Q + beta * sigma, THEN the min-max rescale;  1: rescale the completed Q, then
+     *                                  add beta * sigma (both before the (maxvisit_init + max N) * value_scale factor)
+     *   epistemic_variance_backup      0 (default): node variance = running mean of r_var + gamma^2 * U over the visits (the twin of the
+     *                                  value backup);  1: variance of that running mean, (var * n^2 + U) / (n + 1)^2 */
+    int epistemic_bonus_after_rescale;
+    int epistemic_variance_backup;
 } eaz_search_opts;
 
 EAZ_API int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B, const eaz_search_opts* opts, eaz_search** out);

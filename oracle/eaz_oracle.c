@@ -920,6 +920,10 @@ typedef struct OTree {
     const ONet* net;
     float discount;
     int two_player, use_exploration_logits, rescale, use_mixed, max_considered, max_depth;
+    /* the two choices of the epistemic extension that cannot be checked against emctx offline (SURVEY.md A.5 / A.6 "(?)"), see
+     * include/eaz.h eaz_search_opts: bonus_after_rescale 0 = beta * sigma added to the completed Q before the min-max rescale,
+     * 1 = after it; var_backup 0 = running mean of the backed-up variances, 1 = variance of the running mean */
+    int bonus_after_rescale, var_backup;
     float value_scale, maxvisit_init;
     int32_t* table; /* [(max_considered+1), S] sequential-halving considered-visit table */
 } OTree;
@@ -998,10 +1002,12 @@ static void o_qtransform(const OTree* t, int b, int node, float* out) {
     }
     const float beta = t->beta[b];
     int maxN = 0;
+    float bonus[O_MAX_A];
     for (int a = 0; a < A; ++a) {
         float c = visits[a] > 0 ? q[a] : value;
         float cvar = visits[a] > 0 ? qv[a] : value_var;
-        out[a] = c + beta * sqrtf(cvar);
+        bonus[a] = beta * sqrtf(cvar);
+        out[a] = t->bonus_after_rescale ? c : c + bonus[a];
         if (visits[a] > maxN) maxN = visits[a];
     }
     if (t->rescale) {
@@ -1010,6 +1016,8 @@ static void o_qtransform(const OTree* t, int b, int node, float* out) {
         den = den > 1e-8f ? den : 1e-8f;
         for (int a = 0; a < A; ++a) out[a] = (out[a] - mn) / den;
     }
+    if (t->bonus_after_rescale)
+        for (int a = 0; a < A; ++a) out[a] = out[a] + bonus[a];
     const float scale = (t->maxvisit_init + (float)maxN) * t->value_scale;
     for (int a = 0; a < A; ++a) out[a] = scale * out[a];
 }
@@ -1085,7 +1093,8 @@ static void o_backward(OTree* t, int b, int leaf) {
         G = t->children_rewards[ca] + d * G;
         U = t->children_reward_var[ca] + (d * d) * U;
         t->node_values[nb + p] = (t->node_values[nb + p] * cnt + G) / (cnt + 1.0f);
-        t->node_var[nb + p] = (t->node_var[nb + p] * cnt + U) / (cnt + 1.0f);
+        if (t->var_backup == 0) t->node_var[nb + p] = (t->node_var[nb + p] * cnt + U) / (cnt + 1.0f);
+        else t->node_var[nb + p] = ((t->node_var[nb + p] * cnt) * cnt + U) / ((cnt + 1.0f) * (cnt + 1.0f));
         t->node_visits[nb + p] += 1;
         t->children_values[ca] = t->node_values[nb + idx];
         t->children_var[ca] = t->node_var[nb + idx];
@@ -1142,6 +1151,12 @@ EXPORT void* eazo_tree_field(OTree* t, int id) {
 
 /* mctx instantiate_tree_from_root + gumbel_muzero_policy's root masking [EXT].
  * root_logits are the RAW network logits; gumbel is already multiplied by gumbel_scale. */
+/* selects the variant of the two unpinned epistemic choices for the searches that follow (default 0, 0) */
+EXPORT void eazo_search_set_epistemic_variant(OTree* t, int bonus_after_rescale, int var_backup) {
+    t->bonus_after_rescale = bonus_after_rescale != 0;
+    t->var_backup = var_backup != 0;
+}
+
 EXPORT void eazo_search_begin(OTree* t, const float* root_logits, const float* root_value, const float* root_var,
                               const void* root_states, const float* beta, const uint8_t* invalid, const float* gumbel,
                               float discount, int two_player, int use_exploration_logits, int rescale, int use_mixed,
@@ -1267,7 +1282,8 @@ EXPORT void eazo_search_summary(const OTree* t, float* value, float* value_std, 
             if (qvalues_var) qvalues_var[(size_t)b * A + a] = t->children_reward_var[o + a] + (d * d) * t->children_var[o + a];
             const float vc = (float)t->children_visits[o + a];
             if (visit_counts) visit_counts[(size_t)b * A + a] = vc;
-            if (visit_probs) visit_probs[(size_t)b * A + a] = tot > 0.0f ? vc / (tot > 1.0f ? tot : 1.0f) : 1.0f / (float)A;
+            /* mctx Tree.summary [EXT]: visit_probs = visit_counts / max(total, 1) -- all zeros for an unsearched root */
+            if (visit_probs) visit_probs[(size_t)b * A + a] = vc / (tot > 1.0f ? tot : 1.0f);
         }
     }
 }

@@ -79,6 +79,7 @@ def lib():
             "eazo_tree_free": (None, [vp]),
             "eazo_tree_field": (vp, [vp, i32]),
             "eazo_search_begin": (None, [vp, vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, i32, f32, f32, i32, i32]),
+            "eazo_search_set_epistemic_variant": (None, [vp, i32, i32]),
             "eazo_search_sim": (None, [vp, i32]),
             "eazo_search_finish": (None, [vp, vp, vp]),
             "eazo_search_summary": (None, [vp, vp, vp, vp, vp, vp, vp]),
@@ -251,7 +252,8 @@ class OracleTree:
 
     def begin(self, root_logits, root_value, root_var, root_states, beta, invalid, gumbel, discount=0.997,
               two_player=False, use_exploration_logits=False, rescale=True, use_mixed=True, value_scale=0.1,
-              maxvisit_init=50.0, max_considered=16, max_depth=0):
+              maxvisit_init=50.0, max_considered=16, max_depth=0, bonus_after_rescale=False, var_backup=0):
+        self.set_epistemic_variant(bonus_after_rescale, var_backup)
         f = lambda a: np.ascontiguousarray(a, np.float32)
         self._keep = [f(root_logits), f(root_value), f(root_var), np.ascontiguousarray(root_states), f(beta),
                       None if invalid is None else np.ascontiguousarray(invalid, np.uint8), f(gumbel)]
@@ -259,6 +261,10 @@ class OracleTree:
         lib().eazo_search_begin(self.h, _p(k[0]), _p(k[1]), _p(k[2]), _p(k[3]), _p(k[4]), _p(k[5]), _p(k[6]), discount,
                                 int(two_player), int(use_exploration_logits), int(rescale), int(use_mixed), value_scale,
                                 maxvisit_init, max_considered, max_depth)
+
+    def set_epistemic_variant(self, bonus_after_rescale=False, var_backup=0):
+        """The two emctx choices that cannot be pinned offline (include/eaz.h eaz_search_opts), for the searches that follow."""
+        lib().eazo_search_set_epistemic_variant(self.h, int(bonus_after_rescale), int(var_backup))
 
     def sim(self, i):
         lib().eazo_search_sim(self.h, i)

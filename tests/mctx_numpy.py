@@ -68,9 +68,14 @@ class Tree:
         q, qv = self.qvalues(n), self.qvar(n)
         value = self.mixed(self.raw_values[n], q, n, probs)
         vvar = self.mixed(self.raw_var[n], qv, n, probs)
-        cq = np.where(visits > 0, q, value) + o["beta"] * np.sqrt(np.where(visits > 0, qv, vvar))
+        bonus = o["beta"] * np.sqrt(np.where(visits > 0, qv, vvar))
+        cq = np.where(visits > 0, q, value)
+        if not o.get("bonus_after_rescale"):
+            cq = cq + bonus
         if o["rescale"]:
             cq = (cq - cq.min()) / max(cq.max() - cq.min(), 1e-8)
+        if o.get("bonus_after_rescale"):
+            cq = cq + bonus
         return (50.0 + visits.max()) * 0.1 * cq
 
     def score_considered(self, cv, cq):
@@ -81,9 +86,10 @@ class Tree:
 
 
 def search(S, A, root_logits, root_value, root_var, root_state, recurrent_fn, gumbel, invalid, beta, discount, rescale=True,
-           max_considered=16):
-    """recurrent_fn(state, action) -> (reward, discount, masked_logits, value, var, next_state)"""
-    opts = dict(beta=beta, rescale=rescale, gumbel=np.asarray(gumbel, np.float64))
+           max_considered=16, bonus_after_rescale=False, var_backup=0):
+    """recurrent_fn(state, action) -> (reward, discount, masked_logits, value, var, next_state)
+    bonus_after_rescale / var_backup: the two unpinned epistemic choices (include/eaz.h eaz_search_opts)."""
+    opts = dict(beta=beta, rescale=rescale, gumbel=np.asarray(gumbel, np.float64), bonus_after_rescale=bonus_after_rescale)
     t = Tree(S, A, opts)
     invalid = np.asarray(invalid, bool)
     t.children_prior_logits[0] = mask_invalid(np.asarray(root_logits, np.float64), invalid)
@@ -129,7 +135,10 @@ def search(S, A, root_logits, root_value, root_var, root_state, recurrent_fn, gu
             G = t.children_rewards[p_, a_] + t.children_discounts[p_, a_] * G
             U = t.children_rvar[p_, a_] + t.children_discounts[p_, a_] ** 2 * U
             t.node_values[p_] = (t.node_values[p_] * cnt + G) / (cnt + 1.0)
-            t.node_var[p_] = (t.node_var[p_] * cnt + U) / (cnt + 1.0)
+            if var_backup == 0:
+                t.node_var[p_] = (t.node_var[p_] * cnt + U) / (cnt + 1.0)          # running mean of the backed-up variances
+            else:
+                t.node_var[p_] = (t.node_var[p_] * cnt * cnt + U) / (cnt + 1.0) ** 2  # variance of the running mean
             t.node_visits[p_] = cnt + 1
             t.children_values[p_, a_] = t.node_values[idx]
             t.children_var[p_, a_] = t.node_var[idx]

@@ -375,3 +375,121 @@ def test_connect4_evaluate_matches_oracle(oracle, eaz, torch):
     g = torch.zeros(B, 7, device="cuda")
     with pytest.raises(eaz.EazError, match="single-player"):
         search.reanalyze(torch.from_numpy(traj[0]).cuda(), torch.from_numpy(traj[1]).cuda(), gumbel=g)
+
+
+# ---- weight refresh: the facade must never search on stale weights (the reference re-applies model_params on every call) --------
+def test_weights_mutated_in_place_reach_the_device_fc(oracle, eaz, torch):
+    """api.selfplay with the SAME params dict whose arrays were overwritten in place (and with a replaced dict): the device copy is
+    refreshed by content fingerprint, and the result equals the oracle on the new weights -- also through the captured step graph."""
+    from e_alphazero_amd import api, engine
+
+    G, B, S, T = 8, 48, 16, 5
+    env = api.DeepSea(size_of_grid=G, action_map_key=api.random.PRNGKey(2))
+    config = api.Config(selfplay_batch_size=B, selfplay_simulations_per_step=S, selfplay_steps=T)
+    forward = api.get_forward_fn(env, config)
+    model = forward.init(api.random.PRNGKey(3))
+    context = api.Context(env=env, devices=[0], forward=forward, selfplay_recurrent_fn=api.get_epistemic_recurrent_fn(
+        env=env, forward=forward, batch_size=B, exploration=False, discount=config.discount, two_players_game=False))
+    states0 = api.vmap(env.init)(api.random.split(api.random.PRNGKey(5), B))
+
+    def oracle_run(params, state):
+        oenv = oracle.OracleEnv.deepsea(G, env.action_map)
+        onet = oracle.OracleNet(G * G, 256, 2, eaz.params.fc_weight_list(params), bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+        ost = oenv.init(B)
+        return oracle.selfplay(oenv, onet, ost, T=T, S=S, key=engine.key_pair(api.random.PRNGKey(11)), discount=config.discount)
+
+    def check(tag):
+        _, out = api.selfplay(model, config, context, states0, api.random.PRNGKey(11))
+        ref = oracle_run(*model)
+        assert np.array_equal(out.state.data.cpu().numpy(), ref["state"]), tag
+        np.testing.assert_allclose(out.root_value.cpu().numpy(), ref["root_value"], rtol=0, atol=ATOL, err_msg=tag)
+        np.testing.assert_allclose(out.ube_prediction.cpu().numpy(), ref["ube_prediction"], rtol=0, atol=ATOL, err_msg=tag)
+        return out.root_value.clone()
+
+    v0 = check("initial weights")
+    rng = np.random.default_rng(9)
+    for mod in model[0].values():                      # overwrite every array IN PLACE: same dicts, same ndarray objects
+        for k in mod:
+            mod[k][...] = (mod[k] + 0.05 * rng.standard_normal(mod[k].shape)).astype(np.float32)
+    model[1][eaz.params.HASH_MODULE]["binary_set"][::7] ^= 0x5A   # and the novelty set
+    v1 = check("weights mutated in place")
+    assert not torch.equal(v0, v1), "the mutation did not change the search: the test does not cover what it claims"
+    model = forward.init(api.random.PRNGKey(77))       # a brand-new pytree
+    check("replaced pytree")
+
+
+def test_resnet_weights_refresh_in_place_and_state_round_trip(oracle, eaz, torch):
+    """eaz_net_set_resnet_weights repacks into the SAME device buffer: a search (and its captured graph) built before the update
+    runs on the new weights; ResNet.get_state returns the model_state it was given with only the novelty set replaced."""
+    engine, env, net, oenv, onet = _c4_setup(oracle, eaz, 2, seed=4)
+    B, S, T = 24, 12, 4
+    search = engine.Search(env, net, B, S, discount=0.997, two_players_game=True)
+    st = env.init(B, key=2)
+    search.selfplay(st, T, key=31)                       # captures the step graph on the old weights
+    params, state = eaz.params.init_resnet_params(6, 7, 2, 7, 64, 2, seed=123)
+    bs = eaz.params.init_hash_state(fill=0.2, seed=5)[eaz.params.HASH_MODULE]["binary_set"]
+    state[eaz.params.RESNET_HASH_MODULE] = {"binary_set": bs}
+    assert net.sync_model(params, state) is True and net.sync_model(params, state) is False
+    onet2 = oracle.OracleNet.resnet(6, 7, 2, 7, eaz.params.resnet_array_list(params, state, 2), 64, 2, bitset=bs)
+    st = env.init(B, key=2)
+    ost = oenv.init(B, key=(2, 0))
+    out = search.selfplay(st, T, key=31)
+    ref = oracle.selfplay(oenv, onet2, ost, T=T, S=S, key=(31, 0), two_player=True)
+    assert np.array_equal(out["action"].cpu().numpy(), ref["action"]) and np.array_equal(out["state"].cpu().numpy(), ref["state"])
+    np.testing.assert_allclose(out["root_value"].cpu().numpy(), ref["root_value"], rtol=0, atol=ATOL)
+    # model_state round trip: BatchNorm statistics untouched, the bit set is the device's (updated by hash_update)
+    obs = oenv.observe(ost)
+    net.hash_update(torch.from_numpy(obs).cuda())
+    got = net.get_state()
+    assert set(got) == set(state)
+    for mod in state:
+        if mod == eaz.params.RESNET_HASH_MODULE:
+            continue
+        for k in state[mod]:
+            assert np.array_equal(got[mod][k], state[mod][k]), (mod, k)
+    new_bs = got[eaz.params.RESNET_HASH_MODULE]["binary_set"]
+    assert (new_bs | bs == new_bs).all() and (new_bs != bs).any()
+    assert net.sync_model(params, got) is False          # feeding the returned state back is a no-op
+
+
+def test_hash_update_keeps_every_bit_of_a_shared_byte(oracle, eaz, torch):
+    """Documented deviation (INTEGRATION.md): BaseHash.update is `binary_set.at[byte].set(binary_set[byte] | bit)` (hashes.py:45-50);
+    when two samples of one batch fall into the same byte XLA's scatter keeps ONE of the two writes (unspecified which), so one bit can
+    be lost.  The engine ORs atomically and keeps both -- a superset of whatever the reference stores.  A tiny set (2^8 bits) forces
+    the collision."""
+    from e_alphazero_amd import engine
+
+    G, B = 8, 64
+    am, params, _ = deepsea_setup(eaz, G, seed=1, fill=0.0)
+    env = engine.EnvHandle.deepsea(G, am, device=0)
+    net = engine.FCNet(env.ctx, G * G, 256, 2, params, None, hash_bits=8)
+    obs = (np.random.default_rng(1).random((B, G * G)) < 0.2).astype(np.uint8)
+    _, idx = net.hash_lookup(torch.from_numpy(obs).cuda())
+    idx = idx.cpu().numpy().astype(np.int64)
+    byte, bit = idx >> 3, idx & 7
+    shared = [b for b in np.unique(byte) if len(np.unique(bit[byte == b])) > 1]
+    assert shared, "no two samples share a byte: enlarge the batch"
+    net.hash_update(torch.from_numpy(obs).cuda())
+    bs = net.get_state()[eaz.params.HASH_MODULE]["binary_set"]
+    expect = np.zeros(32, np.uint8)
+    np.bitwise_or.at(expect, byte, (1 << bit).astype(np.uint8))
+    assert np.array_equal(bs, expect)                    # every bit of every sample, shared bytes included
+    seen, _ = net.hash_lookup(torch.from_numpy(obs).cuda())
+    assert seen.all()
+
+
+def test_selfplay_rejects_mismatched_output_buffers(eaz, torch):
+    from e_alphazero_amd import engine
+
+    G, B, S, T = 8, 16, 8, 3
+    am, params, state = deepsea_setup(eaz, G, seed=1, fill=0.0)
+    env = engine.EnvHandle.deepsea(G, am, device=0)
+    search = engine.Search(env, engine.FCNet(env.ctx, G * G, 256, 2, params, state), B, S)
+    st = env.init(B, key=0)
+    out = search.selfplay(st, T, key=1)
+    search.selfplay(st, T, key=2, outputs=out)           # same extents: reused
+    with pytest.raises(eaz.EazError, match="outputs"):
+        search.selfplay(st, T + 1, key=3, outputs=out)   # would be an out-of-bounds device write
+    bad = dict(out, root_value=out["root_value"].double())
+    with pytest.raises(eaz.EazError, match="root_value"):
+        search.selfplay(st, T, key=3, outputs=bad)

@@ -165,6 +165,10 @@ def test_search_depth_limited_and_qtransform_options(oracle, eaz, torch, max_dep
     (8, 40, 24, 0.5, dict(use_mixed=False, max_considered=1), True),
     (6, 17, 8, 0.0, dict(two_player=True), False),                     # negated discount (context.py:143)
     (8, 20, 70, 0.0, {}, False),                                       # S = 70: the trees of a workgroup no longer fit into LDS
+    # the two unpinned epistemic choices (include/eaz.h eaz_search_opts), oracle and device behind the same switches
+    (8, 50, 24, 2.0, dict(bonus_after_rescale=True), False),
+    (8, 50, 24, 1.0, dict(var_backup=1), False),
+    (32, 40, 64, 1.5, dict(bonus_after_rescale=True, var_backup=1, max_depth=9), False),
 ])
 def test_search_run_whole_tree(oracle, eaz, torch, G, B, S, beta_max, opts, masked):
     """begin -> run (all S simulations in one call) -> finish: every tree field, the embeddings, action and weights against the
@@ -184,14 +188,16 @@ def test_search_run_whole_tree(oracle, eaz, torch, G, B, S, beta_max, opts, mask
     explore = beta_max > 0
     logits = xp if explore else ex
     okw = dict(discount=0.997, use_exploration_logits=explore, rescale=opts.get("rescale", True), use_mixed=opts.get("use_mixed", True),
-               max_considered=opts.get("max_considered", 16), max_depth=opts.get("max_depth", 0), two_player=opts.get("two_player", False))
+               max_considered=opts.get("max_considered", 16), max_depth=opts.get("max_depth", 0), two_player=opts.get("two_player", False),
+               bonus_after_rescale=opts.get("bonus_after_rescale", False), var_backup=opts.get("var_backup", 0))
     otree = oracle.OracleTree(oenv, onet, B, S)
     otree.begin(logits, v, u, blobs, beta, invalid, g, **okw)
     for sim in range(S):
         otree.sim(sim)
     search = engine.Search(env, net, B, S, discount=0.997, exploration=explore, rescale_values=okw["rescale"], use_mixed_value=okw["use_mixed"],
                            max_num_considered_actions=okw["max_considered"], max_depth=okw["max_depth"] or None,
-                           two_players_game=okw["two_player"])
+                           two_players_game=okw["two_player"], epistemic_bonus_after_rescale=okw["bonus_after_rescale"],
+                           epistemic_variance_backup=okw["var_backup"])
     cu = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
     for rep in range(2):  # the second search reuses the (dirty) tree buffers of the first
         search.begin(cu(logits), cu(v), cu(u), cu(blobs), cu(beta), cu(invalid), cu(g))
@@ -242,6 +248,8 @@ def test_search_begin_then_stepwise_after_persist_default(oracle, eaz, torch):
     oact0, oaw0 = otree.finish()
     _compare_tree(search, otree, "root only")
     assert np.array_equal(act0.cpu().numpy(), oact0)
+    s0, os0 = search.summary(), otree.summary()
+    assert np.array_equal(s0["visit_probs"].cpu().numpy(), os0["visit_probs"]) and not os0["visit_probs"].any()  # counts / max(total, 1)
 
 
 @pytest.mark.parametrize("G,B,S,T,flags", [

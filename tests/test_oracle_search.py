@@ -30,7 +30,7 @@ def test_sequential_halving_known_answers(oracle):
             assert list(oracle.considered_visits(m, S)) == M.considered_visits_sequence(m, S)
 
 
-def _run(oracle, eaz, G, B, S, beta_max, seed):
+def _run(oracle, eaz, G, B, S, beta_max, seed, **variant):
     am, params, state = deepsea_setup(eaz, G, seed=seed, fill=0.5)
     oenv, onet = oracle_deepsea(oracle, eaz, G, am, params, state)
     blobs = random_states_deepsea(G, B, seed=seed + 1)
@@ -38,7 +38,7 @@ def _run(oracle, eaz, G, B, S, beta_max, seed):
     beta = (beta_max * np.linspace(0, 1, B)).astype(np.float32)
     g = oracle.gumbel((seed, 1), B * 2).reshape(B, 2)
     act, aw, summ, tree = oracle.search(oenv, onet, blobs, S, xp if beta_max > 0 else ex, v, u, beta, g, discount=0.997,
-                                        use_exploration_logits=beta_max > 0)
+                                        use_exploration_logits=beta_max > 0, **variant)
     return dict(env=oenv, net=onet, blobs=blobs, logits=xp if beta_max > 0 else ex, v=v, u=u, beta=beta, g=g, act=act, aw=aw,
                 summ=summ, tree=tree.dump())
 
@@ -81,14 +81,19 @@ def _recurrent(oenv, onet, discount, explore):
     return fn
 
 
-@pytest.mark.parametrize("beta_max", [0.0, 1.0])
-def test_against_numpy_restatement_deepsea(oracle, eaz, beta_max):
+@pytest.mark.parametrize("beta_max,variant", [
+    (0.0, {}), (1.0, {}),
+    # the two unpinned epistemic choices (include/eaz.h eaz_search_opts): the C oracle and the NumPy restatement follow the same switches
+    (1.0, dict(bonus_after_rescale=True)), (1.0, dict(var_backup=1)), (2.0, dict(bonus_after_rescale=True, var_backup=1)),
+    (0.0, dict(var_backup=1)),
+])
+def test_against_numpy_restatement_deepsea(oracle, eaz, beta_max, variant):
     G, B, S = 8, 12, 16
-    r = _run(oracle, eaz, G, B, S, beta_max, 21)
+    r = _run(oracle, eaz, G, B, S, beta_max, 21, **variant)
     fn = _recurrent(r["env"], r["net"], float(np.float32(0.997)), beta_max > 0)
     for b in range(B):
         t, a, w = M.search(S, 2, r["logits"][b], float(r["v"][b]), float(r["u"][b]), r["blobs"][b], fn, r["g"][b],
-                           [False, False], float(r["beta"][b]), float(np.float32(0.997)))
+                           [False, False], float(r["beta"][b]), float(np.float32(0.997)), **variant)
         d = r["tree"]
         assert np.array_equal(t.children_index, d["children_index"][b]), b
         assert np.array_equal(t.children_visits, d["children_visits"][b]), b
