@@ -57,6 +57,7 @@ SIGNATURES = {
     "eaz_net_destroy": [_vp],
     "eaz_net_set_weights": [_vp, _vp, _vp, _vp],
     "eaz_net_set_resnet_weights": [_vp, _vp, _i, _vp],
+    "eaz_net_set_simhash": [_vp, _vp, _vp],
     "eaz_net_set_bitset": [_vp, _vp, _vp],
     "eaz_net_get_bitset": [_vp, _vp, _vp],
     "eaz_net_forward": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

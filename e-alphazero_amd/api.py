@@ -294,9 +294,11 @@ class ForwardFn:
     """hk.without_apply_rng(hk.transform_with_state(forward_fn)) of src/context.py:86-106 for the FC network."""
 
     def __init__(self, env: Env, config: Config):
-        if config.hash_class != "XXHash":
-            raise EazError(f"hash_class {config.hash_class!r}: only XXHash is implemented natively (config.py:27 default)")
+        if config.hash_class not in ("XXHash", "SimHash"):
+            raise EazError(f"hash_class {config.hash_class!r}: XXHash (config.py:27 default) and SimHash are implemented natively; "
+                           "LCGHash is self-declared broken in the reference (hashes.py:59)")
         self.env, self.config = env, config
+        self.simhash = config.hash_class == "SimHash"
         # get_network (context.py:41-82): FC net for deep_sea / subleq, EpistemicResidualAZNet for every other pgx game
         self.residual = isinstance(env, ConnectFour)
         self.num_blocks = 5  # resnet.py:49 (get_network passes no override, context.py:79-82)
@@ -313,23 +315,35 @@ class ForwardFn:
         seed = engine.as_key(rng_key) & 0x7FFFFFFF
         if self.residual:
             H, W, cin = self.env.observation_shape
-            return params_lib.init_resnet_params(H, W, cin, self.env.num_actions, 64, self.num_blocks, seed)
-        return (params_lib.init_fc_params(self.in_dim, self.config.linear_layer_size, self.env.num_actions, seed),
-                params_lib.init_hash_state())
+            params, state = params_lib.init_resnet_params(H, W, cin, self.env.num_actions, 64, self.num_blocks, seed)
+            if self.simhash:   # the hash module of the state is named after the hash class (hk module names, hashes.py:112,155)
+                del state[params_lib.RESNET_HASH_MODULE]
+                state.update(params_lib.init_simhash_state(self.in_dim, seed=seed, module=params_lib.RESNET_SIMHASH_MODULE))
+            return params, state
+        params = params_lib.init_fc_params(self.in_dim, self.config.linear_layer_size, self.env.num_actions, seed)
+        if self.simhash:
+            return params, params_lib.init_simhash_state(self.in_dim - self.hash_off, seed=seed)
+        return params, params_lib.init_hash_state()
 
     def net(self, model) -> engine.FCNet:
         """The device network for `model = (params, state)`.  The reference re-applies model_params on every call; here the device copy
         is refreshed whenever the CONTENT of the pytrees differs from what was uploaded last (engine.fingerprint) -- replaced dicts and
         arrays mutated in place are both caught, and an unchanged model costs one hash of its bytes (~0.3 ms for the FC net)."""
         model_params, model_state = model
-        if self._net is None and self.residual:
-            H, W, cin = self.env.observation_shape
-            self._net = engine.ResNet(self.env._h.ctx, H, W, cin, self.env.num_actions, model_params, model_state, 64, self.num_blocks)
-        elif self._net is None:
-            # get_network does not forward max_ube / max_epistemic_variance_reward to the FC net (context.py:68-75)
-            self._net = engine.FCNet(self.env._h.ctx, self.in_dim, self.config.linear_layer_size, self.env.num_actions,
-                                     model_params, model_state, max_ube=1.0, max_epistemic_variance_reward=1.0,
-                                     hash_off=self.hash_off)
+        if self._net is None:
+            first_state = None if self.simhash else model_state   # SimHash: the projection matrix has to be in place first
+            if self.residual:
+                H, W, cin = self.env.observation_shape
+                self._net = engine.ResNet(self.env._h.ctx, H, W, cin, self.env.num_actions, model_params, model_state, 64, self.num_blocks)
+            else:
+                # get_network does not forward max_ube / max_epistemic_variance_reward to the FC net (context.py:68-75)
+                self._net = engine.FCNet(self.env._h.ctx, self.in_dim, self.config.linear_layer_size, self.env.num_actions,
+                                         model_params, first_state, max_ube=1.0, max_epistemic_variance_reward=1.0,
+                                         hash_off=self.hash_off)
+            if self.simhash:
+                mod = params_lib.RESNET_SIMHASH_MODULE if self.residual else params_lib.SIMHASH_MODULE
+                self._net.set_simhash(model_state[mod]["random_matrix"], mod)
+                self._net.set_state(model_state)
         else:
             self._net.sync_model(model_params, model_state)
         return self._net

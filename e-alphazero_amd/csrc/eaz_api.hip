@@ -75,6 +75,7 @@ struct eaz_net {
     size_t bitset_bytes;
     uint32_t* d_ztab;                     // NetDev::ztab storage
     uint32_t* d_hot_index;                // NetDev::hot_index storage
+    float* d_sim_matrix;                  // NetDev::sim_matrix storage (SimHash)
     unsigned long long* d_kstep_counter;  // executed layer-1 k-steps (profiling only; nullptr = off)
     unsigned long long* d_kstep_storage;
 };
@@ -506,6 +507,7 @@ extern "C" int eaz_net_destroy(eaz_net* n) {
     if (n->dev.bitset) (void)hipFree(n->dev.bitset);
     if (n->d_ztab) (void)hipFree(n->d_ztab);
     if (n->d_hot_index) (void)hipFree(n->d_hot_index);
+    if (n->d_sim_matrix) (void)hipFree(n->d_sim_matrix);
     if (n->d_kstep_storage) (void)hipFree(n->d_kstep_storage);
     delete n;
     return 0;
@@ -553,8 +555,32 @@ extern "C" int eaz_net_get_bitset(eaz_net* n, uint8_t* h_bitset, void* stream) {
 
 static int hash_launch(eaz_net* n, int B, const uint8_t* obs, float* novelty, uint8_t* seen, uint32_t* idx, int mode, hipStream_t st) {
     if (B <= 0) return 0;
-    hash_kernel<<<cdiv(static_cast<long>(B) * 4, 256), 256, 0, st>>>(n->dev, obs, B, novelty, seen, idx, mode);
+    if (n->dev.sim_matrix) simhash_kernel<<<cdiv(static_cast<long>(B) * 32, 256), 256, 0, st>>>(n->dev, obs, B, novelty, seen, idx, mode);
+    else hash_kernel<<<cdiv(static_cast<long>(B) * 4, 256), 256, 0, st>>>(n->dev, obs, B, novelty, seen, idx, mode);
     LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int eaz_net_set_simhash(eaz_net* n, const float* h_random_matrix, void* stream) {
+    ARG_OK(n && h_random_matrix);
+    HIP_OK(hipSetDevice(n->ctx->device));
+    const int len = n->dev.hash_len, bits = n->dev.hash_bits;
+    if (!n->d_sim_matrix) HIP_OK(hipMalloc(&n->d_sim_matrix, sizeof(float) * len * bits));
+    HIP_OK(hipMemcpyAsync(n->d_sim_matrix, h_random_matrix, sizeof(float) * len * bits, hipMemcpyHostToDevice, S(stream)));
+    if (n->d_hot_index) {
+        // index of every one-hot row under SimHash: product_j = fmaf(1, R[h][j], +0) = R[h][j]; rows outside the hashed slice give 0
+        std::vector<uint32_t> hi(static_cast<size_t>(n->dev.in_dim), 0u);
+        for (int h = 0; h < n->dev.in_dim; ++h) {
+            const int hh = h - n->dev.hash_off;
+            if (hh < 0 || hh >= len) continue;
+            uint32_t v = 0;
+            for (int j = 0; j < bits; ++j) v |= static_cast<uint32_t>(std::fmaf(1.0f, h_random_matrix[static_cast<size_t>(hh) * bits + j], 0.0f) < 0.0f) << j;
+            hi[h] = v;
+        }
+        HIP_OK(hipMemcpyAsync(n->d_hot_index, hi.data(), hi.size() * sizeof(uint32_t), hipMemcpyHostToDevice, S(stream)));
+    }
+    HIP_OK(hipStreamSynchronize(S(stream)));
+    n->dev.sim_matrix = n->d_sim_matrix;
     return 0;
 }
 

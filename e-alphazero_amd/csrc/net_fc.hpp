@@ -38,7 +38,8 @@ struct NetDev {
     int hash_off, hash_len, hash_bits;
     uint8_t* bitset;  // device, 2^(hash_bits-3) bytes
     const uint32_t* ztab;  // device [4][hash_len/4 + 1]: accumulator of hash lane i after n all-zero stripes (one-hot fast path)
-    const uint32_t* hot_index;  // device [in_dim]: get_indices() of the row that is zero except obs[h] = 1 (hashes.py:162-229)
+    const uint32_t* hot_index;  // device [in_dim]: get_indices() of the row that is zero except obs[h] = 1 (hashes.py:162-229 / :124-139)
+    const float* sim_matrix;    // non-null: hash_class = SimHash, random matrix [hash_len, hash_bits] (hashes.py:124-139)
 };
 
 struct NetOut {
@@ -537,6 +538,36 @@ __global__ void __launch_bounds__(256) hash_kernel(NetDev net, const uint8_t* __
     }
     const bool seen = net.bitset ? ((net.bitset[index >> 3] >> (index & 7u)) & 1u) != 0 : false;  // hashes.py:29-38
     if (novelty) novelty[b] = (seen ? 0.0f : 1.0f) * net.nov_scale;                               // fully_connected.py:90
+    if (seen_out) seen_out[b] = seen ? 1 : 0;
+    if (idx_out) idx_out[b] = index;
+}
+
+// ---- SimHash (src/network/hashes.py:100-139): index = sum_j (product_j < 0) << j with product = x @ random_matrix [n, bits] ------------
+// 32 consecutive lanes per sample, lane j = hash bit j: product_j as the hk.Linear chain (acc = +0; acc = fmaf(x[k], R[k][j], acc), k
+// ascending; zero inputs are skipped, which is exact).  x[k] is one broadcast byte load per group, R[k][.] one coalesced row.
+// mode as hash_kernel.
+__global__ void __launch_bounds__(256) simhash_kernel(NetDev net, const uint8_t* __restrict__ obs, int B, float* novelty,
+                                                      uint8_t* seen_out, uint32_t* idx_out, int mode) {
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = gtid >> 5, j = gtid & 31;
+    const bool live = b < B;
+    const int bits = net.hash_bits, n = net.hash_len;
+    const uint8_t* p = obs + static_cast<long>(live ? b : 0) * net.in_dim + net.hash_off;
+    const float* R = net.sim_matrix + (j < bits ? j : 0);
+    float acc = 0.0f;
+    for (int k = 0; k < n; ++k) {
+        const uint8_t xv = p[k];
+        if (xv) acc = __builtin_fmaf(static_cast<float>(xv), R[static_cast<long>(k) * bits], acc);
+    }
+    const unsigned long long bal = __ballot(live && j < bits && acc < 0.0f);
+    const uint32_t index = static_cast<uint32_t>(bal >> (threadIdx.x & 32));  // the 32 lanes of this sample
+    if (!live || j != 0) return;
+    if (mode == 1) {
+        atomicOr(reinterpret_cast<uint32_t*>(net.bitset) + (index >> 5), 1u << (index & 31u));
+        return;
+    }
+    const bool seen = net.bitset ? ((net.bitset[index >> 3] >> (index & 7u)) & 1u) != 0 : false;
+    if (novelty) novelty[b] = (seen ? 0.0f : 1.0f) * net.nov_scale;
     if (seen_out) seen_out[b] = seen ? 1 : 0;
     if (idx_out) idx_out[b] = index;
 }

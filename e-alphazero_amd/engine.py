@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import EazError, ReanalyzeCfg, SearchOpts, SelfplayCfg, check
-from .params import fc_weight_list, resnet_array_list, HASH_MODULE, RESNET_HASH_MODULE
+from .params import fc_weight_list, resnet_array_list, HASH_MODULE, RESNET_HASH_MODULE, SIMHASH_MODULE, RESNET_SIMHASH_MODULE
 
 _contexts: dict[int, "Context"] = {}
 
@@ -225,7 +225,18 @@ class FCNet:
         bs = np.empty(1 << (self.hash_bits - 3), np.uint8)
         check(_lib.load().eaz_net_get_bitset(self.h, bs.ctypes.data_as(C.c_void_p), _stream()))
         self.state_fp = fingerprint([bs])
-        return {self.hash_module: {"binary_set": bs}}
+        mod = {"binary_set": bs}
+        if getattr(self, "_sim_matrix", None) is not None:
+            mod["random_matrix"] = self._sim_matrix
+        return {self.hash_module: mod}
+
+    def set_simhash(self, random_matrix, module: Optional[str] = None):
+        """hash_class = SimHash (config.py:27, hashes.py:100-139): `random_matrix` is the haiku state '<net>/sim_hash/random_matrix'
+        [hash_len, bits_per_hash].  The novelty set then lives under the sim_hash module name in model_state."""
+        rm = np.ascontiguousarray(random_matrix, np.float32)
+        self._sim_matrix = rm
+        check(_lib.load().eaz_net_set_simhash(self.h, rm.ctypes.data_as(C.c_void_p), _stream()))
+        self.hash_module = module or (RESNET_SIMHASH_MODULE if isinstance(self, ResNet) else SIMHASH_MODULE)
 
     def sync_model(self, params, state) -> bool:
         """Bring the device copy up to date with (params, state) if their CONTENT differs from what was uploaded last -- the caller may
@@ -311,7 +322,10 @@ class ResNet(FCNet):
         check(_lib.load().eaz_net_get_bitset(self.h, bs.ctypes.data_as(C.c_void_p), _stream()))
         self.state_fp = fingerprint([bs])
         out = {k: dict(v) for k, v in (self._state or {}).items()}
-        out[RESNET_HASH_MODULE] = {"binary_set": bs}
+        mod = {"binary_set": bs}
+        if getattr(self, "_sim_matrix", None) is not None:
+            mod["random_matrix"] = self._sim_matrix
+        out[self.hash_module] = mod
         return out
 
     def _param_arrays(self, params, state):

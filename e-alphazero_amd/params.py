@@ -60,6 +60,18 @@ def init_hash_state(bits_per_hash: int = 24, fill: float = 0.0, seed: int = 0):
     return {HASH_MODULE: {"binary_set": bs}}
 
 
+SIMHASH_MODULE = "fc_az_net/sim_hash"
+RESNET_SIMHASH_MODULE = "az_resnet/sim_hash"
+
+
+def init_simhash_state(hash_len: int, bits_per_hash: int = 24, fill: float = 0.0, seed: int = 0, module: str = SIMHASH_MODULE):
+    """haiku state of SimHash (src/network/hashes.py:40-43,126-129): the bit set and the RandomNormal (stddev 1) projection matrix
+    [hash_len, bits_per_hash]."""
+    bs = init_hash_state(bits_per_hash, fill, seed)[HASH_MODULE]["binary_set"]
+    rm = np.random.default_rng(seed + 1).standard_normal((hash_len, bits_per_hash)).astype(np.float32)
+    return {module: {"binary_set": bs, "random_matrix": rm}}
+
+
 def fc_weight_list(params):
     """[(w, b)] * 12 in haiku creation order."""
     return [(np.asarray(params[fc_layer_name(i)]["w"], np.float32), np.asarray(params[fc_layer_name(i)]["b"], np.float32))

@@ -130,7 +130,12 @@ EAZ_API int eaz_net_get_bitset(eaz_net* net, uint8_t* h_bitset, void* stream); /
 /* outputs in the CODE's order (fully_connected.py:101): exploit[B,A], explore[B,A], v[B], u[B], novelty[B] (NULL = skip) */
 EAZ_API int eaz_net_forward(eaz_net* net, int B, const uint8_t* d_obs, float* d_exploit, float* d_explore, float* d_value,
                     float* d_ube, float* d_novelty, void* stream);
-/* BaseHash.__call__ / get_indices / update  hashes.py:23-50,162-229 on d_obs[:, hash_off:hash_off+hash_len] */
+/* hash_class = SimHash (config.py:27; hashes.py:100-139) instead of the default XXHash: h_random_matrix is the haiku state
+ * "<net>/sim_hash/random_matrix", float [hash_len, hash_bits] row-major.  index = sum_j (x @ R)_j < 0 ? 2^j : 0, the product
+ * accumulated as the hk.Linear chain (k ascending).  Applies to every later forward / lookup / update / search of this network;
+ * set it before creating searches.  Synchronous.  (LCGHash, hashes.py:53-98, is self-declared broken and not provided.) */
+EAZ_API int eaz_net_set_simhash(eaz_net* net, const float* h_random_matrix, void* stream);
+/* BaseHash.__call__ / get_indices / update  hashes.py:23-50,162-229 (XXHash) or :124-139 (SimHash) on d_obs[:, hash_off:hash_off+hash_len] */
 EAZ_API int eaz_hash_lookup(eaz_net* net, int B, const uint8_t* d_obs, uint8_t* d_seen, uint32_t* d_indices, void* stream);
 EAZ_API int eaz_hash_update(eaz_net* net, int B, const uint8_t* d_obs, void* stream);
 

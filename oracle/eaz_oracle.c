@@ -601,6 +601,22 @@ static uint32_t o_xxhash_variant(const uint8_t* x, int n /* multiple of 4 */, in
 }
 
 /* BaseHash.__call__, src/network/hashes.py:23-38 */
+/* SimHash.get_indices, src/network/hashes.py:124-139: product = x @ random_matrix [n, bits]; index = sum_j (product_j < 0) << j.
+ * Spec of the build for the product (XLA leaves the order of a dot unspecified): acc = +0; acc = fmaf(x[k], R[k][j], acc), k ascending
+ * -- the hk.Linear chain (o_linear). */
+static uint32_t o_simhash(const uint8_t* x, int n, int bits, const float* R) {
+    uint32_t idx = 0;
+    for (int j = 0; j < bits; ++j) {
+        float acc = 0.0f;
+        for (int k = 0; k < n; ++k) acc = fmaf((float)x[k], R[(size_t)k * bits + j], acc);
+        if (acc < 0.0f) idx |= 1u << j;
+    }
+    return idx;
+}
+EXPORT void eazo_simhash_indices(const uint8_t* x, int B, int n, int bits, const float* R, uint32_t* out) {
+    for (int b = 0; b < B; ++b) out[b] = o_simhash(x + (size_t)b * n, n, bits, R);
+}
+
 static int o_hash_seen(const uint8_t* set, uint32_t index) { return (set[index >> 3] & (1u << (index & 7u))) != 0; }
 
 EXPORT void eazo_xxhash_indices(const uint8_t* x, int B, int n, int bits, uint32_t* out) {
@@ -639,7 +655,14 @@ typedef struct ONet {
     float nov_scale; /* max_epistemic_variance_reward, :20 */
     int hash_off, hash_len, hash_bits;
     const uint8_t* bitset; /* 2^(bits-3) bytes, caller-owned */
+    const float* sim_matrix; /* non-NULL: hash_class = SimHash with this [hash_len, hash_bits] random matrix (caller-owned); NULL: XXHash */
 } ONet;
+
+/* hash_obj.get_indices(hash_input) of the configured hash class (config.py:27, context.py:42-49) */
+static uint32_t o_net_hash_index(const ONet* n, const uint8_t* x) {
+    return n->sim_matrix ? o_simhash(x, n->hash_len, n->hash_bits, n->sim_matrix) : o_xxhash_variant(x, n->hash_len, n->hash_bits);
+}
+EXPORT void eazo_net_set_simhash(ONet* n, const float* R) { n->sim_matrix = R; }
 
 static int o_layer_in(const ONet* n, int l) { return (l % 3) == 0 ? n->in_dim : n->H; }
 static int o_layer_out(const ONet* n, int l) { return (l % 3) < 2 ? n->H : ((l / 3) < 2 ? 1 : n->A); }
@@ -657,6 +680,7 @@ EXPORT ONet* eazo_net_create(int in_dim, int H, int A, const float* const* w, co
     }
     n->max_u = max_u; n->nov_scale = nov_scale;
     n->hash_off = hash_off; n->hash_len = hash_len; n->hash_bits = hash_bits; n->bitset = bitset;
+    n->sim_matrix = NULL;
     return n;
 }
 static void o_resnet_free(struct OResNet* r);
@@ -734,7 +758,7 @@ EXPORT void eazo_net_forward(const ONet* n, int B, const uint8_t* obs, float* ex
     for (int b = 0; b < B; ++b) {
         /* :83-90 novelty = ~seen * max_reward_epistemic_variance */
         int seen = 0;
-        if (n->bitset) seen = o_hash_seen(n->bitset, o_xxhash_variant(obs + (size_t)b * K + n->hash_off, n->hash_len, n->hash_bits));
+        if (n->bitset) seen = o_hash_seen(n->bitset, o_net_hash_index(n, obs + (size_t)b * K + n->hash_off));
         float novelty = (seen ? 0.0f : 1.0f) * n->nov_scale;
         /* :92-96 (not is_training): u = clip(max(novelty, u*max_u), 0, max_u) */
         float uu = u[b] * n->max_u;
@@ -819,6 +843,7 @@ EXPORT ONet* eazo_resnet_create(int H, int W, int Cin, int C, int num_blocks, in
     n->in_dim = H * W * Cin; n->A = A; n->H = C;
     n->max_u = 1.0f; n->nov_scale = 1.0f; /* resnet.py:63-64 */
     n->hash_off = 0; n->hash_len = H * W * Cin; n->hash_bits = hash_bits; n->bitset = bitset;
+    n->sim_matrix = NULL;
     return n;
 }
 
@@ -886,7 +911,7 @@ static void o_resnet_forward(const ONet* n, int B, const uint8_t* obs, float* ex
             else if (h == 3) { o_lin(&r->ul1, hact, fc, 1); o_lin(&r->ul2, fc, out, 0); if (u) u[b] = 0.5f * (o_tanhf(out[0]) + 1.0f); } /* :112-121 */
         }
         int seen = 0;
-        if (n->bitset) seen = o_hash_seen(n->bitset, o_xxhash_variant(obs + (size_t)b * D, D, n->hash_bits));
+        if (n->bitset) seen = o_hash_seen(n->bitset, o_net_hash_index(n, obs + (size_t)b * D));
         const float novelty = (seen ? 0.0f : 1.0f) * n->nov_scale;                  /* :124-125 */
         if (u) u[b] = novelty > u[b] ? novelty : u[b];                              /* :127-130 (not is_training) */
         if (nov) nov[b] = novelty;

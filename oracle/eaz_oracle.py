@@ -65,6 +65,8 @@ def lib():
             "eazo_subleq_encode": (None, [vp, vp, i32, vp]),
             "eazo_subleq_encode_raw": (i32, [i32, i32, vp, i32, vp]),
             "eazo_xxhash_indices": (None, [vp, i32, i32, i32, vp]),
+            "eazo_simhash_indices": (None, [vp, i32, i32, i32, vp, vp]),
+            "eazo_net_set_simhash": (None, [vp, vp]),
             "eazo_hash_update": (None, [vp, vp, i32]),
             "eazo_hash_seen": (None, [vp, vp, i32, vp]),
             "eazo_xxh_round": (u32, [u32, u32]),
@@ -220,6 +222,11 @@ class OracleNet:
     def set_bitset(self, bitset):
         self.bitset = bitset
         lib().eazo_net_set_bitset(self.h, _p(bitset))
+
+    def set_simhash(self, random_matrix):
+        """hash_class = SimHash (hashes.py:100-139) with this [hash_len, bits_per_hash] random matrix instead of XXHash."""
+        self._sim = np.ascontiguousarray(random_matrix, np.float32)
+        lib().eazo_net_set_simhash(self.h, _p(self._sim))
 
     def __del__(self):
         try:

@@ -170,3 +170,25 @@ def test_connect_four_facade(eaz, torch):
     last, data = api.selfplay(model, config, context, states, api.random.PRNGKey(3))
     assert data.state.data.shape[:2] == (T, B) and (data.state._step_count[-1] == T).all()
     assert torch.isfinite(data.root_value).all()
+
+
+def test_simhash_config_through_the_facade(eaz, torch):
+    """config.hash_class = "SimHash" (config.py:27): the model_state carries '<net>/sim_hash' {binary_set, random_matrix}, the facade
+    builds the device network with that projection matrix, and update_hash hands the state back under the same module name."""
+    from e_alphazero_amd import api, params as P
+
+    G, B, S, T = 8, 32, 8, 4
+    env = api.DeepSea(size_of_grid=G, action_map_key=api.random.PRNGKey(1))
+    config, forward, model, context = _setup(api, env, B, S, T, hash_class="SimHash")
+    assert set(model[1]) == {P.SIMHASH_MODULE} and model[1][P.SIMHASH_MODULE]["random_matrix"].shape == (G * G, 24)
+    states = api.vmap(env.init)(api.random.split(api.random.PRNGKey(5), B))
+    last, out = api.selfplay(model, config, context, states, api.random.PRNGKey(11))
+    assert out.state.data.shape[:2] == (T, B)
+    assert (out.ube_prediction == 1.0).all()          # empty novelty set: every state is novel, u = max_u
+    (_, _, _, u, nov), new_state = forward.apply(model[0], model[1], states.observation, update_hash=True)
+    assert set(new_state) == {P.SIMHASH_MODULE} and new_state[P.SIMHASH_MODULE]["binary_set"].any()
+    assert np.array_equal(new_state[P.SIMHASH_MODULE]["random_matrix"], model[1][P.SIMHASH_MODULE]["random_matrix"])
+    (_, _, _, u2, nov2), _ = forward.apply(model[0], new_state, states.observation)
+    assert (nov == 1.0).all() and (nov2 == 0.0).all()  # seen now
+    with pytest.raises(eaz.EazError, match="LCGHash"):
+        api.get_forward_fn(env, api.Config(hash_class="LCGHash"))

@@ -493,3 +493,78 @@ def test_selfplay_rejects_mismatched_output_buffers(eaz, torch):
     bad = dict(out, root_value=out["root_value"].double())
     with pytest.raises(eaz.EazError, match="root_value"):
         search.selfplay(st, T, key=3, outputs=bad)
+
+
+# ---- SimHash (config.hash_class = "SimHash", src/network/hashes.py:100-139) ---------------------------------------------------------
+@pytest.mark.parametrize("kind", ["deepsea", "subleq"])
+def test_simhash_lookup_update_and_selfplay_match_oracle(oracle, eaz, torch, kind):
+    """The second hash class end to end: indices, lookup / update, the forward's novelty, and self-play (incl. the fused DeepSea paths
+    whose one-hot index table is rebuilt for SimHash) against the oracle with the same projection matrix."""
+    from e_alphazero_amd import engine
+
+    if kind == "deepsea":
+        G, A = 8, 2
+        am, params, _ = deepsea_setup(eaz, G, seed=2, fill=0.0)
+        env = engine.EnvHandle.deepsea(G, am, device=0)
+        oenv = oracle.OracleEnv.deepsea(G, am)
+        in_dim, hash_off = G * G, 0
+    else:
+        W, A = 16, 16
+        dims, params, _ = subleq_setup(eaz, W, seed=2, fill=0.0)
+        env = engine.EnvHandle.subleq(W, (1,), True, device=0)
+        oenv = oracle.OracleEnv.subleq(W, (1,), True)
+        in_dim, hash_off = dims["in_dim"], dims["hash_off"]
+    hash_len = in_dim - hash_off
+    st = eaz.params.init_simhash_state(hash_len, fill=0.3, seed=5)[eaz.params.SIMHASH_MODULE]
+    net = engine.FCNet(env.ctx, in_dim, 256, A, params, None, hash_off=hash_off, hash_len=hash_len)
+    net.set_simhash(st["random_matrix"])
+    net.set_state({eaz.params.SIMHASH_MODULE: st})
+    onet = oracle.OracleNet(in_dim, 256, A, eaz.params.fc_weight_list(params), hash_off=hash_off, hash_len=hash_len, bitset=st["binary_set"].copy())
+    onet.set_simhash(st["random_matrix"])
+    B = 300
+    ost, _ = oracle.random_play(oenv, B, 9, key=(4, 0))
+    obs = oenv.observe(ost)
+    seen, idx = net.hash_lookup(torch.from_numpy(obs).cuda())
+    oidx = np.empty(B, np.uint32)
+    hx = np.ascontiguousarray(obs[:, hash_off:])
+    oracle.lib().eazo_simhash_indices(hx.ctypes.data, B, hash_len, 24, st["random_matrix"].ctypes.data, oidx.ctypes.data)
+    assert np.array_equal(idx.cpu().numpy().view(np.uint32), oidx)
+    out, ref = net.forward(torch.from_numpy(obs).cuda()), onet.forward(obs)
+    for a, b in zip(out, ref):
+        np.testing.assert_allclose(a.cpu().numpy(), b, rtol=0, atol=ATOL)
+    # self-play on the engine vs the oracle with the same hash class
+    Bs, S, T = 40, 16, 6
+    search = engine.Search(env, net, Bs, S, discount=0.97)
+    dst = env.init(Bs, key=1)
+    ost2 = oenv.init(Bs, key=(1, 0)) if kind == "subleq" else oenv.init(Bs)
+    o = search.selfplay(dst, T, key=17)
+    r = oracle.selfplay(oenv, onet, ost2, T=T, S=S, key=(17, 0), discount=0.97)
+    assert np.array_equal(o["action"].cpu().numpy(), r["action"])
+    for k in ("root_value", "ube_prediction", "q_values_epistemic_variance"):
+        np.testing.assert_allclose(o[k].cpu().numpy(), r[k], rtol=0, atol=ATOL, err_msg=k)
+    # update: scatter-OR of the SimHash indices; the state round trip carries the matrix
+    net.hash_update(torch.from_numpy(obs).cuda())
+    got = net.get_state()[eaz.params.SIMHASH_MODULE]
+    expect = st["binary_set"].copy()
+    np.bitwise_or.at(expect, (oidx >> 3).astype(np.int64), (1 << (oidx & 7)).astype(np.uint8))
+    assert np.array_equal(got["binary_set"], expect) and np.array_equal(got["random_matrix"], st["random_matrix"])
+
+
+def test_unsupported_shapes_fail_loudly(eaz, torch):
+    """The device path is specialised for linear_layer_size = 256 (config.py:24, every reference configuration) and Subleq word sizes
+    that are multiples of 4 (the reference allows 16..256, subleq.py:606): anything else must be refused with a message, never computed
+    on some fallback."""
+    from e_alphazero_amd import engine
+
+    env = engine.EnvHandle.deepsea(8, np.zeros((8, 8), np.uint8), device=0)
+    with pytest.raises(eaz.EazError, match="linear_layer_size = 256"):
+        engine.FCNet(env.ctx, 64, 128, 2, eaz.params.init_fc_params(64, 128, 2, seed=0))
+    with pytest.raises(eaz.EazError, match="word_size % 4"):
+        engine.EnvHandle.subleq(18, (1,), True, device=0)
+    with pytest.raises(eaz.EazError, match=r"\[16, 256\]"):
+        engine.EnvHandle.subleq(8, (1,), True, device=0)
+    with pytest.raises(eaz.EazError, match="multiple of 4"):
+        engine.FCNet(env.ctx, 64, 256, 2, eaz.params.init_fc_params(64, 256, 2, seed=0), hash_off=2, hash_len=61)
+    net = engine.FCNet(env.ctx, 64, 256, 2, eaz.params.init_fc_params(64, 256, 2, seed=0))
+    with pytest.raises(eaz.EazError, match="observation size"):
+        engine.Search(engine.EnvHandle.deepsea(4, np.zeros((4, 4), np.uint8), device=0), net, 8, 4)

@@ -140,3 +140,22 @@ def test_fc_forward_hash_io_slice(oracle, eaz):
                            hash_len=dims["hash_len"], bitset=bs)
     nov = net.forward(obs)[4]
     assert (nov == 0).all()  # both observations share the IO slice that was marked seen
+
+
+def test_simhash_indices_against_numpy(oracle):
+    """SimHash.get_indices (src/network/hashes.py:124-139) restated with NumPy in float64: the oracle's f32 k-ascending chain gives the
+    same sign pattern except where a product is within rounding of zero (none in this sample; the chain order is the build's contract)."""
+    rng = np.random.default_rng(3)
+    B, n, bits = 200, 160, 24
+    x = (rng.random((B, n)) < 0.2).astype(np.uint8)
+    R = rng.standard_normal((n, bits)).astype(np.float32)
+    idx = np.empty(B, np.uint32)
+    oracle.lib().eazo_simhash_indices(x.ctypes.data, B, n, bits, R.ctypes.data, idx.ctypes.data)
+    prod = x.astype(np.float64) @ R.astype(np.float64)
+    assert np.abs(prod).min() > 1e-4
+    ref = ((prod < 0.0) * (2 ** np.arange(bits, dtype=np.uint64))).sum(axis=1).astype(np.uint32)
+    assert np.array_equal(idx, ref)
+    zero = np.zeros((1, n), np.uint8)   # an all-zero input: every product is +0, no bit set
+    out = np.empty(1, np.uint32)
+    oracle.lib().eazo_simhash_indices(zero.ctypes.data, 1, n, bits, R.ctypes.data, out.ctypes.data)
+    assert out[0] == 0
