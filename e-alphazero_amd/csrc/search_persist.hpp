@@ -68,7 +68,7 @@ struct PersistArgs {
 };
 
 constexpr int kPsAmapMax = 4096;
-constexpr int kPsMiscBytes = 2048;
+constexpr int kPsMiscBytes = 3584;
 
 struct PersistLds {
     int tstride;                      // words per tree
@@ -101,6 +101,7 @@ struct PersistMisc {
     float beta[kPsTrees];
     float gumbel[kPsTrees][kPsA];
     int invalid[kPsTrees][kPsA];
+    float edge[kPsTrees][16][2];  // backward: (reward, discount) of the 16 path levels of the chunk being folded
 };
 static_assert(sizeof(PersistMisc) <= kPsMiscBytes, "misc block too small");
 
@@ -412,11 +413,21 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
                     int wtop = __builtin_amdgcn_readlane(top, 0);
                     { const int t1 = __builtin_amdgcn_readlane(top, 16), t2 = __builtin_amdgcn_readlane(top, 32), t3 = __builtin_amdgcn_readlane(top, 48);
                       wtop = wtop > t1 ? wtop : t1; wtop = wtop > t2 ? wtop : t2; wtop = wtop > t3 ? wtop : t3; }
+                    // every lane needs the edges of all deeper levels of its tree: through LDS (one 8-byte store, then wide broadcast loads)
+                    // rather than 32 ds_bpermutes
+                    *reinterpret_cast<float2*>(&M.edge[ti][tj][0]) = make_float2(er, ed);
+                    ps_wave_sync();
+                    float ers[16], eds[16];
+#pragma unroll
+                    for (int s4 = 0; s4 < 8; ++s4) {
+                        const floatx4 v = *reinterpret_cast<const floatx4*>(&M.edge[ti][2 * s4][0]);
+                        ers[2 * s4] = v[0]; eds[2 * s4] = v[1]; ers[2 * s4 + 1] = v[2]; eds[2 * s4 + 1] = v[3];
+                    }
                     float G = Gin, U = Uin;
 #pragma unroll
                     for (int s = 15; s >= 0; --s) {
                         if (s > wtop) continue;
-                        const float rs = __shfl(er, s, 16), dd = __shfl(ed, s, 16);
+                        const float rs = ers[s], dd = eds[s];
                         if (s <= top && s >= tj) {
                             G = rs + dd * G;
                             U = 0.0f + (dd * dd) * U;  // children_rewards_epistemic_variance == 0 (context.py:149)
