@@ -55,3 +55,20 @@ def test_failed_rank_fails_the_launch():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--dry-run", "--batch", "-1"], env=_clean_env(),
                        capture_output=True, text=True, timeout=170)
     assert r.returncode != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_ranks_on_the_gpu_box_through_the_self_launch():
+    """The real engine under the N > 1 entry: `python bench.py --gpus 2` on a box with fewer GPUs than ranks is a rehearsal (the ranks
+    share the card, gloo all-gather through host memory) -- every line of the sharded path runs, `n_gpus` is 2, the value is not a
+    scaling number and says so."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "256", "--selfplay-steps", "4",
+                        "--no-cpu-baseline", "--no-extra"], env=_clean_env(), capture_output=True, text=True, timeout=580)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = _json_line(r.stdout)
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 512 and res["value"] > 0
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        assert "rehearsal" in res
