@@ -483,12 +483,18 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
     dense_flops = wl["net_flops"]
     if persistent:
         # search_persist_kernel: ALL S simulations of a real step in one launch (trees in LDS, DeepSea step, S forwards of B leaves)
+        # self-play: ONE launch per selfplay() call = T real steps x (root inference + S simulations), trees in LDS, DeepSea steps,
+        # (S + 1) forwards of B rows per real step
         kname = "search_persist_kernel"
-        k_ms = search.profile_replay("search", 20)
         n_launch = prof["search"]["launches"]
-        flops, dense = S * l23, S * dense_flops
+        fused = n_launch == n_instr
+        k_ms = search.profile_replay("search", 3 if fused else 20)
+        n_fwd = T_instr * (S + 1) if fused else S
+        flops, dense = n_fwd * l23, n_fwd * dense_flops
         pair_us = 1e3 * prof["search"]["ms"] / n_launch
-        algo = f"{S} simulations x {B} leaves x (layers 2-3 of 3 heads = {l23 // B} FLOP per leaf; layer 1 is a one-hot row gather)"
+        algo = (f"{T_instr} real steps x ({S} simulations + root) x {B} rows x (layers 2-3 of 3 heads = {l23 // B} FLOP per row; "
+                "layer 1 is a one-hot row gather)") if fused else \
+               f"{S} simulations x {B} leaves x (layers 2-3 of 3 heads = {l23 // B} FLOP per leaf; layer 1 is a one-hot row gather)"
     else:
         kname = wl["net_kernel"]
         k_ms = search.profile_replay("net", 200 if name != "c4" else 10)

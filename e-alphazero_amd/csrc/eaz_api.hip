@@ -130,6 +130,8 @@ struct eaz_search {
     int clear_pending;   // eaz_search_begin left the global tree arrays uncleared (the persistent kernel rewrites all of them)
     int sims_done;       // simulations run since eaz_search_begin
     unsigned long long* d_stamps;
+    PersistSelfplay last_sp;   // arguments of the last fused self-play launch (eaz_profile_replay)
+    char* d_replay_states;     // scratch states for that replay
 };
 
 extern "C" int eaz_ctx_create(int device, eaz_ctx** out) {
@@ -794,6 +796,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     s->B = B; s->S = opts->num_simulations; s->N = s->S + 1; s->A = env->dev.A;
     s->prof_on = 0; s->step_graph = nullptr; s->graph_states = nullptr; s->graph_flags = -1; s->pending_expand = -1;
     s->persist_ok = 0; s->persist_lds = 0; s->clear_pending = 0; s->sims_done = 0; s->d_stamps = nullptr;
+    std::memset(&s->last_sp, 0, sizeof s->last_sp); s->d_replay_states = nullptr;
     HIP_OK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&s->main, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
@@ -864,6 +867,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
                         mc >= 1 && L.total <= 160 * 1024;
         if (s->persist_ok)
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(search_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+        if (s->persist_ok) DALLOC(s->d_replay_states, static_cast<size_t>(B) * env->dev.state_bytes);
 #ifdef EAZ_FC_STAMPS
         DALLOC(s->d_stamps, 256 * 32);
         HIP_OK(hipMemset(s->d_stamps, 0, 256 * 32 * sizeof(unsigned long long)));
@@ -928,8 +932,10 @@ static int ensure_cleared(eaz_search* s, hipStream_t st) {
     return 0;
 }
 
-static int persist_launch(eaz_search* s, hipStream_t st) {
+static int persist_launch(eaz_search* s, hipStream_t st, const PersistSelfplay* sp = nullptr) {
     PersistArgs pa;
+    if (sp) pa.sp = *sp;
+    else std::memset(&pa.sp, 0, sizeof pa.sp);
     pa.t = s->tree;
     pa.t.fused_rf = 1;
     pa.net = s->net->dev;
@@ -1298,6 +1304,24 @@ extern "C" int eaz_selfplay_run(eaz_search* s, const eaz_selfplay_cfg* cfg, uint
     const int flags = (cfg->uniform_search_policy ? kFlagUniform : 0) | (cfg->sample_actions ? kFlagSampleVisits : 0) |
                       (cfg->sample_from_improved_policy ? kFlagSampleImproved : 0) | (d_gumbel ? kFlagExplicitGumbel : 0) |
                       (cfg->directed_exploration ? 16 : 0) | (static_cast<int>(cfg->exploration_beta != 0.0f) << 5);
+    if (s->persist_ok && g_persist) {
+        // DeepSea + FC network: the WHOLE call -- T real steps of root inference, search, action choice, auto-reset step and output -- is ONE
+        // launch of the persistent kernel (csrc/search_persist.hpp); nothing is captured, staged or copied
+        if (cfg->selfplay_steps == 0) return 0;
+        PersistSelfplay sp;
+        std::memset(&sp, 0, sizeof sp);
+        sp.on = 1; sp.T = cfg->selfplay_steps; sp.key = k;
+        sp.flags = (cfg->uniform_search_policy ? kSpUniform : 0) | (cfg->sample_actions ? kSpSampleVisits : 0) |
+                   (cfg->sample_from_improved_policy ? kSpSampleImproved : 0);
+        sp.sbeta = cfg->directed_exploration ? cfg->exploration_beta : 0.0f;  // selfplay.py:92
+        sp.gumbel_scale = s->opts.gumbel_scale;
+        sp.states = static_cast<char*>(d_states); sp.gumbel = d_gumbel;
+        sp.out_states = static_cast<char*>(d_out_states); sp.out_root_value = d_out_root_value; sp.out_root_std = d_out_root_std;
+        sp.out_value_pred = d_out_value_pred; sp.out_ube_pred = d_out_ube_pred; sp.out_qvar = d_out_qvar; sp.out_action = d_out_action;
+        s->last_sp = sp;
+        ProfScope ps(s, EAZ_K_SEARCH, S(stream));
+        return persist_launch(s, S(stream), &sp);
+    }
     // graph replay needs a capturable stream: work runs on the search's own stream, ordered after/before the caller's by events
     const bool use_graph = cfg->use_graph && !s->prof_on;
     hipStream_t user = S(stream), st = user;
@@ -1516,14 +1540,24 @@ extern "C" int eaz_profile_replay(eaz_search* s, int cls, int iters, double* ms_
     auto once = [&]() -> int {
         // the persistent search re-reads the root that the last eaz_search_begin left in the tree arrays (timing only: the statistics of
         // node 0 keep the previous launch's totals)
-        if (cls == EAZ_K_SEARCH) return persist_launch(s, st);
+        if (cls == EAZ_K_SEARCH) {
+            if (!s->last_sp.on) return persist_launch(s, st);
+            // the last fused self-play call again, on a scratch copy of its states and without outputs
+            PersistSelfplay sp = s->last_sp;
+            sp.states = s->d_replay_states; sp.gumbel = nullptr;
+            sp.out_states = nullptr; sp.out_root_value = sp.out_root_std = sp.out_value_pred = sp.out_ube_pred = sp.out_qvar = nullptr;
+            sp.out_action = nullptr;
+            return persist_launch(s, st, &sp);
+        }
         if (cls == EAZ_K_NET) return fused ? fc_onehot_launch(s->net, s->B, s->d_leaf_hot, s->d_novelty, o, hl, st) : fc_launch(s->net, s->B, s->d_obs, o, hl, st);
         leaf_gather_deepsea_kernel<<<cdiv(static_cast<long>(s->B) * 64, 256), 256, 0, st>>>(s->env->dev, s->tree, s->d_obs, s->d_next_reward,
                                                                                           s->d_next_term, s->d_next_legal);
         LAUNCH_OK();
         return 0;
     };
-    for (int i = 0; i < 3; ++i) { int rc = once(); if (rc) return rc; }
+    if (cls == EAZ_K_SEARCH && s->last_sp.on)
+        HIP_OK(hipMemcpyAsync(s->d_replay_states, s->last_sp.states, static_cast<size_t>(s->B) * s->env->dev.state_bytes, hipMemcpyDeviceToDevice, st));
+    for (int i = 0; i < (cls == EAZ_K_SEARCH ? 1 : 3); ++i) { int rc = once(); if (rc) return rc; }
     hipEvent_t a, b;
     HIP_OK(hipEventCreate(&a));
     HIP_OK(hipEventCreate(&b));

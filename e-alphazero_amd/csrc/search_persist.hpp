@@ -58,7 +58,23 @@ enum : int {
     PR_WORDS = 21
 };
 
+// Fused self-play (src/selfplay.py:78-149): with `on` the launch runs T real steps of step_fn for its 16 environments -- root inference,
+// root preparation (selfplay.py:92-106), the S simulations, final action / action weights (A.2), summary (A.7), action choice (:118-134),
+// auto-reset env.step (:135) and SelfplayOutput[t] (:136-143) -- and never touches the global tree arrays.
+enum : int { kSpUniform = 1, kSpSampleVisits = 2, kSpSampleImproved = 4 };
+struct PersistSelfplay {
+    int on, T, flags;
+    Key key;                  // key of the call; key_seq[t] = fold(key, kTagStep + t) (selfplay.py:147)
+    float sbeta, gumbel_scale;
+    char* states;             // [B] DeepSea states: last_states in, new last_states out
+    const float* gumbel;      // explicit unscaled root noise [T,B,A] or null (generated from the step's key)
+    char* out_states;         // SelfplayOutput fields [T,B(,A)]; any may be null
+    float *out_root_value, *out_root_std, *out_value_pred, *out_ube_pred, *out_qvar;
+    int32_t* out_action;
+};
+
 struct PersistArgs {
+    PersistSelfplay sp;
     TreeDev t;       // options + the global SoA arrays (root in, whole tree out)
     NetDev net;
     EnvDev env;
@@ -102,6 +118,8 @@ struct PersistMisc {
     float gumbel[kPsTrees][kPsA];
     int invalid[kPsTrees][kPsA];
     float edge[kPsTrees][16][2];  // backward: (reward, discount) of the 16 path levels of the chunk being folded
+    float root_v[kPsTrees], root_u[kPsTrees];  // fused self-play: value / ube prediction of the root (SelfplayOutput)
+    uint32_t root_state[kPsTrees];             // fused self-play: the environment's current state, packed
 };
 static_assert(sizeof(PersistMisc) <= kPsMiscBytes, "misc block too small");
 
@@ -144,6 +162,28 @@ __device__ __forceinline__ void ps_wave_sync() {
 #else
 #define EAZ_PSTAMP(i)
 #endif
+
+// pgx.Env.step (A.1) around deep_sea.py:59-81 on a state in registers; `flip` = action_map[row][pos] != 0 is fetched by the caller
+// (LDS or global).  Identical to envs.hpp ds_step.
+__device__ __forceinline__ int ps_ds_row(const eaz_deepsea_state& s, int G) {
+    int rr = s.step_count;  // _step_count is incremented before _step: the row read is the pre-increment count (deep_sea.py:62)
+    return rr < 0 ? 0 : (rr > G - 1 ? G - 1 : rr);
+}
+__device__ __forceinline__ eaz_deepsea_state ps_ds_step(eaz_deepsea_state s, int act, int flip, int G) {
+    if (s.terminated | s.truncated) {
+        s.reward = 0.0f;  // finished episode: no-op with zero rewards
+        return s;
+    }
+    s.step_count += 1;
+    const int shift = ((act == 0) ^ (flip != 0)) ? -1 : 1;        // :63
+    int pos = s.pos + shift;
+    pos = pos < 0 ? 0 : (pos > G - 1 ? G - 1 : pos);              // :64
+    const int term = s.step_count >= G - 1;                       // :72
+    s.pos = pos;
+    s.terminated = static_cast<uint8_t>(term);
+    s.reward = (term && pos == G - 1) ? 1.0f : 0.0f;              // :74-78
+    return s;
+}
 
 // mctx seq_halving.score_considered + masked_argmax [EXT] (A.2) with the root noise / mask of this tree in registers
 __device__ __forceinline__ int ps_root_pick(const Group<1, kPsA>& g, const NodeRows<kPsA>& r, const float (&cq)[kPsA], float considered_visit,
@@ -235,7 +275,8 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
         for (int c = 0; c < 4; ++c) W3s[(h * 4 + c) * kFcH + k] = c < No ? W3[k * No + c] : 0.0f;
     }
     __syncthreads();
-    if (tid < kPsTrees) {
+    const bool fused = a.sp.on != 0;
+    if (tid < kPsTrees && !fused) {
         const int i = tid, b = tree0 + i < B ? tree0 + i : B - 1;  // trees beyond the batch mirror the last one and are never written back
         uint32_t* R = trees + i * L.tstride;
         for (int n = 0; n < N; ++n) {
@@ -275,7 +316,9 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
             for (int c = 0; c < 4; ++c) hb1[h][c] = a.net.b[hidv[h + 1] * 3][4 * lane + c];
         const float* W1g[2] = {a.net.w[hidv[1] * 3] + 4 * lane, a.net.w[hidv[2] * 3] + 4 * lane};
         __builtin_amdgcn_s_setprio(3);  // the youngest wave of the workgroup loses every issue arbitration against its SIMD partner otherwise
-        for (int sim = 0; sim < S; ++sim) {
+        const int n_fwd = (fused ? a.sp.T : 1) * (S + (fused ? 1 : 0));  // fused: every real step starts with the root's forward
+        for (int f = 0; f < n_fwd; ++f) {
+            const int sim = fused ? f % (S + 1) - 1 : f;
             EAZ_PSTAMP(0);
             __syncthreads();  // S0
             // W1 rows of the second head: in flight under layer 2 of the first (waves 0-3 issue nothing but their weight stream there)
@@ -365,11 +408,36 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
         uint16_t* P = path + ti * S;
         const int gb = tree0 + ti < B ? tree0 + ti : B - 1;
         const Group<1, kPsA> g = make_group<1, kPsA>(gb, 0, kPsA);
-        const float beta = M.beta[ti];
+        const bool tree_live = tree0 + ti < B;  // trees beyond the batch mirror the last one; they never store outside LDS
+        // fused self-play: beta * linspace(0, 1, B)[b] (selfplay.py:105, root_prep_kernel); search only: the caller's per-tree beta
+        const float beta = fused ? a.sp.sbeta * (B > 1 ? static_cast<float>(gb) / static_cast<float>(B - 1) : 0.0f) : M.beta[ti];
         const bool need_var = beta != 0.0f;
+        auto amap_flip = [&](const eaz_deepsea_state& st) -> int {
+            const int idx = ps_ds_row(st, env.G) * env.G + st.pos;                                         // deep_sea.py:62
+            return (a.amap_lds ? amap[idx] : env.action_map[idx]) != 0;
+        };
 
-        for (int sim = 0; sim <= S; ++sim) {
+        const int n_steps = fused ? a.sp.T : 1;
+        for (int step = 0; step < n_steps; ++step) {
+        Key kt{0u, 0u};
+        if (fused) {
+            // ---- a new real step: empty trees (mctx instantiate_tree_from_root, A.3: ints -1 / 0, floats 0), the root's observation ----
+            kt = fold(a.sp.key, kTagStep + static_cast<uint32_t>(step));                                   // key_seq[t], selfplay.py:147
+            for (int n = tj; n < N; n += 16) {
+                uint32_t* R = T + n * PR_WORDS;
+#pragma unroll
+                for (int w = 0; w < PR_WORDS; ++w) R[w] = (w == PR_INDEX || w == PR_INDEX + 1) ? 0xFFFFFFFFu : 0u;
+            }
+            if (tj == 0) {
+                if (step == 0) M.root_state[ti] = ps_pack(ds_load(a.sp.states + static_cast<long>(gb) * sizeof(eaz_deepsea_state)));
+                const int hh = ds_hot_index(env, ps_unpack(M.root_state[ti]));                             // states.observation, selfplay.py:89-91
+                M.hot[ti] = hh < 0 ? 0 : (hh >= K1 ? K1 - 1 : hh);
+            }
+            ps_wave_sync();
+        }
+        for (int sim = fused ? -1 : 0; sim <= S; ++sim) {
             EAZ_PSTAMP(0);
+            if (sim >= 0) {
             const int D = M.D[ti], dst = M.dst[ti];
             if (sim > 0) {
                 // ---- expand: mctx update_tree_node + topology (A.3) with epistemic_recurrent_fn (src/context.py:132-153) ------------
@@ -513,30 +581,15 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
                 }
                 const int nd = nx < 0 ? sim + 1 : nx;
                 M.parent[ti] = node; M.action[ti] = act; M.dst[ti] = nd; M.D[ti] = depth;
-                eaz_deepsea_state ns = ps_unpack(T[node * PR_WORDS + PR_STATE]);  // context.py:125-127
-                if (ns.terminated | ns.truncated) {
-                    ns.reward = 0.0f;  // pgx.Env.step on a finished episode: no-op with zero rewards (envs.hpp ds_step)
-                } else {
-                    // ds_step (deep_sea.py:59-81) with the action map in LDS
-                    const int Gd = env.G;
-                    ns.step_count += 1;
-                    int rr = ns.step_count - 1;
-                    rr = rr < 0 ? 0 : (rr > Gd - 1 ? Gd - 1 : rr);
-                    const int flip = (a.amap_lds ? amap[rr * Gd + ns.pos] : env.action_map[rr * Gd + ns.pos]) != 0;  // :62
-                    const int shift = ((act == 0) ^ flip) ? -1 : 1;                                                   // :63
-                    int pos = ns.pos + shift;
-                    pos = pos < 0 ? 0 : (pos > Gd - 1 ? Gd - 1 : pos);                                                // :64
-                    const int term = ns.step_count >= Gd - 1;                                                         // :72
-                    ns.pos = pos;
-                    ns.terminated = static_cast<uint8_t>(term);
-                    ns.reward = (term && pos == Gd - 1) ? 1.0f : 0.0f;                                                // :74-78
-                }
+                const eaz_deepsea_state ps0 = ps_unpack(T[node * PR_WORDS + PR_STATE]);
+                const eaz_deepsea_state ns = ps_ds_step(ps0, act, amap_flip(ps0), env.G);  // context.py:125-127
                 T[nd * PR_WORDS + PR_STATE] = ps_pack(ns);
                 M.o_reward[ti] = ns.reward;   // rewards[b, current_player], single player (deep_sea.py:100-102)
                 M.o_term[ti] = ns.terminated;
                 const int hh = ds_hot_index(env, ns);
                 M.hot[ti] = hh < 0 ? 0 : (hh >= K1 ? K1 - 1 : hh);
             }
+            }  // sim >= 0
             EAZ_PSTAMP(3);
             __syncthreads();  // S0: hot[], the leaf's reward / terminated flag
             // -------------------------------------------------------- forward of the 16 leaves --------------------------------------------
@@ -626,9 +679,109 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
             }
             EAZ_PSTAMP(5);
             __syncthreads();  // S7: the heads' outputs
+            if (sim < 0) {
+                // ---- fused self-play, root: selfplay.py:92-106,113 (root_prep_kernel) + mctx instantiate_tree_from_root (tree_root_kernel) ----
+                if (tj == 0) {
+                    const float root_v = M.o_value[ti];
+                    const float root_u = ube_combine(M.o_ube[ti], M.o_nov[ti], t.max_u);                  // fully_connected.py:92-96
+                    const Key gkey = fold(kt, kTagGumbel);
+                    float lg[kPsA], gum[kPsA];
+#pragma unroll
+                    for (int c = 0; c < kPsA; ++c) {
+                        lg[c] = (a.sp.flags & kSpUniform) ? 1.0f : M.o_logit[ti][c];                      // :96-98
+                        const long gi = static_cast<long>(gb) * kPsA + c;
+                        const float gn = a.sp.gumbel ? a.sp.gumbel[static_cast<long>(step) * B * kPsA + gi] : gumbel(gkey, static_cast<uint32_t>(gi));
+                        gum[c] = a.sp.gumbel_scale * gn;
+                        M.gumbel[ti][c] = gum[c];
+                        M.invalid[ti][c] = 0;                                                             // :113 ~legal_action_mask: all legal (deep_sea.py:19)
+                    }
+                    const float m = g.vmax(lg);                                                           // mask_invalid_actions (A.2)
+                    T[PR_LOGITS] = f2u(lg[0] - m); T[PR_LOGITS + 1] = f2u(lg[1] - m);
+                    T[PR_RAW_VALUE] = f2u(root_v); T[PR_NODE_VALUE] = f2u(root_v);
+                    T[PR_RAW_VAR] = f2u(root_u); T[PR_NODE_VAR] = f2u(root_u);
+                    T[PR_NODE_VISITS] = 1u;
+                    T[PR_STATE] = M.root_state[ti];
+                    M.root_v[ti] = root_v; M.root_u[ti] = root_u;
+                    M.D[ti] = 0; M.parent[ti] = 0; M.action[ti] = 0; M.dst[ti] = 0;
+                }
+                ps_wave_sync();
+            }
         }
+        if (fused && tj == 0) {
+            // ---- fused self-play, after the search: gumbel_muzero_policy tail (A.2, tree_finish_kernel), epistemic_summary (A.7,
+            // tree_summary_kernel), action choice (selfplay.py:118-134, choose_action_kernel), auto-reset env.step (:135), SelfplayOutput[t] ----
+            NodeRows<kPsA> rw;
+#pragma unroll
+            for (int c = 0; c < kPsA; ++c) {
+                rw.logits[c] = u2f(T[PR_LOGITS + c]); rw.values[c] = u2f(T[PR_VALUES + c]); rw.rewards[c] = u2f(T[PR_REWARDS + c]);
+                rw.discounts[c] = u2f(T[PR_DISCOUNTS + c]); rw.visits[c] = static_cast<int>(T[PR_VISITS + c]);
+                rw.index[c] = static_cast<int>(T[PR_INDEX + c]); rw.var[c] = need_var ? u2f(T[PR_VAR + c]) : 0.0f; rw.rvar[c] = 0.0f;
+            }
+            float cq[kPsA];
+            qtransform<1, kPsA>(t, g, rw, u2f(T[PR_RAW_VALUE]), u2f(T[PR_RAW_VAR]), beta, cq);
+            const int inv[kPsA] = {M.invalid[ti][0], M.invalid[ti][1]};
+            const float gum[kPsA] = {M.gumbel[ti][0], M.gumbel[ti][1]};
+            const int maxN = rw.visits[0] > rw.visits[1] ? rw.visits[0] : rw.visits[1];
+            int act = ps_root_pick(g, rw, cq, static_cast<float>(maxN), gum, inv);
+            float x[kPsA], aw[kPsA];
+#pragma unroll
+            for (int c = 0; c < kPsA; ++c) x[c] = rw.logits[c] + cq[c];
+            const float mx = g.vmax(x);
+#pragma unroll
+            for (int c = 0; c < kPsA; ++c) x[c] = inv[c] ? kF32Min : x[c] - mx;
+            g.softmax(x, aw);
+            // summary
+            const float sum_value = u2f(T[PR_NODE_VALUE]), sum_std = __builtin_sqrtf(u2f(T[PR_NODE_VAR]));
+            const float ftot = static_cast<float>(rw.visits[0] + rw.visits[1]);
+            float qvar[kPsA], vprob[kPsA];
+#pragma unroll
+            for (int c = 0; c < kPsA; ++c) {
+                const float d = rw.discounts[c];
+                qvar[c] = 0.0f + (d * d) * u2f(T[PR_VAR + c]);  // children_rewards_epistemic_variance == 0
+                vprob[c] = static_cast<float>(rw.visits[c]) / (ftot > 1.0f ? ftot : 1.0f);
+            }
+            // action choice: categorical over visit PROBABILITIES / action weights used as logits (reproduced literally), = argmax(x + Gumbel)
+            if (a.sp.flags & kSpSampleVisits) {
+                const Key kvis = fold(kt, kTagSampleVisits);
+                float best = -kInf; int bi = 0;
+#pragma unroll
+                for (int c = 0; c < kPsA; ++c) {
+                    const float v = vprob[c] + gumbel(kvis, static_cast<uint32_t>(gb * kPsA + c));
+                    if (v > best) { best = v; bi = c; }
+                }
+                act = bi;
+            }
+            if (a.sp.flags & kSpSampleImproved) {
+                const Key kimp = fold(kt, kTagSampleImproved);
+                float best = -kInf; int bi = 0;
+#pragma unroll
+                for (int c = 0; c < kPsA; ++c) {
+                    const float v = aw[c] + gumbel(kimp, static_cast<uint32_t>(gb * kPsA + c));
+                    if (v > best) { best = v; bi = c; }
+                }
+                act = bi;
+            }
+            // vmap(auto_reset(env.step, env.init)) (selfplay.py:26-75,135): a finished episode restarts, anything else steps
+            const eaz_deepsea_state cur = ps_unpack(M.root_state[ti]);
+            const eaz_deepsea_state nxt = (cur.terminated | cur.truncated) ? ds_init() : ps_ds_step(cur, act, amap_flip(cur), env.G);
+            M.root_state[ti] = ps_pack(nxt);
+            if (tree_live) {
+                const long o = static_cast<long>(step) * B + gb;
+                if (a.sp.out_value_pred) a.sp.out_value_pred[o] = M.root_v[ti];
+                if (a.sp.out_ube_pred) a.sp.out_ube_pred[o] = M.root_u[ti];
+                if (a.sp.out_root_value) a.sp.out_root_value[o] = sum_value;
+                if (a.sp.out_root_std) a.sp.out_root_std[o] = sum_std;
+                if (a.sp.out_action) a.sp.out_action[o] = act;
+                if (a.sp.out_qvar) { a.sp.out_qvar[o * kPsA] = qvar[0]; a.sp.out_qvar[o * kPsA + 1] = qvar[1]; }
+                if (a.sp.out_states) ds_store(a.sp.out_states + o * sizeof(eaz_deepsea_state), nxt);
+                if (step == n_steps - 1) ds_store(a.sp.states + static_cast<long>(gb) * sizeof(eaz_deepsea_state), nxt);
+            }
+        }
+        if (fused) ps_wave_sync();
+        }  // real steps
     }
 
+    if (fused) return;  // self-play never reads the tree arrays
     // ---------------------------------------------------------------- write the trees back (mctx SoA layout) -----------------------
     __syncthreads();
     int16_t* par = reinterpret_cast<int16_t*>(H1);            // [16][N] parent, then [16][N] action_from_parent (H1/H2 are free now)
