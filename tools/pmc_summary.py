@@ -35,8 +35,8 @@ def main():
             e[f"{cname}_KB_per_launch"] = round(tot / max(n, 1), 2)
             e["launches"] = n
         kernels[k] = e
-    json.dump({"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 1 --warmup 0 "
-                          "--selfplay-steps 4 --no-cpu-baseline --no-extra (two separate passes)",
+    json.dump({"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 1 --warmup 1 "
+                          "--no-cpu-baseline --no-extra (two separate passes; the kernel's launches include the output-less replay launches of the roofline measurement)",
                "note": "RAW counter values in KB (rocprofv3 FETCH_SIZE / WRITE_SIZE), two separate passes.  MI355X_MICROARCH.md (HBM): on gfx950 "
                        "FETCH_SIZE reports exactly half of the bytes of a 16-B-per-lane streaming read -- consumers double it for kernels "
                        "whose fetches are such streams (bench.py does for the forward kernel's weight loads); WRITE_SIZE is exact for "
