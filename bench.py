@@ -350,7 +350,7 @@ def run_rank(args):
     # ---- the other single-GPU configurations of BASELINE.json, short passes after the timed region (driver-visible C3 / C4 numbers) ----
     if rank == 0 and n_gpus == 1 and args.workload == "c2" and not args.no_extra and not args.batch and not args.sims:
         result["extra"] = {}
-        for name, (xs, xw, xt) in (("c3", (2, 1, 0)), ("c4", (1, 1, 2))):
+        for name, (xs, xw, xt) in (("c3", (3, 1, 0)), ("c4", (1, 1, 2))):
             xargs = argparse.Namespace(**vars(args))
             xargs.workload, xargs.selfplay_steps = name, xt
             wl = meas = None

@@ -17,6 +17,7 @@
 #include "net_resnet.hpp"
 #include "search_kernels.hpp"
 #include "search_persist.hpp"
+#include "net_fc_pipe.hpp"
 
 using namespace eaz;
 
@@ -339,7 +340,11 @@ static int net_create_fc_impl(eaz_net* n, int in_dim, int hidden, int num_action
     for (int l = 0; l < 12; ++l) {
         int k, m;
         layer_dims(in_dim, hidden, num_actions, l, &k, &m);
-        HIP_OK(hipMalloc(&n->d_w[l], sizeof(float) * k * m));
+        // layer-1 weights are followed by zero rows up to a whole number of 16-k-step rounds: the pipelined forward (net_fc_pipe.hpp)
+        // streams whole rounds and its reads stay inside the allocation
+        const size_t rows = (l % 3) == 0 ? static_cast<size_t>(fp_kpad(k)) : static_cast<size_t>(k);
+        HIP_OK(hipMalloc(&n->d_w[l], sizeof(float) * rows * m));
+        if (rows != static_cast<size_t>(k)) HIP_OK(hipMemset(n->d_w[l], 0, sizeof(float) * rows * m));
         HIP_OK(hipMalloc(&n->d_b[l], sizeof(float) * m));
         HIP_OK(hipMemcpy(n->d_w[l], h_w[l], sizeof(float) * k * m, hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(n->d_b[l], h_b[l], sizeof(float) * m, hipMemcpyHostToDevice));
@@ -390,6 +395,8 @@ static int net_create_fc_impl(eaz_net* n, int in_dim, int hidden, int num_action
         HIP_OK(hipMemcpy(n->d_hot_index, hi.data(), hi.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         n->dev.hot_index = n->d_hot_index;
     }
+    if (fp_eligible(in_dim, num_actions))
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc16p_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, fp_lds_bytes(kFpMaxK, kFcW3Cols)));
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_forward_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFcLdsBytes));
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_forward_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFcLdsBytes));
     HIP_OK(hipMalloc(&n->d_kstep_storage, 8 * sizeof(unsigned long long)));
@@ -610,7 +617,7 @@ extern "C" int eaz_tune_set(int knob, int value) {
         return 0;
     }
     if (knob == EAZ_TUNE_FC_TILE) {
-        ARG_OK(value == 0 || value == 16 || value == 64);
+        ARG_OK(value == 0 || value == 1 || value == 16 || value == 64);
         g_fc_tile = value;
     } else if (knob == EAZ_TUNE_FUSED_LEAF) {
         g_fused_leaf = value != 0;
@@ -635,6 +642,14 @@ static int fc_launch(eaz_net* n, int B, const uint8_t* obs, const NetOut& o, con
     if (B <= 0 || heads.n <= 0) return 0;
     if (n->kind == 1) {  // residual tower: six samples per workgroup, all heads in one launch
         resnet_forward_kernel<<<cdiv(B, kRnSamples), 256, kRnLdsBytes, st>>>(n->rdev, obs, B, o);
+        LAUNCH_OK();
+        return 0;
+    }
+    // narrow heads on observations that fit an f32 LDS tile: the pipelined 16-row kernel (net_fc_pipe.hpp), one workgroup per tile, all
+    // heads back to back
+    if ((g_fc_tile == 0 || g_fc_tile == 1) && fp_eligible(n->dev.in_dim, n->dev.A)) {
+        const int lds = fp_lds_bytes(n->dev.in_dim, n->dev.A);
+        fc16p_forward_kernel<<<dim3(cdiv(B, kF16M), heads.n), 256, lds, st>>>(n->dev, obs, B, o, heads, n->d_kstep_counter);
         LAUNCH_OK();
         return 0;
     }

@@ -274,7 +274,8 @@ EAZ_API int eaz_profile_replay(eaz_search* s, int kernel_class, int iters, doubl
 /* Kernel-selection knobs for A/B measurements and for the parity tests (every setting computes identical results).  They are
  * read when a kernel is launched -- a real step that eaz_selfplay_run has already captured into its graph keeps the values it was
  * captured with -- so set them before creating the search they are meant for.
- *   EAZ_TUNE_FC_TILE    0 = automatic (16-row tiles while the launch is fully resident, else 64), 16 or 64 = pinned
+ *   EAZ_TUNE_FC_TILE    0 = automatic (the pipelined 16-row kernel for narrow heads on observations of <= 1024 inputs, otherwise 16-row
+ *                       tiles while the launch is fully resident, else 64), 1 = pipelined where eligible, 16 or 64 = pinned
  *   EAZ_TUNE_FUSED_LEAF 1 = DeepSea searches created from now on step the environment inside the tree kernel and feed the
  *                           network the one-hot index (no leaf-gather launch); 0 = separate leaf-gather + dense forward */
 #define EAZ_TUNE_FC_TILE 0
