@@ -131,7 +131,7 @@ def build_workload(name, args, device, rank):
         A = W
         desc = f"Subleq word_size={W} task=1 binary obs, batch={B}/GPU, {S} sims, {T} real steps per selfplay() call, FC H={H} (BASELINE.json configs[2])"
         data = "synthetic (random-init FC net, half-filled novelty set)"
-        net_kernel, net_flops = "fc16_forward_kernel", fc_flops_per_eval(in_dim, A, (0, 1, 2)) * B
+        net_kernel, net_flops = "fc16p_forward_kernel", fc_flops_per_eval(in_dim, A, (0, 1, 2)) * B   # dense rows, narrow heads: the pipelined kernel
         pmc_tag, gather_kernel = None, "subleq_step_kernel (env step + observation row)"
 
         def oracle(O):
@@ -499,7 +499,7 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
         kname = wl["net_kernel"]
         k_ms = search.profile_replay("net", 200 if name != "c4" else 10)
         n_launch = max(prof["net"]["launches"], 1)
-        if kname == "fc16_forward_kernel":
+        if kname in ("fc16_forward_kernel", "fc16p_forward_kernel"):
             # counter unit: one k-step of a 16-row tile; never more than the dense layer 1 (padded k-steps of a partial block are not work)
             l1 = min(prof["net"]["layer1_ksteps"] * (16 * H * 4 * 2) / n_launch, sum(2 * wl["in_dim"] * H for _ in heads) * B)
             flops = l23 + l1
