@@ -131,6 +131,11 @@ struct eaz_search {
     int clear_pending;   // eaz_search_begin left the global tree arrays uncleared (the persistent kernel rewrites all of them)
     int sims_done;       // simulations run since eaz_search_begin
     unsigned long long* d_stamps;
+    // per-simulation path, sub-batch pipelining: views of this search over [0, b0) and [b0, B) that run the simulations on two streams, so
+    // that one half's latency-bound env-step kernel overlaps the other half's MFMA-bound forward (Subleq: the interpreter launch is one
+    // wavefront per CU for 60 us).  Views share the parent's allocations (pointer offsets), own their streams / events.
+    std::vector<eaz_search*> shards;
+    hipEvent_t ev_shard_fork, ev_shard_join;
     PersistSelfplay last_sp;   // arguments of the last fused self-play launch (eaz_profile_replay)
     char* d_replay_states;     // scratch states for that replay
 };
@@ -600,6 +605,7 @@ static int g_fused_leaf = [] { const char* e = std::getenv("EAZ_FUSED_LEAF"); re
 static int g_tree_block = [] { const char* e = std::getenv("EAZ_TREE_BLOCK"); return e ? std::atoi(e) : 64; }();
 static int g_tree_spread = [] { const char* e = std::getenv("EAZ_TREE_SPREAD"); return e ? std::atoi(e) : 0; }();  // 0 = automatic
 static int g_persist = [] { const char* e = std::getenv("EAZ_PERSIST"); return e ? std::atoi(e) : 1; }();
+static int g_shards = [] { const char* e = std::getenv("EAZ_SHARDS"); return e ? std::atoi(e) : 0; }();  // 0 = automatic
 
 extern "C" int eaz_tune_set(int knob, int value) {
     if (knob == EAZ_TUNE_TREE_BLOCK) {
@@ -614,6 +620,11 @@ extern "C" int eaz_tune_set(int knob, int value) {
     }
     if (knob == EAZ_TUNE_PERSIST) {
         g_persist = value != 0;
+        return 0;
+    }
+    if (knob == EAZ_TUNE_SHARDS) {
+        ARG_OK(value == 0 || value == 1 || value == 2 || value == 4);
+        g_shards = value;
         return 0;
     }
     if (knob == EAZ_TUNE_FC_TILE) {
@@ -799,6 +810,38 @@ struct ProfScope {
     }
 };
 
+// a view of `p` over the trees [b0, b0 + Bs): every per-tree array pointer moved by b0 rows, own streams and events, nothing owned
+static int make_shard(eaz_search* p, int b0, int Bs, eaz_search** out) {
+    eaz_search* c = new eaz_search(*p);
+    c->allocs.clear(); c->spans.clear(); c->ev_pool.clear(); c->shards.clear();
+    c->step_graph = nullptr; c->graph_states = nullptr; c->graph_flags = -1; c->pending_expand = -1; c->prof_on = 0;
+    c->persist_ok = 0; c->clear_pending = 0; c->d_replay_states = nullptr; c->d_stamps = nullptr;
+    c->B = Bs;
+    c->side = c->main = nullptr;
+    c->ev_fork = c->ev_join = c->ev_in = c->ev_out = c->ev_shard_fork = c->ev_shard_join = nullptr;
+    // no side stream of its own: the novelty lookup runs in line with the half-batch (the two halves overlap each other instead; a second
+    // level of fork / join inside the captured step crashed hipGraph instantiation on ROCm 7.2)
+    HIP_OK(hipStreamCreateWithFlags(&c->main, hipStreamNonBlocking));
+    const long N = p->N, A = p->A, SB = p->tree.state_bytes, Sn = p->S, OD = p->env->dev.obs_dim;
+    TreeDev& t = c->tree;
+    t.B = Bs;
+#define OFF(ptr, per_tree) ptr = ptr ? ptr + static_cast<long>(b0) * (per_tree) : ptr
+    OFF(t.node_visits, N); OFF(t.parents, N); OFF(t.action_from_parent, N);
+    OFF(t.raw_values, N); OFF(t.node_values, N); OFF(t.raw_var, N); OFF(t.node_var, N);
+    OFF(t.children_index, N * A); OFF(t.children_visits, N * A); OFF(t.children_prior_logits, N * A); OFF(t.children_values, N * A);
+    OFF(t.children_rewards, N * A); OFF(t.children_discounts, N * A); OFF(t.children_var, N * A); OFF(t.children_reward_var, N * A);
+    OFF(t.beta, 1); OFF(t.root_invalid, A); OFF(t.root_gumbel, A); OFF(t.embeddings, N * SB);
+    OFF(t.sim_parent, 1); OFF(t.sim_action, 1); OFF(t.sim_next, 1); OFF(t.path_node, Sn); OFF(t.path_action, Sn); OFF(t.path_len, 1);
+    OFF(t.net_logits, A); OFF(t.net_value, 1); OFF(t.net_ube, 1); OFF(t.net_novelty, 1);
+    OFF(t.next_reward, 1); OFF(t.next_term, 1); OFF(t.next_legal, A);
+    OFF(t.fuse_reward, 1); OFF(t.fuse_term, 1); OFF(t.leaf_hot, 1);
+    OFF(c->d_obs, OD); OFF(c->d_novelty, 1); OFF(c->d_exploit, A); OFF(c->d_explore, A); OFF(c->d_v, 1); OFF(c->d_u, 1);
+    OFF(c->d_next_reward, 1); OFF(c->d_next_term, 1); OFF(c->d_next_legal, A); OFF(c->d_leaf_hot, 1);
+#undef OFF
+    *out = c;
+    return 0;
+}
+
 extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B, const eaz_search_opts* opts, eaz_search** out) {
     ARG_OK(ctx && env && net && opts && out && B > 0);
     ARG_OK(opts->num_simulations >= 1 && opts->num_simulations <= 4096);
@@ -883,6 +926,22 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
         if (s->persist_ok)
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(search_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
         if (s->persist_ok) DALLOC(s->d_replay_states, static_cast<size_t>(B) * env->dev.state_bytes);
+        // two half-batches on two streams where the env step is the interpreter (Subleq) and the batch is big enough to split
+        s->ev_shard_fork = s->ev_shard_join = nullptr;
+        int want = g_shards ? g_shards : (env->dev.kind == EAZ_ENV_SUBLEQ && B >= 2048 ? 4 : (env->dev.kind == EAZ_ENV_SUBLEQ && B >= 1024 ? 2 : 1));
+        while (want > 1 && B / want < 64) want /= 2;
+        if (want > 1) {
+            HIP_OK(hipEventCreateWithFlags(&s->ev_shard_fork, hipEventDisableTiming));
+            const int per = ((B / want) / 64) * 64;  // keeps the 16-byte alignment of every per-tree row
+            for (int k = 0; k < want; ++k) {
+                eaz_search* c = nullptr;
+                const int b0 = k * per, Bs = k + 1 == want ? B - b0 : per;
+                const int rc = make_shard(s, b0, Bs, &c);
+                if (rc) { (void)eaz_search_destroy(s); return rc; }
+                HIP_OK(hipEventCreateWithFlags(&c->ev_shard_join, hipEventDisableTiming));
+                s->shards.push_back(c);
+            }
+        }
 #ifdef EAZ_FC_STAMPS
         DALLOC(s->d_stamps, 256 * 32);
         HIP_OK(hipMemset(s->d_stamps, 0, 256 * 32 * sizeof(unsigned long long)));
@@ -894,16 +953,20 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
 
 extern "C" int eaz_search_destroy(eaz_search* s) {
     if (!s) return 0;
+    for (eaz_search* c : s->shards) (void)eaz_search_destroy(c);  // views: streams and events only
+    s->shards.clear();
+    if (s->ev_shard_fork && s->allocs.size()) (void)hipEventDestroy(s->ev_shard_fork);  // views hold a copy of the parent's handle
+    if (s->ev_shard_join) (void)hipEventDestroy(s->ev_shard_join);
     for (void* p : s->allocs) (void)hipFree(p);
     for (auto& sp : s->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto& e : s->ev_pool) (void)hipEventDestroy(e);
     if (s->step_graph) (void)hipGraphExecDestroy(s->step_graph);
     if (s->side) (void)hipStreamDestroy(s->side);
     if (s->main) (void)hipStreamDestroy(s->main);
-    (void)hipEventDestroy(s->ev_in);
-    (void)hipEventDestroy(s->ev_out);
-    (void)hipEventDestroy(s->ev_fork);
-    (void)hipEventDestroy(s->ev_join);
+    if (s->ev_in) (void)hipEventDestroy(s->ev_in);
+    if (s->ev_out) (void)hipEventDestroy(s->ev_out);
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     delete s;
     return 0;
 }
@@ -1083,6 +1146,32 @@ extern "C" int eaz_search_run(eaz_search* s, void* stream) {
         int rc = persist_launch(s, S(stream));
         if (rc) return rc;
         s->clear_pending = 0;
+        s->sims_done = s->S;
+        return 0;
+    }
+    if (s->shards.size() > 1 && !s->prof_on && s->pending_expand < 0 && s->sims_done == 0) {
+        // sub-batches: shard 0 on the caller's stream, the others on their own streams (forked / joined with events: capturable); trees are
+        // independent, so the results are those of the unsharded loop
+        hipStream_t st = S(stream);
+        int rc = ensure_cleared(s, st);
+        if (rc) return rc;
+        const size_t K = s->shards.size();
+        for (eaz_search* c : s->shards) { c->opts = s->opts; c->tree.fused_rf = 1; c->pending_expand = -1; c->fuse_leaf = s->fuse_leaf; }
+        HIP_OK(hipEventRecord(s->ev_shard_fork, st));
+        for (size_t k = 1; k < K; ++k) HIP_OK(hipStreamWaitEvent(s->shards[k]->main, s->ev_shard_fork, 0));
+        for (int sim = 0; sim < s->S; ++sim)
+            for (size_t k = 0; k < K; ++k) {
+                rc = eaz_search_simulate(s->shards[k], sim, k == 0 ? st : s->shards[k]->main);
+                if (rc) return rc;
+            }
+        for (size_t k = 0; k < K; ++k) {
+            rc = flush_expand(s->shards[k], k == 0 ? st : s->shards[k]->main);
+            if (rc) return rc;
+        }
+        for (size_t k = 1; k < K; ++k) {
+            HIP_OK(hipEventRecord(s->shards[k]->ev_shard_join, s->shards[k]->main));
+            HIP_OK(hipStreamWaitEvent(st, s->shards[k]->ev_shard_join, 0));
+        }
         s->sims_done = s->S;
         return 0;
     }

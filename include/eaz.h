@@ -289,6 +289,10 @@ EAZ_API int eaz_profile_replay(eaz_search* s, int kernel_class, int iters, doubl
  *                        simulations in ONE persistent launch (16 trees per workgroup, csrc/search_persist.hpp); 0 = one tree kernel +
  *                        one forward per simulation.  eaz_search_simulate always uses the per-simulation kernels. */
 #define EAZ_TUNE_PERSIST 4
+/*   EAZ_TUNE_SHARDS      sub-batch pipelining of the per-simulation path, read by eaz_search_create: 2 / 4 = the batch is searched as that many
+ *                        sub-batches on as many streams (one sub-batch's env-step launch overlaps another's forward), 1 = off,
+ *                        0 (default) = 4 for Subleq batches of >= 2048 environments, 2 from 1024, else 1 */
+#define EAZ_TUNE_SHARDS 5
 EAZ_API int eaz_tune_set(int knob, int value);
 
 #ifdef __cplusplus

@@ -30,11 +30,12 @@ def eaz():
 
 # Every GPU test runs once per kernel selection (include/eaz.h eaz_tune_set): all of them must give identical results.
 KERNEL_VARIANTS = {
-    # name: (fc_tile, fused_leaf, tree_block, tree_spread, persist)
-    "persist": (0, 1, 64, 0, 1),           # default: eligible searches (DeepSea, FC, trees fit LDS) run as ONE persistent launch
-    "auto-fused": (0, 1, 64, 0, 0),        # 16-row FC tiles, DeepSea leaf step fused into the tree kernel + one-hot forward
-    "tile16-unfused": (16, 0, 128, 4, 0),  # 16-row FC tiles on dense observation rows, separate leaf-gather launch
-    "tile64-unfused": (64, 0, 256, 1, 0),  # 64-row FC tiles, separate leaf-gather launch, 256-thread tree workgroups
+    # name: (fc_tile, fused_leaf, tree_block, tree_spread, persist, shards)
+    "persist": (0, 1, 64, 0, 1, 0),           # default: eligible searches (DeepSea, FC, trees fit LDS) run as ONE persistent launch
+    "auto-fused": (0, 1, 64, 0, 0, 1),        # 16-row FC tiles, DeepSea leaf step fused into the tree kernel + one-hot forward
+    "tile16-unfused": (16, 0, 128, 4, 0, 1),  # 16-row FC tiles on dense observation rows, separate leaf-gather launch
+    "tile64-sharded": (64, 0, 256, 1, 0, 2),  # 64-row FC tiles, separate leaf-gather launch, 256-thread tree workgroups; every search of
+                                              # >= 128 trees runs as two half-batches on two streams (sub-batch pipelining)
 }
 
 
@@ -47,7 +48,7 @@ def pytest_generate_tests(metafunc):
 def kernel_variant(request):
     from e_alphazero_amd import engine
 
-    tile, fused, tblock, tspread, persist = KERNEL_VARIANTS[request.param]
-    engine.tune(fc_tile=tile, fused_leaf=fused, tree_block=tblock, tree_spread=tspread, persist=persist)
+    tile, fused, tblock, tspread, persist, shards = KERNEL_VARIANTS[request.param]
+    engine.tune(fc_tile=tile, fused_leaf=fused, tree_block=tblock, tree_spread=tspread, persist=persist, shards=shards)
     yield request.param
-    engine.tune(fc_tile=0, fused_leaf=1, tree_block=64, tree_spread=0, persist=1)
+    engine.tune(fc_tile=0, fused_leaf=1, tree_block=64, tree_spread=0, persist=1, shards=0)
