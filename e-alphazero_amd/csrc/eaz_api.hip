@@ -623,7 +623,7 @@ extern "C" int eaz_tune_set(int knob, int value) {
         return 0;
     }
     if (knob == EAZ_TUNE_SHARDS) {
-        ARG_OK(value == 0 || value == 1 || value == 2 || value == 4);
+        ARG_OK(value == 0 || value == 1 || value == 2 || value == 4);  // 8 / 16 streams measured 328 k / 192 k env-steps/s at C3 (4: 559 k)
         g_shards = value;
         return 0;
     }
