@@ -256,6 +256,8 @@ static int subleq_envs_per_wg(int B) {
     while (epw > 8 && cdiv(B, epw) < 256) epw /= 2;
     return epw;
 }
+// word_size 16: one wavefront per environment (subleq16_wave_kernel) instead of one lane; EAZ_SUBLEQ_WAVE=0 keeps the per-lane kernel
+static int g_subleq_wave = [] { const char* e = std::getenv("EAZ_SUBLEQ_WAVE"); return e ? std::atoi(e) : 1; }();
 static int subleq_lds_bytes(int W) { return W == 16 ? 0 : 2 * 64 * W; }
 
 static int env_step_launch(eaz_env* env, int B, const void* in, const int32_t* action, Key key, int mode, void* out,
@@ -273,10 +275,15 @@ static int env_step_launch(eaz_env* env, int B, const void* in, const int32_t* a
             LAUNCH_OK();
         }
     } else if (env->dev.kind == EAZ_ENV_SUBLEQ) {
-        const int epw = subleq_envs_per_wg(B);
-        subleq_step_kernel<<<cdiv(B, epw), 64, subleq_lds_bytes(env->dev.W), st>>>(env->dev, src, dst, action, B, mode, key, d_key,
-                                                                                  static_cast<char*>(out_copy), mover_reward, nullptr, nullptr,
-                                                                                  epw, 256, nullptr);
+        if (env->dev.W == 16 && g_subleq_wave) {
+            subleq16_wave_kernel<<<B, 64, 0, st>>>(env->dev, src, dst, action, B, mode, key, d_key, static_cast<char*>(out_copy), mover_reward,
+                                                   nullptr, nullptr, 256, nullptr);
+        } else {
+            const int epw = subleq_envs_per_wg(B);
+            subleq_step_kernel<<<cdiv(B, epw), 64, subleq_lds_bytes(env->dev.W), st>>>(env->dev, src, dst, action, B, mode, key, d_key,
+                                                                                      static_cast<char*>(out_copy), mover_reward, nullptr, nullptr,
+                                                                                      epw, 256, nullptr);
+        }
         LAUNCH_OK();
     } else {
         connect4_step_kernel<<<cdiv(B, 256), 256, 0, st>>>(env->dev, src, dst, action, B, mode, key, d_key, mover_reward, nullptr, nullptr);
@@ -1100,10 +1107,14 @@ static int recurrent_launch(eaz_search* s, hipStream_t st) {
             const int epw = subleq_envs_per_wg(B);
             // word_size 16 + binary encoding: the step kernel also writes the observation row (no obs_emit launch)
             const bool fused_obs = g_fused_leaf && env->dev.W == 16 && env->dev.binary && env->dev.obs_dim == 240;
-            subleq_step_kernel<<<cdiv(B, epw), 64, subleq_lds_bytes(env->dev.W), st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0},
-                                                                                      nullptr, nullptr, s->d_next_reward, s->d_next_term,
-                                                                                      s->d_next_legal, epw, (env->dev.W + 15) & ~15,
-                                                                                      fused_obs ? s->d_obs : nullptr);
+            if (env->dev.W == 16 && g_subleq_wave)
+                subleq16_wave_kernel<<<B, 64, 0, st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0}, nullptr, nullptr, s->d_next_reward,
+                                                       s->d_next_term, s->d_next_legal, 16, fused_obs ? s->d_obs : nullptr);
+            else
+                subleq_step_kernel<<<cdiv(B, epw), 64, subleq_lds_bytes(env->dev.W), st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0},
+                                                                                          nullptr, nullptr, s->d_next_reward, s->d_next_term,
+                                                                                          s->d_next_legal, epw, (env->dev.W + 15) & ~15,
+                                                                                          fused_obs ? s->d_obs : nullptr);
             LAUNCH_OK();
             if (!fused_obs) {
                 obs_emit_kernel<<<cdiv(static_cast<long>(B) * 64, 256), 256, 0, st>>>(env->dev, dst, B, s->d_obs);

@@ -163,8 +163,7 @@ __global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src,
             }
             bool correct;
             if (W == 16) {
-                MemReg16 mem{prog16, 0ull};
-                correct = subleq_simulate(W, mem, tin, tout, outv);
+                correct = subleq_simulate16(prog16, tin, tout, outv);
             } else {
                 MemLds mem{lmem + static_cast<long>(el) * W, lmem + static_cast<long>(64 + el) * W, W};
                 if (do_init) { for (int i = 0; i < W; i += 4) *reinterpret_cast<uint32_t*>(mem.m + i) = 0u; }
@@ -263,6 +262,228 @@ __global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src,
         uint4* dst = reinterpret_cast<uint4*>(obs_out + static_cast<long>(b) * 240);
 #pragma unroll
         for (int i = 0; i < 15; ++i) dst[i] = make_uint4(ow[4 * i], ow[4 * i + 1], ow[4 * i + 2], ow[4 * i + 3]);
+    }
+}
+
+// ---- Subleq, word_size 16: one wavefront per environment -----------------------------------------------------------------
+// A launch of the per-lane kernel above lasts as long as the slowest interpreter run in the batch, a few programs in every
+// thousand run all 200 cycles, and a VALU cycle body costs ~450 clocks of a lone wavefront.  Here the machine state of ONE
+// environment lives in scalar registers (cursor, counters, flags) and in the lanes of three VGPRs (lane l of `vmem` = program word l,
+// lanes 0..7 of `vin` / `vout` = the IO buffers): an operand fetch is a v_readlane, the write-back a compare-and-select on the lane id, everything else
+// SALU, the branches are real (no divergence: one program per wavefront), and the memory comparison of the periodicity test is one
+// v_cmp.  Results are bit-identical to subleq_simulate (same test suite); the state / observation stores use the 64 lanes.
+__device__ __forceinline__ int sq_rl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+// subleq.py:297-398 `simulate` for one environment per wavefront.  vmem: lane l < 16 = word l (< 16).  vin / vtout: lane l = input l /
+// expected output l, W in every lane beyond the valid ones.  Returns `correct`; v_in_after / v_out: lanes 0..7 = input_after /
+// output_after.  The inner loop runs the cycles that touch memory words only (both operand addresses <= ADDRESS_MAX, cursor in
+// bounds): nothing of the IO state moves there, `all_eq` (:341) included, so halting is folded into the cycle increment `inc`.
+// Brent snapshots (iterations 1, 2, 4, ...; any growing schedule is exact) hold the memory in `vsnap` and the cursor in `s_cur`; an
+// IO event invalidates the snapshot (the input cursor and the output only move forward, so the state before it cannot recur).
+__device__ __forceinline__ bool subleq16_wave_run(int vmem, const int vin, const int vtout, const int lane, int& v_in_after, int& v_out) {
+    constexpr int W = 16, AMAX = 12, AIN = 13, AOUT = 14, kStop = 1000;
+    int vout = W, vsnap = -1;
+    int cur = 0, cycles = 0, in_cur = 0, out_cursor = 0;
+    int s_cur = -1, s_cycle = 0, it = 0, next_snap = 1;
+    int error = 0;
+    int inc = (__builtin_amdgcn_ballot_w64(vout == vtout) & 0xFFull) == 0xFFull ? kStop : 1;  // :341 halts
+    // end of a cycle (:297-299 MAX_CYCLE_COUNT = 200): count it, close a period (state == snapshot => periodic with period
+    // cycles - s_cycle; whole periods are skipped), snapshot
+    auto cycle_end = [&]() {
+        cycles += inc;
+        it += 1;
+        if (cur == s_cur) {
+            if (cycles < 200 && (__builtin_amdgcn_ballot_w64(vmem == vsnap) & 0xFFFFull) == 0xFFFFull) {
+                const int p = cycles - s_cycle;
+                cycles += ((200 - cycles) / p) * p;
+            }
+        }
+        if (it == next_snap) {
+            vsnap = vmem; s_cur = cur; s_cycle = cycles;
+            next_snap *= 2;
+        }
+    };
+    for (;;) {
+        int a = 0, b = 0, c = 0;
+        bool oob;
+        for (;;) {
+            oob = cur >= W - 2;  // :364-370
+            if (oob) break;
+            a = sq_rl(vmem, cur); b = sq_rl(vmem, cur + 1); c = sq_rl(vmem, cur + 2);
+            if (max(a, b) > AMAX) break;
+            const int v = (sq_rl(vmem, a) - sq_rl(vmem, b)) & 15;  // :322
+            vmem = lane == a ? v : vmem;
+            cur = static_cast<unsigned>(v - 1) >= 7u ? c : cur + 3;  // :329-330 jump when value == 0 or 2 * value >= 16
+            cycle_end();
+            if (cycles >= 200) break;
+        }
+        if (cycles >= 200) break;
+        if (oob) { error = 1; break; }  // nothing else changes
+        // ---- a cycle that names IN, OUT or word 15 ------------------------------------------------------------------
+        // read_memory :187-232 (both reads see the pre-advance input state; the input cursor stands for the rolled array :333-338)
+        const int in0 = sq_rl(vin, in_cur);
+        const bool in_ok = in0 < W;
+        int ra = 0, rb = 0;
+        if (a <= AMAX) ra = sq_rl(vmem, a); else if (a == AIN && in_ok) ra = in0;
+        if (b <= AMAX) rb = sq_rl(vmem, b); else if (b == AIN && in_ok) rb = in0;
+        const int v = (ra - rb) & 15;
+        const bool uses_in = a == AIN || b == AIN;
+        if (uses_in) {
+            if (in_ok) { in_cur += 1; s_cur = -1; }
+            else error = 1;
+        }
+        // write_memory :243-295
+        if (a == AOUT) {
+            if (out_cursor >= 8) error = 1;
+            else {
+                vout = lane == out_cursor ? v : vout;
+                if (v != sq_rl(vtout, out_cursor)) error = 1;  // :346-350
+                out_cursor += 1;
+                s_cur = -1;
+                if ((__builtin_amdgcn_ballot_w64(vout == vtout) & 0xFFull) == 0xFFull) inc = kStop;
+            }
+        } else if (a <= AMAX) {
+            vmem = lane == a ? v : vmem;
+        }
+        cur = static_cast<unsigned>(v - 1) >= 7u ? c : cur + 3;
+        if (error) break;
+        cycle_end();
+        if (cycles >= 200) break;
+    }
+    v_in_after = __shfl(vin, (lane + in_cur) & 63);  // lanes 0..7 read lanes <= 15, all W beyond the inputs
+    v_out = vout;
+    return error == 0 && (__builtin_amdgcn_ballot_w64(vout == vtout) & 0xFFull) == 0xFFull;
+}
+
+// Same contract as subleq_step_kernel (word_size 16 only); grid = B workgroups of one wavefront.
+__global__ void __launch_bounds__(64) subleq16_wave_kernel(EnvDev e, StateRef src, StateRef dst, const int32_t* action, int B, int mode,
+                                                           Key key_arg, const Key* key_ptr, char* out_copy, float* next_reward,
+                                                           uint8_t* next_term, uint8_t* next_legal, int mem_copy, uint8_t* obs_out) {
+    constexpr int W = 16;
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const char* sp = state_ptr(src, b, e.state_bytes);
+    char* dp = state_ptr(dst, b, e.state_bytes);
+    const bool copy_mem = reinterpret_cast<const void*>(sp) != reinterpret_cast<const void*>(dp);
+    // ---- the source state, lane-distributed: header (uniform), IO rows (lanes 0..7), memory bytes (lanes 0..15) and the
+    //      16-byte memory chunks (lane l = bytes 16 l ..) for the copies
+    int h_step = 0, h_task = 0, h_flags = 0;
+    int s_exin = W, s_exinaf = W, s_exout = W, s_exoutaf = W, mem_raw = 0;
+    uint4 chunk = make_uint4(0, 0, 0, 0);
+    if (mode != 2) {
+        const int4 hv = *reinterpret_cast<const int4*>(sp);
+        h_step = __builtin_amdgcn_readfirstlane(hv.x);
+        h_task = __builtin_amdgcn_readfirstlane(hv.y);
+        h_flags = __builtin_amdgcn_readfirstlane(hv.w);
+        const uint16_t* io = reinterpret_cast<const uint16_t*>(sp + 16);
+        if (lane < 8) { s_exin = io[lane]; s_exinaf = io[8 + lane]; s_exout = io[16 + lane]; s_exoutaf = io[24 + lane]; }
+        if (lane < W) mem_raw = reinterpret_cast<const uint8_t*>(sp + 80)[lane];
+        if (16 * lane < mem_copy) chunk = *reinterpret_cast<const uint4*>(sp + 80 + 16 * lane);
+    }
+    const int s_term = h_flags & 0xFF, s_trunc = (h_flags >> 8) & 0xFF, s_solved = (h_flags >> 16) & 0xFF;
+    // ---- decide what this environment does (pgx wrapper A.1, auto_reset selfplay.py:66-71, _step subleq.py:671-677)
+    bool do_init = false, finish = false, run = false;
+    int step_count = 0, task = 0, act = 0;
+    {
+        const bool done = mode != 2 && (s_term | s_trunc) != 0;
+        do_init = mode == 2 || (mode == 1 && done);
+        if (do_init) {
+            const Key key = key_ptr ? *key_ptr : key_arg;
+            const Key kb = fold(key, static_cast<uint32_t>(b));
+            const Key ki = mode == 2 ? kb : fold(kb, 1u);
+            const int idx = e.n_tasks > 1 ? static_cast<int>(rbits(ki, 0) % static_cast<uint32_t>(e.n_tasks)) : 0;  // subleq.py:624
+            task = e.tasks[idx];
+            step_count = 0;
+            run = true;
+        } else if (done) {
+            task = h_task; step_count = h_step;  // same state, zero rewards
+        } else {
+            task = h_task;
+            step_count = h_step + 1;
+            act = __builtin_amdgcn_readfirstlane(action[b]);
+            if (step_count >= W - 3 || s_solved) finish = true;  // subleq.py:671-673
+            else run = true;
+        }
+    }
+    task = __builtin_amdgcn_readfirstlane(task);
+    // ---- the new program: the action is word step_count - 1 (subleq.py:654); an initial state is all zeros
+    const int idx = step_count - 1;
+    if (do_init) { mem_raw = 0; chunk = make_uint4(0, 0, 0, 0); }
+    const bool patch = run && !do_init && idx >= 0 && idx < W;
+    if (patch) {
+        const int a8 = act & 0xFF;
+        if (lane == idx) mem_raw = a8;
+        if (lane == 0) {
+            const int sh = 8 * (idx & 3);
+            uint32_t w = (idx >> 2) == 0 ? chunk.x : (idx >> 2) == 1 ? chunk.y : (idx >> 2) == 2 ? chunk.z : chunk.w;
+            w = (w & ~(0xFFu << sh)) | (static_cast<uint32_t>(a8) << sh);
+            if ((idx >> 2) == 0) chunk.x = w; else if ((idx >> 2) == 1) chunk.y = w; else if ((idx >> 2) == 2) chunk.z = w; else chunk.w = w;
+        }
+    }
+    int n_exin = s_exin, n_exinaf = s_exinaf, n_exout = s_exout, n_exoutaf = s_exoutaf;
+    bool all_correct = false;
+    if (run) {
+        all_correct = true;
+        const int vmem = lane < W ? (mem_raw & 15) : 0;
+        for (int c = 0; c < 3 && all_correct; ++c) {  // subleq.py:511 vmap; `solved` is the AND (:525), only case 0 feeds the state
+            uint16_t tin[8], tout[8];
+            subleq_test_case(task, c, W, tin, tout);
+            int vin = W, vtout = W;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { vin = lane == i ? tin[i] : vin; vtout = lane == i ? tout[i] : vtout; }
+            int v_after, v_out;
+            const bool correct = subleq16_wave_run(vmem, vin, vtout, lane, v_after, v_out);
+            if (c == 0) { n_exin = vin; n_exout = vtout; n_exinaf = v_after; n_exoutaf = v_out; }
+            all_correct = correct;
+        }
+    }
+    // ---- assemble the new state --------------------------------------------------------------------------------
+    float reward;
+    int terminated, solved;
+    if (run) {
+        solved = all_correct ? 1 : 0;                  // subleq.py:525
+        reward = solved ? 1.0f : 0.0f;                 // :535-537
+        terminated = do_init ? 0 : s_term;             // _step never sets terminated on this branch (:661-669)
+    } else {
+        solved = s_solved;
+        reward = 0.0f;                                 // terminal no-op (A.1) or subleq.py:673
+        terminated = finish ? 1 : s_term;
+    }
+    const int truncated = do_init ? 0 : s_trunc;
+    const uint4 header = make_uint4(static_cast<uint32_t>(step_count), static_cast<uint32_t>(task), __builtin_bit_cast(uint32_t, reward),
+                                    static_cast<uint32_t>(terminated) | (static_cast<uint32_t>(truncated) << 8) | (static_cast<uint32_t>(solved) << 16));
+    auto emit = [&](char* base, bool io_rows, bool mem_chunks, bool mem_byte) {
+        if (lane == 0) *reinterpret_cast<uint4*>(base) = header;
+        if (io_rows && lane < 8) {
+            uint16_t* io = reinterpret_cast<uint16_t*>(base + 16);
+            io[lane] = static_cast<uint16_t>(n_exin); io[8 + lane] = static_cast<uint16_t>(n_exinaf);
+            io[16 + lane] = static_cast<uint16_t>(n_exout); io[24 + lane] = static_cast<uint16_t>(n_exoutaf);
+        }
+        if (mem_chunks) { if (16 * lane < (do_init ? 256 : mem_copy)) *reinterpret_cast<uint4*>(base + 80 + 16 * lane) = chunk; }
+        else if (mem_byte && lane == idx) reinterpret_cast<uint8_t*>(base + 80)[idx] = static_cast<uint8_t>(mem_raw);
+    };
+    // in place: only what changed; another slot: everything the caller asked to be copied
+    emit(dp, run || copy_mem, copy_mem || do_init, patch);
+    if (out_copy) emit(out_copy + static_cast<long>(b) * sizeof(eaz_subleq_state), true, true, false);
+    if (lane == 0) {
+        if (next_reward) next_reward[b] = reward;
+        if (next_term) next_term[b] = static_cast<uint8_t>(terminated);
+        if (next_legal) *reinterpret_cast<uint4*>(next_legal + static_cast<long>(b) * 16) = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);  // all legal (subleq.py:626)
+    }
+    if (obs_out) {
+        // binary encoding: the 48 x 5 observation (subleq.py:679-707 rows = memory | input | input_after | output | output_after;
+        // :88-98 columns = 4 little-endian bits of v mod 16, then v == 16); lane w < 48 holds row-word w and stores its 5 bytes
+        const int src_lane = lane & 7;
+        const int r0 = __shfl(n_exin, src_lane), r1 = __shfl(n_exinaf, src_lane), r2 = __shfl(n_exout, src_lane), r3 = __shfl(n_exoutaf, src_lane);
+        const int row = (lane - 16) >> 3;
+        const uint32_t v = lane < 16 ? static_cast<uint32_t>(mem_raw) : (row == 0 ? r0 : row == 1 ? r1 : row == 2 ? r2 : r3) & 0xFFFFu;
+        if (lane < 48) {
+            uint8_t* o = obs_out + static_cast<long>(b) * 240 + 5 * lane;
+            const uint32_t m = v & 15u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = static_cast<uint8_t>((m >> j) & 1u);
+            o[4] = static_cast<uint8_t>(v == 16u);
+        }
     }
 }
 
