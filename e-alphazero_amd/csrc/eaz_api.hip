@@ -256,9 +256,7 @@ static int subleq_envs_per_wg(int B) {
     while (epw > 8 && cdiv(B, epw) < 256) epw /= 2;
     return epw;
 }
-// word_size 16: one wavefront per environment (subleq16_wave_kernel) instead of one lane; EAZ_SUBLEQ_WAVE=0 keeps the per-lane kernel
-static int g_subleq_wave = [] { const char* e = std::getenv("EAZ_SUBLEQ_WAVE"); return e ? std::atoi(e) : 1; }();
-static int subleq_lds_bytes(int W) { return W == 16 ? 0 : 2 * 64 * W; }
+static int subleq_lds_bytes(int W) { return 2 * 64 * W; }
 
 static int env_step_launch(eaz_env* env, int B, const void* in, const int32_t* action, Key key, int mode, void* out,
                            void* out_copy, hipStream_t st, const Key* d_key = nullptr, float* mover_reward = nullptr) {
@@ -275,14 +273,14 @@ static int env_step_launch(eaz_env* env, int B, const void* in, const int32_t* a
             LAUNCH_OK();
         }
     } else if (env->dev.kind == EAZ_ENV_SUBLEQ) {
-        if (env->dev.W == 16 && g_subleq_wave) {
+        if (env->dev.W == 16) {  // one wavefront per environment
             subleq16_wave_kernel<<<B, 64, 0, st>>>(env->dev, src, dst, action, B, mode, key, d_key, static_cast<char*>(out_copy), mover_reward,
-                                                   nullptr, nullptr, 256, nullptr);
+                                                   nullptr, nullptr, 256, nullptr, NoveltyFuse{nullptr, nullptr, 0, 0.0f});
         } else {
             const int epw = subleq_envs_per_wg(B);
             subleq_step_kernel<<<cdiv(B, epw), 64, subleq_lds_bytes(env->dev.W), st>>>(env->dev, src, dst, action, B, mode, key, d_key,
                                                                                       static_cast<char*>(out_copy), mover_reward, nullptr, nullptr,
-                                                                                      epw, 256, nullptr);
+                                                                                      epw, 256);
         }
         LAUNCH_OK();
     } else {
@@ -1052,8 +1050,13 @@ static int tree_step_launch(eaz_search* s, int sim, int mode, hipStream_t st) {
 // forward.apply on a batch of observations: the novelty lookup (hash_kernel, 4 lanes per sample, ~64 workgroups) and the
 // MFMA forward (hundreds of workgroups) are independent, so the lookup is forked onto the search's side stream and joined
 // before the consumer of both (tree expand / root preparation applies ube_combine).
-static int infer_launch(eaz_search* s, const uint8_t* obs, float* novelty, const NetOut& o, const HeadList& hl, hipStream_t st) {
+static int infer_launch(eaz_search* s, const uint8_t* obs, float* novelty, const NetOut& o, const HeadList& hl, hipStream_t st,
+                        bool novelty_done = false) {
     const int B = s->B;
+    if (novelty_done) {  // the env-step kernel already looked the observations up
+        ProfScope ps(s, EAZ_K_NET, st);
+        return fc_launch(s->net, B, obs, o, hl, st);
+    }
     hipStream_t hs = st;
     if (s->side) {
         HIP_OK(hipEventRecord(s->ev_fork, st));
@@ -1086,6 +1089,7 @@ static int recurrent_launch(eaz_search* s, hipStream_t st) {
         ProfScope ps(s, EAZ_K_NET, st);
         return fc_onehot_launch(s->net, B, s->d_leaf_hot, s->d_novelty, o, hl, st);
     }
+    bool novelty_done = false;
     {
         ProfScope ps(s, EAZ_K_GATHER, st);
         if (env->dev.kind == EAZ_ENV_DEEPSEA) {
@@ -1107,14 +1111,17 @@ static int recurrent_launch(eaz_search* s, hipStream_t st) {
             const int epw = subleq_envs_per_wg(B);
             // word_size 16 + binary encoding: the step kernel also writes the observation row (no obs_emit launch)
             const bool fused_obs = g_fused_leaf && env->dev.W == 16 && env->dev.binary && env->dev.obs_dim == 240;
-            if (env->dev.W == 16 && g_subleq_wave)
+            // ... and, for the XXHash variant over the IO rows (the FCNet default, fully_connected.py:85-87), the novelty lookup
+            const NetDev& nd = s->net->dev;
+            novelty_done = fused_obs && !nd.sim_matrix && nd.hash_off == 80 && nd.hash_len == 160 && nd.in_dim == 240;
+            if (env->dev.W == 16)
                 subleq16_wave_kernel<<<B, 64, 0, st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0}, nullptr, nullptr, s->d_next_reward,
-                                                       s->d_next_term, s->d_next_legal, 16, fused_obs ? s->d_obs : nullptr);
+                                                       s->d_next_term, s->d_next_legal, 16, fused_obs ? s->d_obs : nullptr,
+                                                       NoveltyFuse{nd.bitset, novelty_done ? s->d_novelty : nullptr, nd.hash_bits, nd.nov_scale});
             else
                 subleq_step_kernel<<<cdiv(B, epw), 64, subleq_lds_bytes(env->dev.W), st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0},
                                                                                           nullptr, nullptr, s->d_next_reward, s->d_next_term,
-                                                                                          s->d_next_legal, epw, (env->dev.W + 15) & ~15,
-                                                                                          fused_obs ? s->d_obs : nullptr);
+                                                                                          s->d_next_legal, epw, (env->dev.W + 15) & ~15);
             LAUNCH_OK();
             if (!fused_obs) {
                 obs_emit_kernel<<<cdiv(static_cast<long>(B) * 64, 256), 256, 0, st>>>(env->dev, dst, B, s->d_obs);
@@ -1122,7 +1129,7 @@ static int recurrent_launch(eaz_search* s, hipStream_t st) {
             }
         }
     }
-    return infer_launch(s, s->d_obs, s->d_novelty, o, hl, st);
+    return infer_launch(s, s->d_obs, s->d_novelty, o, hl, st, novelty_done);
 }
 
 extern "C" int eaz_search_simulate(eaz_search* s, int sim, void* stream) {

@@ -90,23 +90,23 @@ __global__ void __launch_bounds__(256) leaf_gather_deepsea_kernel(EnvDev e, Tree
     }
 }
 
-// ---- Subleq -----------------------------------------------------------------------------------------------------
+// ---- Subleq, word sizes other than 16 ------------------------------------------------------------------------------
 // One lane per environment, `envs_per_wg` (<= 64) environments per one-wavefront workgroup: the kernel's duration is the
 // longest interpreter run of a wavefront, so the environments are spread over as many wavefronts / CUs as the launch has room
 // for (eaz_api.hip).  The three test cases (subleq.py:511 vmap) run one after the other and stop at the first failing one:
 // `solved` is the AND of the three results (:525) and only test case 0 feeds the state (`input_after` / `output_after`,
 // :526-533), so a failed case makes the rest irrelevant -- exact, and two thirds of the interpreter work for the typical
 // (unsolved) program.  Each run is <= 200 cycles (subleq.py:19,297-299) with an exact early exit for programs that have entered
-// a cycle (subleq_simulate).  word_size 16 keeps the program memory in one 64-bit register; other sizes use 2*W bytes of LDS per
+// a cycle (subleq_simulate).  The program memory and its snapshot take 2*W bytes of LDS per
 // lane.  mode as deepsea_step_kernel.  src/dst may alias (in-place real step) or be tree embedding slots (leaf gather).
 // mem_copy: bytes of `memory` copied from src to dst when they differ (256, or W rounded up to 16 when the bytes above W of
 // every dst slot are known to be zero: tree embeddings).
 __global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src, StateRef dst, const int32_t* action, int B,
                                                          int mode, Key key_arg, const Key* key_ptr, char* out_copy,
                                                          float* next_reward, uint8_t* next_term, uint8_t* next_legal,
-                                                         int envs_per_wg, int mem_copy, uint8_t* obs_out) {
+                                                         int envs_per_wg, int mem_copy) {
     const Key key = key_ptr ? *key_ptr : key_arg;  // device-resident key: lets a captured hipGraph serve every real step
-    extern __shared__ __attribute__((aligned(16))) uint8_t lmem[];  // word_size != 16: 2 * 64 * W (working memory + snapshot)
+    extern __shared__ __attribute__((aligned(16))) uint8_t lmem[];  // 2 * 64 * W (working memory + snapshot)
     const int W = e.W;
     const int el = threadIdx.x;
     const int b = blockIdx.x * envs_per_wg + el;
@@ -143,17 +143,6 @@ __global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src,
     bool all_correct = false;
     if (run) {
         const int idx = step_count - 1;  // subleq.py:654
-        unsigned long long prog16 = 0;   // word_size 16: the program as sixteen nibbles
-        if (W == 16) {
-            if (!do_init) {
-                const uint4 mv = *reinterpret_cast<const uint4*>(sp->memory);
-                const uint32_t wsrc[4] = {mv.x, mv.y, mv.z, mv.w};
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    prog16 |= static_cast<unsigned long long>((wsrc[i >> 2] >> (8 * (i & 3))) & 15u) << (4 * i);
-                if (idx >= 0 && idx < W) prog16 = (prog16 & ~(15ull << (4 * idx))) | (static_cast<unsigned long long>(act & 15) << (4 * idx));
-            }
-        }
         all_correct = true;
         for (int c = 0; c < 3 && all_correct; ++c) {
             subleq_test_case(task, c, W, tin, tout);
@@ -161,18 +150,13 @@ __global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src,
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { ex_in[i] = tin[i]; ex_out[i] = tout[i]; }
             }
-            bool correct;
-            if (W == 16) {
-                correct = subleq_simulate16(prog16, tin, tout, outv);
-            } else {
-                MemLds mem{lmem + static_cast<long>(el) * W, lmem + static_cast<long>(64 + el) * W, W};
-                if (do_init) { for (int i = 0; i < W; i += 4) *reinterpret_cast<uint32_t*>(mem.m + i) = 0u; }
-                else {
-                    for (int i = 0; i < W; i += 4) *reinterpret_cast<uint32_t*>(mem.m + i) = *reinterpret_cast<const uint32_t*>(sp->memory + i);
-                    if (idx >= 0 && idx < W) mem.m[idx] = static_cast<uint8_t>(act);
-                }
-                correct = subleq_simulate(W, mem, tin, tout, outv);
+            MemLds mem{lmem + static_cast<long>(el) * W, lmem + static_cast<long>(64 + el) * W, W};
+            if (do_init) { for (int i = 0; i < W; i += 4) *reinterpret_cast<uint32_t*>(mem.m + i) = 0u; }
+            else {
+                for (int i = 0; i < W; i += 4) *reinterpret_cast<uint32_t*>(mem.m + i) = *reinterpret_cast<const uint32_t*>(sp->memory + i);
+                if (idx >= 0 && idx < W) mem.m[idx] = static_cast<uint8_t>(act);
             }
+            const bool correct = subleq_simulate(W, mem, tin, tout, outv);
             if (c == 0) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { in_after[i] = tin[i]; out_after[i] = outv[i]; }
@@ -235,34 +219,6 @@ __global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src,
     if (next_term) next_term[b] = terminated;
     if (next_legal)
         for (int a = 0; a < e.A; ++a) next_legal[static_cast<long>(b) * e.A + a] = 1;  // all legal (subleq.py:626)
-    if (obs_out) {
-        // word_size 16, binary encoding only (the host passes null otherwise): the 48 x 5 observation (subleq.py:679-707 rows =
-        // memory | input | input_after | output | output_after; :88-98 columns = 4 little-endian bits of v mod 16, then v == 16)
-        // of the state just written, assembled in registers and stored as 15 x 16 bytes -- saves the obs_emit launch per simulation
-        const uint4 mv = *reinterpret_cast<const uint4*>(dp->memory);
-        const uint4* iov = reinterpret_cast<const uint4*>(dp->ex_in);  // ex_in, ex_in_after, ex_out, ex_out_after: 4 x 8 u16
-        const uint32_t mw[4] = {mv.x, mv.y, mv.z, mv.w};
-        uint32_t iw[16];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const uint4 v = iov[i]; iw[4 * i] = v.x; iw[4 * i + 1] = v.y; iw[4 * i + 2] = v.z; iw[4 * i + 3] = v.w; }
-        uint32_t ow[60];
-#pragma unroll
-        for (int i = 0; i < 60; ++i) ow[i] = 0u;
-#pragma unroll
-        for (int w = 0; w < 48; ++w) {
-            const uint32_t v = w < 16 ? (mw[w >> 2] >> (8 * (w & 3))) & 0xFFu : (iw[(w - 16) >> 1] >> (16 * ((w - 16) & 1))) & 0xFFFFu;
-            const uint32_t m = v & 15u;  // v mod 16 (v <= 16)
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const uint32_t byte = j < 4 ? (m >> j) & 1u : static_cast<uint32_t>(v == 16u);
-                const int p = 5 * w + j;
-                ow[p >> 2] |= byte << (8 * (p & 3));
-            }
-        }
-        uint4* dst = reinterpret_cast<uint4*>(obs_out + static_cast<long>(b) * 240);
-#pragma unroll
-        for (int i = 0; i < 15; ++i) dst[i] = make_uint4(ow[4 * i], ow[4 * i + 1], ow[4 * i + 2], ow[4 * i + 3]);
-    }
 }
 
 // ---- Subleq, word_size 16: one wavefront per environment -----------------------------------------------------------------
@@ -355,10 +311,20 @@ __device__ __forceinline__ bool subleq16_wave_run(int vmem, const int vin, const
     return error == 0 && (__builtin_amdgcn_ballot_w64(vout == vtout) & 0xFFull) == 0xFFull;
 }
 
+// Novelty lookup of the observation this kernel writes (obs_out != null, XXHash variant over the IO rows = bytes 80..239): saves the
+// hash_kernel launch of a simulation.  novelty == nullptr: no lookup.
+struct NoveltyFuse {
+    const uint8_t* bitset;
+    float* novelty;
+    int hash_bits;
+    float nov_scale;
+};
+
 // Same contract as subleq_step_kernel (word_size 16 only); grid = B workgroups of one wavefront.
 __global__ void __launch_bounds__(64) subleq16_wave_kernel(EnvDev e, StateRef src, StateRef dst, const int32_t* action, int B, int mode,
                                                            Key key_arg, const Key* key_ptr, char* out_copy, float* next_reward,
-                                                           uint8_t* next_term, uint8_t* next_legal, int mem_copy, uint8_t* obs_out) {
+                                                           uint8_t* next_term, uint8_t* next_legal, int mem_copy, uint8_t* obs_out,
+                                                           NoveltyFuse nf) {
     constexpr int W = 16;
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
@@ -483,6 +449,35 @@ __global__ void __launch_bounds__(64) subleq16_wave_kernel(EnvDev e, StateRef sr
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = static_cast<uint8_t>((m >> j) & 1u);
             o[4] = static_cast<uint8_t>(v == 16u);
+        }
+        if (nf.novelty) {
+            // XXHash-variant novelty of the same observation (hashes.py:162-229 over bytes 80..239 = the four IO rows, fully_connected.py:85-87):
+            // hash lane i = stripe i = IO row i = 8 words x 5 bytes, every byte 0 or 1, i.e. astype(f32) bits 0 or 0x3F800000 (:207)
+            const uint32_t P1 = 0x9E3779B1u, P2 = 0x85EBCA77u, P3 = 0xC2B2AE3Du, SEED = 1u, ONE = 0x3F800000u * P2;
+            const int i = lane & 3;
+            uint32_t acc = i == 0 ? SEED + P1 + P2 : (i == 1 ? SEED + P2 : (i == 2 ? SEED : SEED - P1));  // :217-220
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const uint32_t x = static_cast<uint32_t>(__shfl(static_cast<int>(v), 16 + 8 * i + w));
+                const uint32_t m = x & 15u;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const bool one = j < 4 ? ((m >> j) & 1u) != 0 : x == 16u;
+                    const uint32_t t = acc + (one ? ONE : 0u);
+                    acc = ((t << 13) | (t >> 19)) * P1;  // :176-181
+                }
+            }
+            const int rot = i == 0 ? 1 : (i == 1 ? 7 : (i == 2 ? 12 : 18));  // :184-187
+            uint32_t h = (acc << rot) | (acc >> (32 - rot));
+            h += __shfl_xor(h, 1);
+            h += __shfl_xor(h, 2);
+            h += 40u;  // :226 (stripe count)
+            h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;  // :190-197
+            const uint32_t index = h >> (32 - nf.hash_bits);             // :229
+            if (lane == 0) {
+                const bool seen = nf.bitset ? ((nf.bitset[index >> 3] >> (index & 7u)) & 1u) != 0 : false;  // hashes.py:29-38
+                nf.novelty[b] = (seen ? 0.0f : 1.0f) * nf.nov_scale;                                        // fully_connected.py:90
+            }
         }
     }
 }

@@ -169,9 +169,8 @@ __device__ __forceinline__ void unpack8(const Pack8& p, uint16_t v[8]) {
 }
 __device__ __forceinline__ bool pack8_eq(const Pack8& a, const Pack8& b) { return a.lo == b.lo && a.hi == b.hi; }
 
-// Program memory of one interpreter run.  MemLds: W bytes in LDS + W bytes for the periodicity snapshot (any word size).
-// MemReg16: word_size 16 -- every word is < 16, so the whole memory is sixteen nibbles of ONE 64-bit register (no LDS round
-// trips on the interpreter's critical path; the reference's experiments use word_size 16, slurm_experiment_submitter.py:196).
+// Program memory of one interpreter run: W bytes in LDS + W bytes for the periodicity snapshot (any word size; word_size 16, the
+// size of the reference's experiments (slurm_experiment_submitter.py:196), has its own kernel: subleq16_wave_kernel).
 struct MemLds {
     uint8_t* m;
     uint8_t* snap;
@@ -187,17 +186,6 @@ struct MemLds {
         for (int i = 0; i < W && eq; i += 4) eq = *reinterpret_cast<const uint32_t*>(m + i) == *reinterpret_cast<const uint32_t*>(snap + i);
         return eq;
     }
-};
-struct MemReg16 {
-    unsigned long long m, s;
-    __device__ __forceinline__ int get(int i) const { return static_cast<int>((m >> (4 * i)) & 15ull); }
-    static constexpr bool kWordsInRange = true;  // nibbles
-    __device__ __forceinline__ void set_if(bool cond, int i, int v) {
-        const unsigned long long n = (m & ~(15ull << (4 * i))) | (static_cast<unsigned long long>(v) << (4 * i));
-        m = cond ? n : m;
-    }
-    __device__ __forceinline__ void snapshot() { s = m; }
-    __device__ __forceinline__ bool same() const { return s == m; }
 };
 
 // subleq.py:297-398 `simulate`.
@@ -304,117 +292,6 @@ __device__ __forceinline__ bool subleq_simulate(int W, Mem& mem, uint16_t in_arr
     unpack8(in, in_arr);
     unpack8(out, out_arr);
     return !error && pack8_eq(out, tout);
-}
-
-// word_size 16 form of subleq_simulate (same result, bit for bit; tests/test_gpu_golden.py runs both against the literal loop).
-// A step kernel launch lasts as long as its slowest lane, and a few in every thousand programs run all 200 cycles (long counting
-// loops that Brent's snapshots cannot close in time), so the launch costs 200 x the latency of ONE interpreted cycle of one
-// wavefront: the cycle body is cut to the instructions the common cycle needs and the control flow is wavefront-uniform.
-//   * fast cycle (no live lane of the wavefront is out of bounds or names an address above ADDRESS_MAX in a or b): the three
-//     operands come from one shift of the program register, (ra - rb) mod 16 is a mask, the write is unconditional, and none
-//     of the IO state moves (`all_eq` included, so the halt test is folded into the per-lane cycle increment `inc`);
-//   * any other cycle leaves the inner loop for the general body (identical to subleq_simulate's), so the IO registers are
-//     loop invariant where the time goes;
-//   * a lane that halted, failed or reached 200 cycles is not masked off: its counter is >= 200, which keeps it out of the
-//     `special` vote, the skip and every IO update, and what it keeps "executing" is harmless (shifts are in range, only the
-//     program register and cursor move, and neither is read again); the loop ends when no lane is live;
-//   * Brent snapshots are taken on a wavefront-uniform schedule (iterations 1, 2, 4, ... of this loop) instead of per-lane
-//     cycle counts, so the test is a scalar compare; any growing schedule is exact, and so is skipping again after a skip.
-__device__ __forceinline__ bool subleq_simulate16(unsigned long long prog, uint16_t in_arr[8], const uint16_t tout_arr[8],
-                                                  uint16_t out_arr[8]) {
-    constexpr int W = 16, AMAX = 12, AIN = 13, AOUT = 14;
-    constexpr unsigned long long w4 = 0x0010001000100010ull;
-    constexpr int kStop = 1000;  // cycle increment of a lane that halted or failed: one compare covers every way to finish
-    Pack8 in = pack8(in_arr);
-    const Pack8 tout = pack8(tout_arr);
-    Pack8 out{w4, w4};
-    unsigned long long m = prog, s = 0ull;
-    uint32_t cur = 0, out_cursor = 0, io_epoch = 0, s_key = 0xFFFFFFFFu, error = 0;
-    int cycles = 0, s_cycle = 0;
-    int inc = pack8_eq(out, tout) ? kStop : 1;  // :341 `all(output == expected)` halts; it changes only in IO cycles
-    int it = 0, next_snap = 1;                   // wavefront-uniform
-    bool live = true;
-    // end of a cycle: count it, close a period, snapshot; false when no lane has cycles left
-    auto cycle_end = [&]() -> bool {
-        cycles += inc;
-        it += 1;
-        const uint32_t key = cur | (io_epoch << 8);
-        live = cycles < 200;
-        if (m == s && key == s_key && live) {  // state == snapshot: periodic with period cycles - s_cycle; skip whole periods
-            const int p = cycles - s_cycle;
-            cycles += ((200 - cycles) / p) * p;
-        }
-        if (it == next_snap) {
-            s = m; s_key = key; s_cycle = cycles;
-            next_snap *= 2;
-        }
-        return __builtin_amdgcn_ballot_w64(live) != 0;
-    };
-    for (;;) {
-        uint32_t a, b, c;
-        bool more = true;
-        for (;;) {
-            const uint32_t t = static_cast<uint32_t>(m >> ((4u * cur) & 63u));
-            a = t & 15u; b = (t >> 4) & 15u; c = (t >> 8) & 15u;
-            // cur + 2 >= W (:364-370)  <=>  cur - 1 > 12; one signed max covers it and both operand addresses
-            const int top = max(max(static_cast<int>(a), static_cast<int>(b)), static_cast<int>(cur) - 1);
-            if (__builtin_amdgcn_ballot_w64(top > AMAX && live) != 0) break;
-            const uint32_t sa = 4u * a, sb = 4u * b;
-            const uint32_t v = (static_cast<uint32_t>(m >> sa) - static_cast<uint32_t>(m >> sb)) & 15u;  // :322
-            m = (m & ~(15ull << sa)) | (static_cast<unsigned long long>(v) << sa);
-            cur = ((v - 1u) & 15u) >= 7u ? c : cur + 3u;  // :329-330 jump when value == 0 or 2 * value >= 16
-            // halt (:340-345): ({0,1} & c) > 12 never holds, `all_eq` is unchanged (it is part of `inc`)
-            more = cycle_end();
-            if (!more) break;
-        }
-        if (!more) break;
-        {
-            const bool oob = cur >= 14u, ok = !oob && live;
-            const bool a_mem = a <= static_cast<uint32_t>(AMAX), b_mem = b <= static_cast<uint32_t>(AMAX);
-            const int ma = static_cast<int>((m >> (4u * (a_mem ? a : 0u))) & 15ull);
-            const int mb = static_cast<int>((m >> (4u * (b_mem ? b : 0u))) & 15ull);
-            const bool uses_in = (a == AIN) || (b == AIN), wr_out = a == AOUT;
-            // read_memory :187-232 (both reads see the pre-advance input state)
-            const int in0 = static_cast<int>(in.lo & 0xFFFFu);
-            const bool in_ok = in0 < W;
-            const int ra = a_mem ? ma : ((a == AIN && in_ok) ? in0 : 0);
-            const int rb = b_mem ? mb : ((b == AIN && in_ok) ? in0 : 0);
-            const bool acc = ok && uses_in && in_ok;
-            const uint32_t v = static_cast<uint32_t>(ra - rb) & 15u;
-            // write_memory :243-295 (output port)
-            const bool out_full = out_cursor >= 8u;
-            bool err = (uses_in && !in_ok) || (wr_out && out_full);
-            const bool modified = ok && wr_out && !out_full;
-            const int sh = 16 * static_cast<int>(out_cursor & 3u);
-            const unsigned long long clr = ~(0xFFFFull << sh), ins = static_cast<unsigned long long>(v) << sh;
-            const unsigned long long olo = (out.lo & clr) | ins, ohi = (out.hi & clr) | ins;
-            out.lo = (modified && out_cursor < 4u) ? olo : out.lo;
-            out.hi = (modified && out_cursor >= 4u) ? ohi : out.hi;
-            out_cursor += modified ? 1u : 0u;
-            // :333-338 roll the input by one, pad with W
-            const unsigned long long ilo = (in.lo >> 16) | (in.hi << 48), ihi = (in.hi >> 16) | (static_cast<unsigned long long>(W) << 48);
-            in.lo = acc ? ilo : in.lo;
-            in.hi = acc ? ihi : in.hi;
-            io_epoch += (acc || modified) ? 1u : 0u;
-            const bool all_eq = pack8_eq(out, tout);
-            const uint32_t oc = (out_cursor - 1u) & 7u;  // -1 wraps to the last element (jnp negative index); masked by `modified`
-            const unsigned long long diff = oc < 4u ? (out.lo ^ tout.lo) : (out.hi ^ tout.hi);
-            err = err || (modified && ((diff >> (16u * (oc & 3u))) & 0xFFFFull) != 0);  // :346-350
-            // write_memory (memory), jump, halt
-            const unsigned long long nm = (m & ~(15ull << (4u * a))) | (static_cast<unsigned long long>(v) << (4u * a));
-            m = (ok && a_mem) ? nm : m;
-            const bool jump = ((v - 1u) & 15u) >= 7u;
-            cur = oob ? cur : (jump ? c : cur + 3u);
-            if (live) {
-                error = (oob || err) ? 1u : 0u;
-                inc = (oob || err || all_eq) ? kStop : 1;
-            }
-        }
-        if (!cycle_end()) break;
-    }
-    unpack8(in, in_arr);
-    unpack8(out, out_arr);
-    return error == 0u && pack8_eq(out, tout);
 }
 
 // subleq.py:26-56 / :63-98 encoders: byte (row-word v, column j) of the observation
