@@ -132,7 +132,7 @@ def build_workload(name, args, device, rank):
         desc = f"Subleq word_size={W} task=1 binary obs, batch={B}/GPU, {S} sims, {T} real steps per selfplay() call, FC H={H} (BASELINE.json configs[2])"
         data = "synthetic (random-init FC net, half-filled novelty set)"
         net_kernel, net_flops = "fc16p_forward_kernel", fc_flops_per_eval(in_dim, A, (0, 1, 2)) * B   # dense rows, narrow heads: the pipelined kernel
-        pmc_tag, gather_kernel = None, "subleq_step_kernel (env step + observation row)"
+        pmc_tag, gather_kernel = None, "subleq16_tree_leaf_kernel (tree step + env step + observation row + novelty)"
 
         def oracle(O):
             oenv = O.OracleEnv.subleq(W, (1,), True)
@@ -531,7 +531,16 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
     fields["roofline"] = roof
     # ---- leaf gather (north-star: >= 40 % of the HBM roof on the leaf-gather kernel) ----
     gbytes = B * (2 * env.state_bytes + env.obs_dim)
-    if prof["gather"]["launches"] == 0:
+    if prof["gather"]["launches"] == 0 and args.workload == "c3":
+        sims = max(T_instr * n_instr * S, 1)
+        fields["leaf_gather"] = {
+            "status": "fused into the tree kernel for this configuration",
+            "kernel": wl["gather_kernel"],
+            "avg_us_per_simulation_tree_plus_leaf": 1e3 * prof["tree"]["ms"] / sims,
+            "why": "Subleq-16: one wavefront per tree walks the tree, runs the interpreter for the chosen edge (parent slot -> child slot), writes the "
+                   "observation row and looks its novelty up; the launch is bound by the slowest interpreter run (<= 200 cycles of one wavefront), "
+                   "not by the 3.7 MB it moves (DESIGN.md 4.4)"}
+    elif prof["gather"]["launches"] == 0:
         fields["leaf_gather"] = {
             "status": "retired for this configuration",
             "why": "DeepSea's env.step is a few integer operations on a 16-byte state: the search kernel steps the chosen edge itself (child state "

@@ -1140,6 +1140,33 @@ extern "C" int eaz_search_simulate(eaz_search* s, int sim, void* stream) {
     s->tree.fused_rf = 1;
     s->tree.fuse_env = s->fuse_leaf ? 1 + s->env->dev.kind : 0;
     int mode = kTreeSelect | (s->pending_expand >= 0 ? kTreeExpand : 0);
+    const EnvDev& ed = s->env->dev;
+    if (g_fused_leaf && ed.kind == EAZ_ENV_SUBLEQ && ed.W == 16 && s->lpt == 16 && s->apl == 1 && s->net->kind == 0) {
+        // tree step + leaf step (+ observation row and, where the hashed slice is the IO rows, novelty) in one launch
+        const NetDev& nd = s->net->dev;
+        const bool obs_done = ed.binary && ed.obs_dim == 240;
+        const bool novelty_done = obs_done && !nd.sim_matrix && nd.hash_off == 80 && nd.hash_len == 160 && nd.in_dim == 240;
+        {
+            ProfScope ps(s, EAZ_K_TREE, st);
+            subleq16_tree_leaf_kernel<<<s->B, 64, 0, st>>>(s->tree, sim, mode, ed, s->d_next_reward, s->d_next_term, s->d_next_legal,
+                                                          obs_done ? s->d_obs : nullptr,
+                                                          NoveltyFuse{nd.bitset, novelty_done ? s->d_novelty : nullptr, nd.hash_bits, nd.nov_scale});
+            LAUNCH_OK();
+        }
+        if (!obs_done) {
+            ProfScope ps(s, EAZ_K_GATHER, st);
+            StateRef dst{s->tree.embeddings, s->tree.sim_next, s->N};
+            obs_emit_kernel<<<cdiv(static_cast<long>(s->B) * 64, 256), 256, 0, st>>>(ed, dst, s->B, s->d_obs);
+            LAUNCH_OK();
+        }
+        HeadList hl{3, {0, 1, s->opts.exploration ? 3 : 2, 0}};
+        NetOut o{s->opts.exploration ? nullptr : s->d_exploit, s->opts.exploration ? s->d_explore : nullptr, s->d_v, s->d_u};
+        rc = infer_launch(s, s->d_obs, s->d_novelty, o, hl, st, novelty_done);
+        if (rc) return rc;
+        s->pending_expand = sim;
+        s->sims_done += 1;
+        return 0;
+    }
     rc = tree_step_launch(s, sim, mode, st);
     if (rc) return rc;
     rc = recurrent_launch(s, st);

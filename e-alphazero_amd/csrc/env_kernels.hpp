@@ -320,16 +320,13 @@ struct NoveltyFuse {
     float nov_scale;
 };
 
-// Same contract as subleq_step_kernel (word_size 16 only); grid = B workgroups of one wavefront.
-__global__ void __launch_bounds__(64) subleq16_wave_kernel(EnvDev e, StateRef src, StateRef dst, const int32_t* action, int B, int mode,
-                                                           Key key_arg, const Key* key_ptr, char* out_copy, float* next_reward,
-                                                           uint8_t* next_term, uint8_t* next_legal, int mem_copy, uint8_t* obs_out,
-                                                           NoveltyFuse nf) {
+// One environment on one wavefront: state at sp -> state at dp (environment index b of the batch: key folding and the [b] outputs).
+// `action`: the action of a plain step (wavefront-uniform).
+__device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* sp, char* dp, const int b, const int lane, const int action,
+                                                   const int mode, const Key key_arg, const Key* key_ptr, char* out_copy, float* next_reward,
+                                                   uint8_t* next_term, uint8_t* next_legal, const int mem_copy, uint8_t* obs_out,
+                                                   const NoveltyFuse& nf) {
     constexpr int W = 16;
-    const int lane = threadIdx.x;
-    const int b = blockIdx.x;
-    const char* sp = state_ptr(src, b, e.state_bytes);
-    char* dp = state_ptr(dst, b, e.state_bytes);
     const bool copy_mem = reinterpret_cast<const void*>(sp) != reinterpret_cast<const void*>(dp);
     // ---- the source state, lane-distributed: header (uniform), IO rows (lanes 0..7), memory bytes (lanes 0..15) and the
     //      16-byte memory chunks (lane l = bytes 16 l ..) for the copies
@@ -366,7 +363,7 @@ __global__ void __launch_bounds__(64) subleq16_wave_kernel(EnvDev e, StateRef sr
         } else {
             task = h_task;
             step_count = h_step + 1;
-            act = __builtin_amdgcn_readfirstlane(action[b]);
+            act = action;
             if (step_count >= W - 3 || s_solved) finish = true;  // subleq.py:671-673
             else run = true;
         }
@@ -480,6 +477,17 @@ __global__ void __launch_bounds__(64) subleq16_wave_kernel(EnvDev e, StateRef sr
             }
         }
     }
+}
+
+// Same contract as subleq_step_kernel (word_size 16 only); grid = B workgroups of one wavefront.
+__global__ void __launch_bounds__(64) subleq16_wave_kernel(EnvDev e, StateRef src, StateRef dst, const int32_t* action, int B, int mode,
+                                                           Key key_arg, const Key* key_ptr, char* out_copy, float* next_reward,
+                                                           uint8_t* next_term, uint8_t* next_legal, int mem_copy, uint8_t* obs_out,
+                                                           NoveltyFuse nf) {
+    const int b = blockIdx.x;
+    const int act = action ? __builtin_amdgcn_readfirstlane(action[b]) : 0;
+    subleq16_wave_body(e, state_ptr(src, b, e.state_bytes), state_ptr(dst, b, e.state_bytes), b, threadIdx.x, act, mode, key_arg, key_ptr,
+                       out_copy, next_reward, next_term, next_legal, mem_copy, obs_out, nf);
 }
 
 // ---- connect_four -------------------------------------------------------------------------------------------------

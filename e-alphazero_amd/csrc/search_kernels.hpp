@@ -4,6 +4,7 @@
 // Reference: mctx instantiate_tree_from_root / gumbel_muzero_policy tail / Tree.summary [EXT]
 // and src/selfplay.py:92-134.
 #pragma once
+#include "env_kernels.hpp"
 #include "rng.hpp"
 #include "tree.hpp"
 
@@ -255,6 +256,25 @@ __global__ void __launch_bounds__(256) reanalyze_targets_kernel(int B, int A, co
         value_target[g.b] = vt * not_term0;                                                                       // :109
         ube_target[g.b] = ut * not_term0;                                                                         // :110
     }
+}
+
+// ---- Subleq word_size 16: tree step + leaf step in one launch ---------------------------------------------------------------------
+// One wavefront per tree: [expand + backward of simulation sim-1, select of simulation sim] on its first 16 lanes (one per action;
+// the other lanes mirror them), then env.step of the chosen edge by the one-wavefront interpreter (subleq16_wave_body): embedding
+// slot of the parent -> slot of the child, plus the child's observation row and novelty for the network forward.  Same arithmetic
+// as tree_step_kernel<16, 1> followed by subleq16_wave_kernel; what goes is one dependent launch per simulation (a graph edge
+// costs about as much as the select walk) and the round trip of (parent, action, child slot) through memory.
+__global__ void __launch_bounds__(64) subleq16_tree_leaf_kernel(TreeDev t, int sim, int mode, EnvDev e, float* next_reward, uint8_t* next_term,
+                                                                uint8_t* next_legal, uint8_t* obs_out, NoveltyFuse nf) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const TreeSel sel = tree_step_body<16, 1>(t, sim, mode, b, lane);
+    if (!(mode & kTreeSelect)) return;
+    const int node = __builtin_amdgcn_readfirstlane(sel.node), action = __builtin_amdgcn_readfirstlane(sel.action);
+    const int dst = __builtin_amdgcn_readfirstlane(sel.dst);
+    char* base = t.embeddings + static_cast<long>(b) * t.N * t.state_bytes;
+    // embedding slots 1.. are only ever written here and the allocation starts zeroed: bytes >= 16 of `memory` stay zero
+    subleq16_wave_body(e, base + static_cast<long>(node) * t.state_bytes, base + static_cast<long>(dst) * t.state_bytes, b, lane, action, 0,
+                       Key{0, 0}, nullptr, nullptr, next_reward, next_term, next_legal, 16, obs_out, nf);
 }
 
 }  // namespace eaz

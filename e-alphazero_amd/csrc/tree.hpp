@@ -340,11 +340,16 @@ __device__ unsigned long long g_tree_stamps[1024 * 8];
 // kernel is bound by memory-level parallelism, not by lanes: one wavefront of 2-lane groups walks 32 trees whose rows lie in
 // ~10 different cache lines per level each, so spreading the trees over more wavefronts / CUs (more miss queues) is what
 // shortens a launch (DESIGN.md "tree_step_kernel").
+// result of the select phase (group-uniform): the leaf's parent, the action taken there, the node slot of the child
+struct TreeSel {
+    int node, action, dst;
+};
+
+// The body of tree_step_kernel for tree `b`, lane `sub` of its LPT * spread lanes (also called by the fused tree + leaf kernel of
+// search_kernels.hpp, one wavefront per tree).
 template <int LPT, int APL>
-__global__ void __launch_bounds__(256) tree_step_kernel(TreeDev t, int sim, int mode, int spread) {
-    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int slot = LPT * spread;
-    const int b = gtid / slot, sub = gtid - b * slot;
+__device__ __forceinline__ TreeSel tree_step_body(const TreeDev& t, int sim, int mode, int b, int sub) {
+    TreeSel sel{0, 0, 0};
     const bool live = b < t.B && sub < LPT;  // mirror / dead groups keep executing (shuffles need every lane) without storing
     const Group<LPT, APL> g = make_group<LPT, APL>(b < t.B ? b : 0, sub % LPT, t.A);
     const int N = t.N, A = t.A;
@@ -550,7 +555,19 @@ __global__ void __launch_bounds__(256) tree_step_kernel(TreeDev t, int sim, int 
             }
         }
         EAZ_TSTAMP(4, static_cast<unsigned long long>(depth));
+        sel.node = node;
+        sel.action = action;
+        sel.dst = nxt == -1 ? sim + 1 : nxt;
     }
+    return sel;
+}
+
+template <int LPT, int APL>
+__global__ void __launch_bounds__(256) tree_step_kernel(TreeDev t, int sim, int mode, int spread) {
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = LPT * spread;
+    const int b = gtid / slot, sub = gtid - b * slot;
+    tree_step_body<LPT, APL>(t, sim, mode, b, sub);
 }
 
 }  // namespace eaz
