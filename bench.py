@@ -481,7 +481,18 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
     A = wl["A"]
     l23 = sum(2 * (H * H + H * (1 if h < 2 else A)) for h in heads) * B
     dense_flops = wl["net_flops"]
-    if persistent:
+    if persistent and name == "c3":
+        # subleq16_search_kernel: all S simulations of a real step in one launch (tree step + interpreter + forward per simulation, 16 trees per
+        # workgroup).  A ~3 ms launch: the event pair of the instrumented pass is its duration (the ~4 us launch gap is 0.1 %).  FLOPs: the S
+        # forwards, dense (the kernel runs whole rounds of layer 1; padded k-steps are not counted).
+        kname = "subleq16_search_kernel"
+        n_launch = prof["search"]["launches"]
+        k_ms = pair_ms = prof["search"]["ms"] / n_launch
+        flops = dense = S * dense_flops
+        pair_us = 1e3 * pair_ms
+        algo = (f"{S} simulations x {B} leaves x dense forward of 3 heads ({dense_flops // B} FLOP per leaf); the launch also walks the trees and "
+                "runs the Subleq interpreter, during which the MFMA pipes idle")
+    elif persistent:
         # search_persist_kernel: ALL S simulations of a real step in one launch (trees in LDS, DeepSea step, S forwards of B leaves)
         # self-play: ONE launch per selfplay() call = T real steps x (root inference + S simulations), trees in LDS, DeepSea steps,
         # (S + 1) forwards of B rows per real step

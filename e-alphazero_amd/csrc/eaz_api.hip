@@ -18,6 +18,7 @@
 #include "search_kernels.hpp"
 #include "search_persist.hpp"
 #include "net_fc_pipe.hpp"
+#include "search_subleq.hpp"
 
 using namespace eaz;
 
@@ -1031,6 +1032,39 @@ static int persist_launch(eaz_search* s, hipStream_t st, const PersistSelfplay* 
     return 0;
 }
 
+// Subleq-16 + FC network whose novelty is the XXHash variant over the IO rows: every simulation of a search in one launch
+// (search_subleq.hpp).  Decided per run: the hash class of a network can change after the search was created (eaz_net_set_simhash).
+static bool sq16_persist_eligible(const eaz_search* s) {
+    const EnvDev& ed = s->env->dev;
+    if (!(ed.kind == EAZ_ENV_SUBLEQ && ed.W == 16 && ed.binary && ed.obs_dim == 240 && s->lpt == 16 && s->apl == 1 && s->net->kind == 0)) return false;
+    const NetDev& nd = s->net->dev;
+    return fp_eligible(nd.in_dim, nd.A) && nd.in_dim == 240 && !nd.sim_matrix && nd.hash_off == 80 && nd.hash_len == 160;
+}
+static int sq16_persist_launch(eaz_search* s, int sim0, int n_sims, bool expand_first, bool expand_last, hipStream_t st) {
+    Sq16SearchArgs a;
+    a.t = s->tree;
+    a.t.fused_rf = 1;
+    a.t.fuse_env = 0;
+    a.e = s->env->dev;
+    a.net = s->net->dev;
+    a.out = NetOut{s->opts.exploration ? nullptr : s->d_exploit, s->opts.exploration ? s->d_explore : nullptr, s->d_v, s->d_u};
+    a.heads = HeadList{3, {0, 1, s->opts.exploration ? 3 : 2, 0}};  // context.py:132
+    a.obs = s->d_obs;
+    a.next_reward = s->d_next_reward; a.next_term = s->d_next_term; a.next_legal = s->d_next_legal;
+    a.nf = NoveltyFuse{a.net.bitset, s->d_novelty, a.net.hash_bits, a.net.nov_scale};
+    a.sim0 = sim0; a.n_sims = n_sims; a.expand_first = expand_first; a.expand_last = expand_last;
+    a.stamps = s->d_stamps;
+    const int lds = kSqHeadGroups * fp_lds_bytes(a.net.in_dim, a.net.A);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(subleq16_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    subleq16_search_kernel<<<cdiv(s->B, 16), kSqThreads, lds, st>>>(a);
+    LAUNCH_OK();
+    return 0;
+}
+
 static int tree_step_launch(eaz_search* s, int sim, int mode, hipStream_t st) {
     ProfScope ps(s, EAZ_K_TREE, st);
     // automatic: one-wavefront workgroups, and trees spread until the launch has at least one wavefront per CU
@@ -1191,6 +1225,17 @@ extern "C" int eaz_search_run(eaz_search* s, void* stream) {
         int rc = persist_launch(s, S(stream));
         if (rc) return rc;
         s->clear_pending = 0;
+        s->sims_done = s->S;
+        return 0;
+    }
+    if (g_persist && s->sims_done == 0 && s->pending_expand < 0 && sq16_persist_eligible(s)) {
+        // Subleq-16: all S simulations in one launch, 16 trees per workgroup (search_subleq.hpp)
+        hipStream_t st = S(stream);
+        int rc = ensure_cleared(s, st);
+        if (rc) return rc;
+        ProfScope ps(s, EAZ_K_SEARCH, st);
+        rc = sq16_persist_launch(s, 0, s->S, false, true, st);
+        if (rc) return rc;
         s->sims_done = s->S;
         return 0;
     }
@@ -1649,6 +1694,11 @@ extern "C" __attribute__((visibility("default"))) int eaz_diag_tree_stamps(unsig
 extern "C" __attribute__((visibility("default"))) int eaz_diag_persist_stamps(eaz_search* s, unsigned long long* h_out /* [256*32] */) {
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpy(h_out, s->d_stamps, sizeof(unsigned long long) * 256 * 32, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int eaz_diag_sq_stamps(unsigned long long* h_out /* [16] */) {
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_sq_stamps), sizeof(unsigned long long) * 16));
     return 0;
 }
 extern "C" __attribute__((visibility("default"))) int eaz_diag_fc_stamps(unsigned long long* h_out /* [1024*8] */) {

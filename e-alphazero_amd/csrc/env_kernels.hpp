@@ -320,13 +320,37 @@ struct NoveltyFuse {
     float nov_scale;
 };
 
+__device__ __forceinline__ void subleq16_novelty(const NoveltyFuse& nf, const int b, const uint32_t index) {
+    const bool seen = nf.bitset ? ((nf.bitset[index >> 3] >> (index & 7u)) & 1u) != 0 : false;  // hashes.py:29-38
+    nf.novelty[b] = (seen ? 0.0f : 1.0f) * nf.nov_scale;                                        // fully_connected.py:90
+}
+
+#ifdef EAZ_FC_STAMPS
+// Diagnostic build only: shader-clock stamps inside the last subleq16_wave_body call of workgroup 0, wave 0 (tools/subleq_stamps.py)
+__device__ unsigned long long g_sq_stamps[16];
+#define EAZ_WSTAMP(i)                                                                                  \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                                     \
+            unsigned long long t_;                                                                     \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+            g_sq_stamps[i] = t_;                                                                       \
+        }                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    } while (0)
+#else
+#define EAZ_WSTAMP(i)
+#endif
+
 // One environment on one wavefront: state at sp -> state at dp (environment index b of the batch: key folding and the [b] outputs).
 // `action`: the action of a plain step (wavefront-uniform).
+// index_out (optional): the caller looks the novelty up itself (subleq16_novelty) from the hash index left there.
 __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* sp, char* dp, const int b, const int lane, const int action,
                                                    const int mode, const Key key_arg, const Key* key_ptr, char* out_copy, float* next_reward,
                                                    uint8_t* next_term, uint8_t* next_legal, const int mem_copy, uint8_t* obs_out,
-                                                   const NoveltyFuse& nf) {
+                                                   const NoveltyFuse& nf, uint32_t* index_out = nullptr) {
     constexpr int W = 16;
+    EAZ_WSTAMP(0);
     const bool copy_mem = reinterpret_cast<const void*>(sp) != reinterpret_cast<const void*>(dp);
     // ---- the source state, lane-distributed: header (uniform), IO rows (lanes 0..7), memory bytes (lanes 0..15) and the
     //      16-byte memory chunks (lane l = bytes 16 l ..) for the copies
@@ -343,6 +367,7 @@ __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* 
         if (lane < W) mem_raw = reinterpret_cast<const uint8_t*>(sp + 80)[lane];
         if (16 * lane < mem_copy) chunk = *reinterpret_cast<const uint4*>(sp + 80 + 16 * lane);
     }
+    EAZ_WSTAMP(1);
     const int s_term = h_flags & 0xFF, s_trunc = (h_flags >> 8) & 0xFF, s_solved = (h_flags >> 16) & 0xFF;
     // ---- decide what this environment does (pgx wrapper A.1, auto_reset selfplay.py:66-71, _step subleq.py:671-677)
     bool do_init = false, finish = false, run = false;
@@ -383,6 +408,7 @@ __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* 
             if ((idx >> 2) == 0) chunk.x = w; else if ((idx >> 2) == 1) chunk.y = w; else if ((idx >> 2) == 2) chunk.z = w; else chunk.w = w;
         }
     }
+    EAZ_WSTAMP(2);
     int n_exin = s_exin, n_exinaf = s_exinaf, n_exout = s_exout, n_exoutaf = s_exoutaf;
     bool all_correct = false;
     if (run) {
@@ -400,6 +426,7 @@ __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* 
             all_correct = correct;
         }
     }
+    EAZ_WSTAMP(3);
     // ---- assemble the new state --------------------------------------------------------------------------------
     float reward;
     int terminated, solved;
@@ -433,6 +460,7 @@ __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* 
         if (next_term) next_term[b] = static_cast<uint8_t>(terminated);
         if (next_legal) *reinterpret_cast<uint4*>(next_legal + static_cast<long>(b) * 16) = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);  // all legal (subleq.py:626)
     }
+    EAZ_WSTAMP(4);
     if (obs_out) {
         // binary encoding: the 48 x 5 observation (subleq.py:679-707 rows = memory | input | input_after | output | output_after;
         // :88-98 columns = 4 little-endian bits of v mod 16, then v == 16); lane w < 48 holds row-word w and stores its 5 bytes
@@ -447,6 +475,7 @@ __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* 
             for (int j = 0; j < 4; ++j) o[j] = static_cast<uint8_t>((m >> j) & 1u);
             o[4] = static_cast<uint8_t>(v == 16u);
         }
+        EAZ_WSTAMP(5);
         if (nf.novelty) {
             // XXHash-variant novelty of the same observation (hashes.py:162-229 over bytes 80..239 = the four IO rows, fully_connected.py:85-87):
             // hash lane i = stripe i = IO row i = 8 words x 5 bytes, every byte 0 or 1, i.e. astype(f32) bits 0 or 0x3F800000 (:207)
@@ -471,12 +500,11 @@ __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* 
             h += 40u;  // :226 (stripe count)
             h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;  // :190-197
             const uint32_t index = h >> (32 - nf.hash_bits);             // :229
-            if (lane == 0) {
-                const bool seen = nf.bitset ? ((nf.bitset[index >> 3] >> (index & 7u)) & 1u) != 0 : false;  // hashes.py:29-38
-                nf.novelty[b] = (seen ? 0.0f : 1.0f) * nf.nov_scale;                                        // fully_connected.py:90
-            }
+            if (index_out) { if (lane == 0) *index_out = index; }
+            else if (lane == 0) subleq16_novelty(nf, b, index);
         }
     }
+    EAZ_WSTAMP(6);
 }
 
 // Same contract as subleq_step_kernel (word_size 16 only); grid = B workgroups of one wavefront.

@@ -29,19 +29,19 @@ __host__ inline bool fp_eligible(int in_dim, int A) { return in_dim <= kFpMaxK &
 
 // grid = (row tiles, heads): one workgroup = 16 rows x one head (40 KB of LDS at the C3 shape, 148 VGPRs: three workgroups per CU, whose
 // barriers / staging / layer-3 chains overlap each other's MFMA streams)
-__global__ void __launch_bounds__(256) fc16p_forward_kernel(NetDev net, const uint8_t* __restrict__ obs, int B, NetOut out, HeadList heads,
-                                                            unsigned long long* kstep_counter) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+// The forward of head `head` for the 16 rows from `row0` on, by 256 threads `tid` = 0..255 (three workgroup barriers; `lds` = fp_lds_bytes).
+// Called once per workgroup by fc16p_forward_kernel and once per head and simulation by the persistent Subleq search kernel.
+__device__ __forceinline__ void fc16p_body(const NetDev& net, const uint8_t* __restrict__ obs, const int B, const NetOut& out, const int head,
+                                           const int row0, uint8_t* lds, const int tid, unsigned long long* kstep_counter) {
     const int K1 = net.in_dim, Kp = fp_kpad(K1);
     float* X = reinterpret_cast<float*>(lds);
     float* H2 = X;  // aliases the observation tile
     const int xf = fp_xfloats(K1) > kF16HFloats ? fp_xfloats(K1) : kF16HFloats;
     float* H1 = X + xf;
     float* part = H1 + kF16HFloats;      // [4 waves][16 rows][16 outputs]
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 15, kq = lane >> 4;
     const int n0 = wave * 64, col = n0 + 4 * r, voff = (kq * kFcH + col) * 4;
-    const int row0 = blockIdx.x * kF16M;
-    const int head = heads.id[blockIdx.y], No = head < 2 ? 1 : net.A;
+    const int No = head < 2 ? 1 : net.A;
     auto rsrc = [](const float* p, int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000); };
     const __amdgpu_buffer_rsrc_t rs1 = rsrc(net.w[head * 3], Kp * kFcH * 4), rs2 = rsrc(net.w[head * 3 + 1], kFcH * kFcH * 4);
 
@@ -166,6 +166,12 @@ __global__ void __launch_bounds__(256) fc16p_forward_kernel(NetDev net, const ui
     }
     EAZ_STAMP(6);
     if (kstep_counter && tid == 0) atomicAdd(kstep_counter, static_cast<unsigned long long>((K1 + 3) / 4));
+}
+
+__global__ void __launch_bounds__(256) fc16p_forward_kernel(NetDev net, const uint8_t* __restrict__ obs, int B, NetOut out, HeadList heads,
+                                                            unsigned long long* kstep_counter) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    fc16p_body(net, obs, B, out, heads.id[blockIdx.y], blockIdx.x * kF16M, lds, threadIdx.x, kstep_counter);
 }
 
 }  // namespace eaz

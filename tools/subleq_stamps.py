@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Phase breakdown of subleq16_search_kernel at C3 from the diagnostic build (make -C e-alphazero_amd/csrc diag): s_memtime stamps of
+simulation S/2, lane 0 of each of the four waves of every workgroup."""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("EAZ_LIB", os.path.join(ROOT, "e-alphazero_amd", "libeaz_diag.so"))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import e_alphazero_amd as eaz  # noqa: E402
+from e_alphazero_amd import engine  # noqa: E402
+
+W, B, S = 16, int(os.environ.get("B", 4096)), 64
+cols, rows = 5, W + 32
+in_dim, hash_off = rows * cols, W * cols
+params = eaz.params.init_fc_params(in_dim, 256, W, seed=0)
+env = engine.EnvHandle.subleq(W, (1,), True, device=0)
+net = engine.FCNet(env.ctx, in_dim, 256, W, params, eaz.params.init_hash_state(fill=0.5), hash_off=hash_off, hash_len=in_dim - hash_off)
+search = engine.Search(env, net, B, S, discount=0.97)
+states = env.init(B, key=0)
+search.selfplay(states, 6, key=0, use_graph=False)   # mid-episode states
+obs = env.observe(states)
+ex, xp, v, u, _ = net.forward(obs)
+g = torch.zeros(B, W, device="cuda")
+for rep in range(3):
+    search.begin(ex, v, u, states, torch.zeros(B, device="cuda"), None, g)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    search.run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+print(f"search.run(): {1e3 * dt:.3f} ms = {1e6 * dt / S:.2f} us per simulation (host-timed, one launch)")
+lib = eaz.load_library()
+lib.eaz_diag_persist_stamps.argtypes = [C.c_void_p, C.c_void_p]
+buf = np.zeros(256 * 32, np.uint64)
+lib.eaz_diag_persist_stamps(search.h, buf.ctypes.data)
+st = buf.reshape(256, 4, 8).astype(np.int64)  # waves 0-3 of the 8 (stamp slots of waves 4-7 alias lower ones: not recorded)
+st = st[st[:, 0, 0] > 0]
+
+
+def seg(name, d):
+    print(f"   {name:58s} median {np.median(d):8.0f}   p10 {np.percentile(d, 10):8.0f}   p90 {np.percentile(d, 90):8.0f} cycles")
+
+
+w0 = st[:, 0, :]
+print(f"{len(st)} workgroups, simulation {S // 2} (100 MHz s_memtime ticks x clock ratio: see persist_stamps.py)")
+seg("T: tree step (wave 0)", w0[:, 1] - w0[:, 0])
+seg("T -> E barrier (wave 0)", w0[:, 2] - w0[:, 1])
+seg("E: 4 interpreters in turn (wave 0)", w0[:, 3] - w0[:, 2])
+seg("E: slowest wave of the workgroup", (st[:, :, 3] - st[:, :, 2]).max(axis=1))
+seg("E -> F barrier (wave 0)", w0[:, 4] - w0[:, 3])
+seg("F: 3 heads (wave 0)", w0[:, 5] - w0[:, 4])
+seg("F -> next barrier", w0[:, 6] - w0[:, 5])
+seg("one simulation", w0[:, 6] - w0[:, 0])
+
+lib.eaz_diag_sq_stamps.argtypes = [C.c_void_p]
+q = np.zeros(16, np.uint64)
+lib.eaz_diag_sq_stamps(q.ctypes.data)
+q = q.astype(np.int64)
+print("inside one subleq16_wave_body call (workgroup 0, wave 0, last call of the launch):")
+for name, i in (("loads of the parent state", 0), ("decision + program patch", 1), ("test cases + interpreter", 2), ("assemble + state stores", 3),
+                ("observation row", 4), ("hash", 5)):
+    print(f"   {name:40s} {q[i + 1] - q[i]:8d} cycles")
