@@ -323,7 +323,7 @@ __device__ unsigned long long g_tree_stamps[1024 * 8];
 #define EAZ_TSTAMP(i, extra)                                                                            \
     do {                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                             \
-        if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                   \
+        if (threadIdx.x == 0 && blockIdx.x < 1024 && (mode & kTreeSelect)) {                           \
             unsigned long long t_;                                                                     \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
             g_tree_stamps[blockIdx.x * 8 + (i)] = t_;                                                  \

@@ -66,3 +66,14 @@ print("inside one subleq16_wave_body call (workgroup 0, wave 0, last call of the
 for name, i in (("loads of the parent state", 0), ("decision + program patch", 1), ("test cases + interpreter", 2), ("assemble + state stores", 3),
                 ("observation row", 4), ("hash", 5)):
     print(f"   {name:40s} {q[i + 1] - q[i]:8d} cycles")
+
+# tree_step_body's own stamps (tree.hpp EAZ_TSTAMP): the last call with a select phase = simulation S-1, thread 0 of each workgroup
+lib.eaz_diag_tree_stamps.argtypes = [C.c_void_p]
+tb = np.zeros(1024 * 8, np.uint64)
+lib.eaz_diag_tree_stamps(tb.ctypes.data)
+tb = tb.reshape(1024, 8).astype(np.int64)[:256]
+print(f"tree_step_body, simulation {S - 1} (select depth of tree 0 of the workgroup: median {np.median(tb[:, 5]):.0f}):")
+seg("expand: loads + new node stores", tb[:, 1] - tb[:, 0])
+seg("backward", tb[:, 2] - tb[:, 1])
+seg("select walk", tb[:, 3] - tb[:, 2])
+seg("result stores", tb[:, 4] - tb[:, 3])
