@@ -10,14 +10,18 @@ search-internal steps are not counted.
 --workload c4: connect_four, B = 8192, S = 200, ResNet 64ch x 5 blocks, two-player (configs[3]); T = 4 per step by default
                (one real step is 201 ResNet forwards of 8192 positions, ~0.6 s).
 
-N > 1: one process per GPU (torchrun), the batch is sharded (weak scaling, B per GPU fixed); the only collective is one RCCL
+N > 1: `python bench.py --gpus N` starts the N ranks itself (one process per GPU, before anything touches the GPU); under torchrun the
+process is a rank already.  The batch is sharded (weak scaling, B per GPU fixed); the only collective is one RCCL
 all-gather per selfplay() call that pools the [T, B, ...] trajectory block of every rank (the counterpart of
 src/main.py:383-385), inside the timed region.  When there are more ranks than visible GPUs (rehearsing the launch path on a
 one-GPU box) the ranks share the card and the process group is gloo; the JSON line then carries "rehearsal".
 
-Prints ONE JSON line on rank 0 (see the task contract), with `roofline` for the dominant kernel (network forward, f32 MFMA)
-measured live with HIP events on the launch stream, `roofline_gather` for the leaf-gather kernel class (HBM), and
-`cpu_baseline` = the CPU oracle timed on this host on a bounded sample of the same workload.
+Before anything is timed the parity gate runs 16 environments of the benchmark's inputs through the engine and the CPU oracle and
+aborts on any difference.  Prints ONE JSON line on rank 0 (see the task contract), with `roofline` for the dominant kernel against the
+f32-MFMA peak (C2: search_persist_kernel, one launch per selfplay() call; C3: subleq16_search_kernel, one launch per real step; C4:
+resnet_forward_kernel), measured live with HIP events on the launch stream, `leaf_gather` / `roofline_gather` for the leaf-gather class,
+`extra.c3` / `extra.c4` (short passes of the other two configurations, default run only) and `cpu_baseline` = the CPU oracle timed on
+this host on a bounded sample of the same workload.
 """
 import argparse
 import json
