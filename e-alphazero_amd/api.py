@@ -8,7 +8,8 @@ Names, argument meaning and call shapes follow the reference so that `src/selfpl
     jax.vmap(env.init)(keys), jax.vmap(env.step)(s, a, keys)          vmap(env.init)(keys), vmap(env.step)(s, a, keys)
     auto_reset(env.step, env.init)            selfplay.py:26-75       auto_reset(env.step, env.init)
     DeepSea(size_of_grid, action_map_key)     envs/deep_sea.py:37     DeepSea(size_of_grid, action_map_key)
-    Subleq(tasks, word_size, use_binary_encoding) envs/subleq.py:599  Subleq(tasks, word_size, use_binary_encoding=...)
+    Subleq(tasks, word_size, reward_fn, use_binary_encoding) :599     Subleq(tasks, word_size, reward_fn, use_binary_encoding)
+    solved_or_not / lowest_bytes              envs/subleq.py:535-542  solved_or_not / lowest_bytes (tags; evaluated on the device)
     get_forward_fn(env, config).apply(...)    context.py:86-106       get_forward_fn(env, config).apply(...)
     get_epistemic_recurrent_fn(...)           context.py:109-157      get_epistemic_recurrent_fn(...)
     emctx.EpistemicRootFnOutput / EpistemicRecurrentFnOutput          EpistemicRootFnOutput / EpistemicRecurrentFnOutput
@@ -192,18 +193,33 @@ class SubleqTask(enum.IntEnum):  # src/envs/subleq.py:110-124
     SUMMATION = 14
 
 
+def solved_or_not(execution_result=None):
+    """src/envs/subleq.py:535-537 -- a tag for Subleq(reward_fn=...): the reward is computed on the device."""
+    raise EazError("reward functions are tags for Subleq(reward_fn=...); the engine evaluates them on the device")
+
+
+def lowest_bytes(execution_result=None):
+    """src/envs/subleq.py:540-542 -- a tag for Subleq(reward_fn=...): solved / (1 + bytes_used), computed on the device."""
+    raise EazError("reward functions are tags for Subleq(reward_fn=...); the engine evaluates them on the device")
+
+
 class Subleq(Env):
-    """src/envs/subleq.py:571-724 (reward_fn = solved_or_not)."""
+    """src/envs/subleq.py:571-724.  reward_fn: `solved_or_not` (default, :603) or `lowest_bytes`, by function or by name; any other
+    callable is refused (the reward is evaluated inside the step kernel)."""
 
     id = "subleq"
 
-    def __init__(self, tasks, word_size: int = 256, use_binary_encoding: bool = False, device=None):
+    def __init__(self, tasks, word_size: int = 256, reward_fn=solved_or_not, use_binary_encoding: bool = False, device=None):
         if not 16 <= word_size <= 256:
             raise AssertionError("16 <= word_size <= 256 (subleq.py:606)")
+        name = reward_fn if isinstance(reward_fn, str) else getattr(reward_fn, "__name__", None)
+        if name not in engine.SUBLEQ_REWARD_FNS or (callable(reward_fn) and reward_fn not in (solved_or_not, lowest_bytes)):
+            raise EazError(f"Subleq reward_fn must be solved_or_not or lowest_bytes (subleq.py:535-542), got {reward_fn!r}")
         self.tasks = [int(t) for t in tasks]
         self.word_size = word_size
+        self.reward_fn = name
         self.use_binary_encoding = use_binary_encoding
-        self._h = engine.EnvHandle.subleq(word_size, self.tasks, use_binary_encoding, device=device)
+        self._h = engine.EnvHandle.subleq(word_size, self.tasks, use_binary_encoding, device=device, reward_fn=name)
 
 
 class ConnectFour(Env):

@@ -214,6 +214,15 @@ extern "C" int eaz_env_create_subleq(eaz_ctx* ctx, int W, const int32_t* h_tasks
     return 0;
 }
 
+extern "C" int eaz_env_set_subleq_reward(eaz_env* env, int reward_fn) {
+    ARG_OK(env != nullptr);
+    if (env->dev.kind != EAZ_ENV_SUBLEQ) return fail("eaz_env_set_subleq_reward: not a Subleq environment");
+    if (reward_fn != EAZ_SUBLEQ_REWARD_SOLVED_OR_NOT && reward_fn != EAZ_SUBLEQ_REWARD_LOWEST_BYTES)
+        return fail("eaz_env_set_subleq_reward: unknown reward function %d (subleq.py:535-542)", reward_fn);
+    env->dev.reward_fn = reward_fn;
+    return 0;
+}
+
 extern "C" int eaz_env_create_connect4(eaz_ctx* ctx, eaz_env** out) {
     ARG_OK(ctx && out);
     eaz_env* e = new eaz_env();

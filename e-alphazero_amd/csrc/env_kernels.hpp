@@ -90,6 +90,12 @@ __global__ void __launch_bounds__(256) leaf_gather_deepsea_kernel(EnvDev e, Tree
     }
 }
 
+// reward of a SOLVED program (an unsolved one gets 0 from either function; only then have all three cases run, so `bytes_used` is the
+// maximum over all of them, subleq.py:530): solved_or_not = 1, lowest_bytes = 1 / (1 + bytes_used) (one correctly rounded f32 division)
+__device__ __forceinline__ float subleq_reward(const EnvDev& e, int bytes_used) {
+    return e.reward_fn ? 1.0f / static_cast<float>(1 + bytes_used) : 1.0f;
+}
+
 // ---- Subleq, word sizes other than 16 ------------------------------------------------------------------------------
 // One lane per environment, `envs_per_wg` (<= 64) environments per one-wavefront workgroup: the kernel's duration is the
 // longest interpreter run of a wavefront, so the environments are spread over as many wavefronts / CUs as the launch has room
@@ -141,6 +147,7 @@ __global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src,
     }
     uint16_t tin[8], tout[8], outv[8], ex_in[8], ex_out[8], in_after[8], out_after[8];
     bool all_correct = false;
+    int bytes_used = 0;
     if (run) {
         const int idx = step_count - 1;  // subleq.py:654
         all_correct = true;
@@ -156,7 +163,9 @@ __global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src,
                 for (int i = 0; i < W; i += 4) *reinterpret_cast<uint32_t*>(mem.m + i) = *reinterpret_cast<const uint32_t*>(sp->memory + i);
                 if (idx >= 0 && idx < W) mem.m[idx] = static_cast<uint8_t>(act);
             }
-            const bool correct = subleq_simulate(W, mem, tin, tout, outv);
+            int bytes_c = 0;
+            const bool correct = subleq_simulate(W, mem, tin, tout, outv, bytes_c);
+            bytes_used = bytes_c > bytes_used ? bytes_c : bytes_used;  // :530 results.bytes_used.max()
             if (c == 0) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { in_after[i] = tin[i]; out_after[i] = outv[i]; }
@@ -171,7 +180,7 @@ __global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src,
     uint8_t terminated, solved;
     if (run) {
         solved = all_correct ? 1 : 0;                                                                 // subleq.py:525
-        reward = solved ? 1.0f : 0.0f;                                                                // :535-537
+        reward = solved ? subleq_reward(e, bytes_used) : 0.0f;                                        // :535-537 / :540-542
         terminated = do_init ? 0 : sp->terminated;  // _step never sets terminated on this branch (:661-669)
         if (do_init) {
             for (int i = 0; i < 256; i += 16) *reinterpret_cast<uint4*>(dp->memory + i) = make_uint4(0, 0, 0, 0);
@@ -236,10 +245,11 @@ __device__ __forceinline__ int sq_rl(int v, int l) { return __builtin_amdgcn_rea
 // bounds): nothing of the IO state moves there, `all_eq` (:341) included, so halting is folded into the cycle increment `inc`.
 // Brent snapshots (iterations 1, 2, 4, ...; any growing schedule is exact) hold the memory in `vsnap` and the cursor in `s_cur`; an
 // IO event invalidates the snapshot (the input cursor and the output only move forward, so the state before it cannot recur).
-__device__ __forceinline__ bool subleq16_wave_run(int vmem, const int vin, const int vtout, const int lane, int& v_in_after, int& v_out) {
+__device__ __forceinline__ bool subleq16_wave_run(int vmem, const int vin, const int vtout, const int lane, int& v_in_after, int& v_out,
+                                                  int& bytes_used) {
     constexpr int W = 16, AMAX = 12, AIN = 13, AOUT = 14, kStop = 1000;
     int vout = W, vsnap = -1;
-    int cur = 0, cycles = 0, in_cur = 0, out_cursor = 0;
+    int cur = 0, cycles = 0, in_cur = 0, out_cursor = 0, top_cur = -3;  // top_cur: highest cursor of an executed cycle (:311)
     int s_cur = -1, s_cycle = 0, it = 0, next_snap = 1;
     int error = 0;
     int inc = (__builtin_amdgcn_ballot_w64(vout == vtout) & 0xFFull) == 0xFFull ? kStop : 1;  // :341 halts
@@ -265,6 +275,7 @@ __device__ __forceinline__ bool subleq16_wave_run(int vmem, const int vin, const
         for (;;) {
             oob = cur >= W - 2;  // :364-370
             if (oob) break;
+            top_cur = max(top_cur, cur);
             a = sq_rl(vmem, cur); b = sq_rl(vmem, cur + 1); c = sq_rl(vmem, cur + 2);
             if (max(a, b) > AMAX) break;
             const int v = (sq_rl(vmem, a) - sq_rl(vmem, b)) & 15;  // :322
@@ -308,6 +319,7 @@ __device__ __forceinline__ bool subleq16_wave_run(int vmem, const int vin, const
     }
     v_in_after = __shfl(vin, (lane + in_cur) & 63);  // lanes 0..7 read lanes <= 15, all W beyond the inputs
     v_out = vout;
+    bytes_used = top_cur + 3;
     return error == 0 && (__builtin_amdgcn_ballot_w64(vout == vtout) & 0xFFull) == 0xFFull;
 }
 
@@ -411,6 +423,7 @@ __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* 
     EAZ_WSTAMP(2);
     int n_exin = s_exin, n_exinaf = s_exinaf, n_exout = s_exout, n_exoutaf = s_exoutaf;
     bool all_correct = false;
+    int bytes_used = 0;
     if (run) {
         all_correct = true;
         const int vmem = lane < W ? (mem_raw & 15) : 0;
@@ -421,7 +434,9 @@ __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* 
 #pragma unroll
             for (int i = 0; i < 8; ++i) { vin = lane == i ? tin[i] : vin; vtout = lane == i ? tout[i] : vtout; }
             int v_after, v_out;
-            const bool correct = subleq16_wave_run(vmem, vin, vtout, lane, v_after, v_out);
+            int bytes_c;
+            const bool correct = subleq16_wave_run(vmem, vin, vtout, lane, v_after, v_out, bytes_c);
+            bytes_used = max(bytes_used, bytes_c);  // :530 results.bytes_used.max()
             if (c == 0) { n_exin = vin; n_exout = vtout; n_exinaf = v_after; n_exoutaf = v_out; }
             all_correct = correct;
         }
@@ -432,7 +447,7 @@ __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* 
     int terminated, solved;
     if (run) {
         solved = all_correct ? 1 : 0;                  // subleq.py:525
-        reward = solved ? 1.0f : 0.0f;                 // :535-537
+        reward = solved ? subleq_reward(e, bytes_used) : 0.0f;  // :535-537 / :540-542
         terminated = do_init ? 0 : s_term;             // _step never sets terminated on this branch (:661-669)
     } else {
         solved = s_solved;

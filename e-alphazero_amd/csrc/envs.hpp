@@ -22,6 +22,7 @@ struct EnvDev {
     int n_tasks;
     int tasks[16];
     int binary;
+    int reward_fn;  // 0 = solved_or_not (subleq.py:535-537), 1 = lowest_bytes (:540-542)
 };
 
 // A batch of states addressed as base + (b * nodes_per_tree + idx[b]) * state_bytes  (idx == nullptr -> 0).
@@ -196,7 +197,8 @@ struct MemLds {
 // (cycles += floor((200 - cycles) / p) * p) and the last (200 - cycles) mod p cycles are interpreted normally.  The result is the
 // state the reference reaches after exactly MAX_CYCLE_COUNT = 200 cycles (:19).
 template <class Mem>
-__device__ __forceinline__ bool subleq_simulate(int W, Mem& mem, uint16_t in_arr[8], const uint16_t tout_arr[8], uint16_t out_arr[8]) {
+__device__ __forceinline__ bool subleq_simulate(int W, Mem& mem, uint16_t in_arr[8], const uint16_t tout_arr[8], uint16_t out_arr[8],
+                                                int& bytes_used) {
     const int AMAX = W - 4, AIN = W - 3, AOUT = W - 2;  // :162-165
     const unsigned long long w4 = 0x0001000100010001ull * static_cast<unsigned long long>(W);
     Pack8 in = pack8(in_arr);
@@ -218,6 +220,7 @@ __device__ __forceinline__ bool subleq_simulate(int W, Mem& mem, uint16_t in_arr
         cycles += 1;
         const bool oob = cur + 2 >= W;  // :364-370: error, nothing else changes
         const bool ok = !oob;
+        bytes_used = (ok && cur + 3 > bytes_used) ? cur + 3 : bytes_used;  // :311 (the skipped periods revisit cursors already counted)
         const int cc = oob ? 0 : cur;
         const int a = mem.get(cc), b = mem.get(cc + 1), c = mem.get(cc + 2);
         const bool a_mem = a <= AMAX, b_mem = b <= AMAX;

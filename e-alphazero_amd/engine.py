@@ -102,6 +102,9 @@ class Context:
         return _contexts[device]
 
 
+SUBLEQ_REWARD_FNS = ("solved_or_not", "lowest_bytes")  # include/eaz.h EAZ_SUBLEQ_REWARD_*
+
+
 class EnvHandle:
     """eaz_env + batched operations on compact state blobs (uint8 [B, state_bytes] device tensors)."""
 
@@ -124,12 +127,17 @@ class EnvHandle:
         return cls(ctx, h)
 
     @classmethod
-    def subleq(cls, word_size: int, tasks: Sequence[int], use_binary_encoding: bool, device=None):
+    def subleq(cls, word_size: int, tasks: Sequence[int], use_binary_encoding: bool, device=None, reward_fn: str = "solved_or_not"):
+        """reward_fn: "solved_or_not" (subleq.py:535-537, the default of subleq.py:603) or "lowest_bytes" (:540-542)."""
         ctx = Context.get(device)
         t = np.ascontiguousarray(tasks, np.int32)
+        if reward_fn not in SUBLEQ_REWARD_FNS:
+            raise EazError(f"unknown Subleq reward function {reward_fn!r} (available: {', '.join(SUBLEQ_REWARD_FNS)})")
         h = C.c_void_p()
         check(_lib.load().eaz_env_create_subleq(ctx.h, word_size, t.ctypes.data_as(C.c_void_p), len(t), int(use_binary_encoding), C.byref(h)))
-        return cls(ctx, h)
+        env = cls(ctx, h)
+        check(_lib.load().eaz_env_set_subleq_reward(h, SUBLEQ_REWARD_FNS.index(reward_fn)))
+        return env
 
     @classmethod
     def connect4(cls, device=None):

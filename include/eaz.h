@@ -88,6 +88,10 @@ EAZ_API int eaz_key_fold(uint64_t key, uint32_t tag, uint64_t* out);
 EAZ_API int eaz_env_create_deepsea(eaz_ctx* ctx, int size_of_grid, const uint8_t* h_action_map /* [G*G] or NULL */, eaz_env** out);
 /* Subleq(tasks, word_size, use_binary_encoding) subleq.py:599-621 */
 EAZ_API int eaz_env_create_subleq(eaz_ctx* ctx, int word_size, const int32_t* h_tasks, int n_tasks, int use_binary_encoding, eaz_env** out);
+/* Subleq(reward_fn=...) subleq.py:603: solved_or_not (:535-537, the default) or lowest_bytes (:540-542: solved / (1 + bytes_used),
+ * bytes_used = the highest cursor + 3 any executed cycle of the three test runs reached, :311,:530).  Set before the first init / step. */
+enum { EAZ_SUBLEQ_REWARD_SOLVED_OR_NOT = 0, EAZ_SUBLEQ_REWARD_LOWEST_BYTES = 1 };
+EAZ_API int eaz_env_set_subleq_reward(eaz_env* env, int reward_fn);
 /* pgx.make("connect_four") [EXT] main.py:190-194 */
 EAZ_API int eaz_env_create_connect4(eaz_ctx* ctx, eaz_env** out);
 EAZ_API int eaz_env_destroy(eaz_env* env);

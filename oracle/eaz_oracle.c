@@ -55,6 +55,7 @@ typedef struct OEnv {
     int tasks[16];
     int binary;
     int enc_width;
+    int reward_fn; /* 0 = solved_or_not (subleq.py:535-537), 1 = lowest_bytes (:540-542) */
 } OEnv;
 
 /* compact state blobs; the observation is a pure function of these (deep_sea.py:66-70, subleq.py:697-705) */
@@ -246,16 +247,18 @@ static void o_subleq_simulate(int W, const int32_t* mem0, const int32_t* tin, co
     res->correct = !error && all_eq; /* :394 */
 }
 
-/* src/envs/subleq.py:504-532 (run_tests) + :535-537 (solved_or_not) ; writes the fields _step/_init replace */
-static void o_subleq_run_tests(int W, OSubleqState* s) {
+/* src/envs/subleq.py:504-532 (run_tests) + the reward function (:535-537 solved_or_not / :540-542 lowest_bytes);
+ * writes the fields _step/_init replace */
+static void o_subleq_run_tests(int W, int reward_fn, OSubleqState* s) {
     int32_t tin[3][O_IOLEN], tout[3][O_IOLEN];
     o_subleq_test_cases(s->task, W, tin, tout);
-    int solved = 1;
+    int solved = 1, bytes_used = 0;
     OSimResult r0;
     for (int c = 0; c < 3; ++c) {
         OSimResult r;
         o_subleq_simulate(W, s->memory, tin[c], tout[c], &r);
         solved &= r.correct;
+        if (r.bytes_used > bytes_used) bytes_used = r.bytes_used; /* :530 results.bytes_used.max() */
         if (c == 0) r0 = r;
     }
     memcpy(s->ex_in, tin[0], sizeof tin[0]);
@@ -263,7 +266,8 @@ static void o_subleq_run_tests(int W, OSubleqState* s) {
     memcpy(s->ex_in_after, r0.in_after, sizeof r0.in_after);
     memcpy(s->ex_out_after, r0.out_after, sizeof r0.out_after);
     s->solved = (uint8_t)solved;
-    s->reward = solved ? 1.0f : 0.0f;
+    /* solved.astype(f32) / (1 + bytes_used): int32 + float32 promote to float32, one correctly rounded division */
+    s->reward = reward_fn ? (solved ? 1.0f : 0.0f) / (float)(1 + bytes_used) : (solved ? 1.0f : 0.0f);
 }
 
 /* src/envs/subleq.py:623-646 (_init).  `jax.random.choice(key, tasks)` -> tasks[bits % n] with the build's RNG. */
@@ -271,7 +275,7 @@ static void o_subleq_init(const OEnv* e, OKey key, OSubleqState* s) {
     memset(s, 0, sizeof(*s));
     int idx = e->n_tasks > 1 ? (int)(o_bits(key, 0) % (uint32_t)e->n_tasks) : 0;
     s->task = e->tasks[idx];
-    o_subleq_run_tests(e->W, s);
+    o_subleq_run_tests(e->W, e->reward_fn, s);
 }
 
 /* src/envs/subleq.py:648-677 (_step); step_count already incremented */
@@ -284,7 +288,7 @@ static void o_subleq_step(const OEnv* e, OSubleqState* s, int action) {
     }
     int idx = s->step_count - 1; /* :654 */
     if (idx >= 0 && idx < W) s->memory[idx] = action;
-    o_subleq_run_tests(W, s);
+    o_subleq_run_tests(W, e->reward_fn, s);
 }
 
 /* src/envs/subleq.py:26-56 (one-hot) and :63-98 (binary) encoders, one row */
@@ -487,6 +491,13 @@ EXPORT OEnv* eazo_env_subleq(int W, const int* tasks, int n_tasks, int binary) {
     e->obs_cols = binary ? e->enc_width : W + 1;
     e->state_bytes = (int)sizeof(OSubleqState);
     return e;
+}
+
+/* Subleq(reward_fn=...) subleq.py:603: 0 = solved_or_not, 1 = lowest_bytes */
+EXPORT int eazo_env_set_subleq_reward(OEnv* e, int reward_fn) {
+    if (!e || e->kind != O_ENV_SUBLEQ || reward_fn < 0 || reward_fn > 1) return -1;
+    e->reward_fn = reward_fn;
+    return 0;
 }
 
 EXPORT OEnv* eazo_env_connect4(void) {

@@ -48,6 +48,7 @@ def lib():
         sig = {
             "eazo_env_deepsea": (vp, [i32, vp]),
             "eazo_env_subleq": (vp, [i32, vp, i32, i32]),
+            "eazo_env_set_subleq_reward": (i32, [vp, i32]),
             "eazo_env_connect4": (vp, []),
             "eazo_resnet_create": (vp, [i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
             "eazo_env_free": (None, [vp]),
@@ -141,11 +142,14 @@ class OracleEnv:
         return e
 
     @classmethod
-    def subleq(cls, W, tasks=(1,), binary=True):
+    def subleq(cls, W, tasks=(1,), binary=True, reward_fn="solved_or_not"):
+        """reward_fn: "solved_or_not" (subleq.py:535-537, the default of subleq.py:603) or "lowest_bytes" (:540-542)."""
         t = np.asarray(tasks, dtype=np.int32)
         h = lib().eazo_env_subleq(W, _p(t), len(t), int(binary))
         if not h:
             raise ValueError("invalid subleq parameters")
+        if lib().eazo_env_set_subleq_reward(h, {"solved_or_not": 0, "lowest_bytes": 1}[reward_fn]) != 0:
+            raise ValueError("invalid reward_fn")
         e = cls(h, "subleq")
         e.W = W
         return e

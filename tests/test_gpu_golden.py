@@ -567,4 +567,53 @@ def test_unsupported_shapes_fail_loudly(eaz, torch):
         engine.FCNet(env.ctx, 64, 256, 2, eaz.params.init_fc_params(64, 256, 2, seed=0), hash_off=2, hash_len=61)
     net = engine.FCNet(env.ctx, 64, 256, 2, eaz.params.init_fc_params(64, 256, 2, seed=0))
     with pytest.raises(eaz.EazError, match="observation size"):
-        engine.Search(engine.EnvHandle.deepsea(4, np.zeros((4, 4), np.uint8), device=0), net, 8, 4)
+        engine.Search(engine.EnvHandle.deepsea(4, np.zeros((4, 4), np.uint8), device=0), net, 8, 4)@pytest.mark.gpu
+@pytest.mark.parametrize("W", [16, 32])
+def test_subleq_lowest_bytes_reward(oracle, eaz, torch, W):
+    """Subleq(reward_fn=lowest_bytes) (subleq.py:540-542) on both step kernels (one wavefront per environment at word_size 16, one lane
+    otherwise): the hand-worked answers of tests/test_oracle_envs.py (1/4 for `subleq OUT IN 0`, 1/7 for the five-word program), and
+    bit-identical states against the oracle on programs built around the solving instruction at every cursor position."""
+    from e_alphazero_amd import api, engine
+    from helpers import ORACLE_SUBLEQ
+
+    IN, OUT = W - 3, W - 2
+    for prog, want in (([OUT, IN], np.float32(1.0) / np.float32(4.0)), ([0, 0, 3, OUT, IN], np.float32(1.0) / np.float32(7.0))):
+        for fn, solved_reward in (("lowest_bytes", want), ("solved_or_not", np.float32(1.0))):
+            env = engine.EnvHandle.subleq(W, (1,), True, device=0, reward_fn=fn)
+            st = env.init(4, key=1)
+            for t, word in enumerate(prog):
+                st = env.step(st, torch.full((4,), word, dtype=torch.int32, device="cuda"), key=t)
+                r = env.fields(st)["rewards"].cpu().numpy().reshape(-1)
+                assert (r == (solved_reward if t == len(prog) - 1 else 0.0)).all(), (W, prog, fn, t, r)
+    # programs `subleq 0 0 c` ... `subleq OUT IN c` at cursor c = 3 k: bytes_used = c + 3, every reachable denominator
+    env = engine.EnvHandle.subleq(W, (1,), True, device=0, reward_fn="lowest_bytes")
+    oenv = oracle.OracleEnv.subleq(W, (1,), True, reward_fn="lowest_bytes")
+    cs = [c for c in range(3, W - 6, 3)]
+    B = len(cs)
+    ost = oenv.init(B, key=(5, 0))
+    o = ost.view(ORACLE_SUBLEQ).reshape(B)
+    mem = np.zeros((B, 256), np.int32)
+    for i, c in enumerate(cs):
+        mem[i, 2] = c
+        mem[i, c], mem[i, c + 1] = OUT, IN       # word c + 2 = c arrives as the action below
+    o["memory"] = mem
+    o["step_count"] = np.array(cs) + 2
+    ost = o.view(np.uint8).reshape(B, -1)
+    st = torch.from_numpy(subleq_oracle_to_device(ost)).cuda()
+    a = np.array(cs, np.int32)
+    st = env.step(st, torch.from_numpy(a).cuda(), key=7)
+    ost = oenv.step(ost, a, key=(7, 0))
+    assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost)
+    oo = ost.view(ORACLE_SUBLEQ).reshape(B)
+    solved = oo["solved"].astype(bool)
+    assert solved.all()
+    want = np.where(solved, np.float32(1.0) / (1 + (np.array(cs) + 3)).astype(np.float32), np.float32(0.0))
+    assert np.array_equal(oo["reward"], want.astype(np.float32))
+    # the facade takes the reference's functions (or their names) and refuses anything else
+    assert api.Subleq([1], 16, api.lowest_bytes, True).reward_fn == "lowest_bytes"
+    assert api.Subleq([1], 16, use_binary_encoding=True).reward_fn == "solved_or_not"
+    with pytest.raises(eaz.EazError):
+        api.Subleq([1], 16, reward_fn=lambda r: 1.0)
+
+
+

@@ -238,3 +238,23 @@ def test_subleq_observation_layout(oracle):
     assert np.array_equal(obs[W + 8:W + 16], enc(np.full(8, W)))  # all input consumed
     assert np.array_equal(obs[W + 16:W + 24], enc(tout[0]))
     assert np.array_equal(obs[W + 24:W + 32], enc(tout[0]))        # output after == expected output
+
+
+def test_subleq_lowest_bytes_known_answers(oracle):
+    """Subleq(reward_fn=lowest_bytes), subleq.py:540-542: solved / (1 + bytes_used), bytes_used = highest cursor + 3 of any executed cycle
+    (:311), maximum over the three test runs (:530).  Hand-worked at W = 16 (IN = 13, OUT = 14):
+      [14, 13]            `subleq OUT IN 0` runs at cursor 0 only                       -> bytes_used = 3, reward 1/4
+      [0, 0, 3, 14, 13]   `subleq 0 0 3` (mem[0] = 0, jump 3) then `subleq OUT IN 0` at cursor 3, back through cursor 0
+                                                                                        -> bytes_used = 6, reward 1/7
+    and every shorter prefix of the second program is unsolved (reward 0 under either function)."""
+    W = 16
+    for prog, want in (([14, 13], np.float32(1.0) / np.float32(4.0)), ([0, 0, 3, 14, 13], np.float32(1.0) / np.float32(7.0))):
+        for fn, solved_reward in (("lowest_bytes", want), ("solved_or_not", np.float32(1.0))):
+            env = oracle.OracleEnv.subleq(W, (1,), True, reward_fn=fn)
+            st = env.init(1)
+            for t, word in enumerate(prog):
+                st = env.step(st, np.array([word], np.int32))
+                r = env.fields(st)["rewards"][0]
+                assert r == (solved_reward if t == len(prog) - 1 else 0.0), (prog, fn, t, r)
+    with pytest.raises((ValueError, KeyError)):
+        oracle.OracleEnv.subleq(W, (1,), True, reward_fn="fewest_cycles")
