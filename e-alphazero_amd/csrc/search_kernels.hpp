@@ -104,7 +104,15 @@ __global__ void __launch_bounds__(256) tree_finish_kernel(TreeDev t, int32_t* ac
 #pragma unroll
     for (int j = 0; j < APL; ++j) lmax = r.visits[j] > lmax ? r.visits[j] : lmax;
     const int maxN = gmaxi<LPT>(lmax);
-    const int action = root_pick<LPT, APL>(t, g, r, cq, static_cast<float>(maxN));
+    float r_gumbel[APL];
+    uint8_t r_invalid[APL];
+#pragma unroll
+    for (int j = 0; j < APL; ++j) {
+        const long o = static_cast<long>(g.b) * A + (g.ok[j] ? g.act[j] : 0);
+        r_gumbel[j] = t.root_gumbel[o];
+        r_invalid[j] = t.root_invalid[o];
+    }
+    const int action = root_pick<LPT, APL>(t, g, r, cq, static_cast<float>(maxN), r_gumbel, r_invalid);
     float x[APL], p[APL];
 #pragma unroll
     for (int j = 0; j < APL; ++j) x[j] = r.logits[j] + cq[j];

@@ -64,13 +64,19 @@ __device__ __forceinline__ float var_backup_update(int mode, float nvar, float c
 }
 
 // ---- cross-lane exchange ------------------------------------------------------------------------------------
-// lane ^ MASK exchange.  MASK 1 and 2 are DPP quad permutes (no LDS round trip, ~8 cycles), 4..16 ds_swizzle bit-mask
-// mode (LDS crossbar, no address VGPR), 32 falls back to ds_bpermute.  The reductions below run up to log2(LPT) of
-// these per call and several calls per tree level, so their latency is on the critical path of every simulation.
+// lane ^ MASK exchange.  MASK 1 and 2 are DPP quad permutes (no LDS round trip, ~8 cycles); 4 and 8 are two DPP moves each --
+// gfx9 has no xor-mask DPP, but i ^ 4 = quad-reverse(half-mirror(i)) (i ^ 7 ^ 3) and i ^ 8 = half-mirror(row-mirror(i)) (i ^ 15 ^ 7)
+// inside a row of 16 lanes -- instead of a ds_swizzle through the LDS crossbar (~4x the latency); 16 is ds_swizzle bit-mask mode,
+// 32 falls back to ds_bpermute.  The reductions below run up to log2(LPT) of these per call and a dozen calls per tree level, so their
+// latency is on the critical path of every simulation.
 template <int MASK>
 __device__ __forceinline__ int xor_lane_i(int v) {
     if constexpr (MASK == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
     else if constexpr (MASK == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    else if constexpr (MASK == 4)
+        return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);   // row_half_mirror, quad_perm [3,2,1,0]
+    else if constexpr (MASK == 8)
+        return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true), 0x141, 0xF, 0xF, true);  // row_mirror, row_half_mirror
     else if constexpr (MASK < 32) return __builtin_amdgcn_ds_swizzle(v, (MASK << 10) | 0x1F);  // and 0x1F, or 0, xor MASK
     else return __shfl_xor(v, MASK);
 }
@@ -286,19 +292,20 @@ __device__ __forceinline__ void qtransform(const TreeDev& t, const Group<LPT, AP
 }
 
 // mctx seq_halving.score_considered + masked_argmax [EXT] (A.2)
+// gumbel / invalid: this lane's slots of root_gumbel[b, :] / root_invalid[b, :] (loaded by the caller ahead of the walk)
 template <int LPT, int APL>
 __device__ __forceinline__ int root_pick(const TreeDev& t, const Group<LPT, APL>& g, const NodeRows<APL>& r,
-                                         const float (&cq)[APL], float considered_visit) {
+                                         const float (&cq)[APL], float considered_visit, const float (&gumbel)[APL],
+                                         const uint8_t (&invalid)[APL]) {
     const float m = g.vmax(r.logits);
     float sc[APL];
 #pragma unroll
     for (int j = 0; j < APL; ++j) {
         if (g.ok[j]) {
-            const long o = static_cast<long>(g.b) * t.A + g.act[j];
-            float s = (t.root_gumbel[o] + (r.logits[j] - m)) + cq[j];
+            float s = (gumbel[j] + (r.logits[j] - m)) + cq[j];
             s = s > -1e9f ? s : -1e9f;
             s = s + (static_cast<float>(r.visits[j]) == considered_visit ? 0.0f : -kInf);
-            sc[j] = t.root_invalid[o] ? -kInf : s;
+            sc[j] = invalid[j] ? -kInf : s;
         } else {
             sc[j] = -kInf;
         }
@@ -493,6 +500,18 @@ __device__ __forceinline__ TreeSel tree_step_body(const TreeDev& t, int sim, int
         // ---- simulate (A.4) ----------------------------------------------------------------------------------
         int node = 0, depth = 0, action = 0, nxt = 0;
         const bool need_var = beta != 0.0f;
+        // What the root's selection reads besides its rows depends on the tree id only: requested here, with the first row loads, instead
+        // of one dependent round trip each inside the root iteration.
+        float r_gumbel[APL];
+        uint8_t r_invalid[APL];
+        int lvalid0 = 0;
+#pragma unroll
+        for (int j = 0; j < APL; ++j) {
+            const long o = static_cast<long>(g.b) * A + (g.ok[j] ? g.act[j] : 0);
+            r_gumbel[j] = t.root_gumbel[o];
+            r_invalid[j] = t.root_invalid[o];
+            if (g.ok[j]) lvalid0 += 1 - static_cast<int>(r_invalid[j]);
+        }
         while (true) {
             NodeRows<APL> r;
             load_rows<LPT, APL>(t, g, node, need_var, r);
@@ -500,16 +519,16 @@ __device__ __forceinline__ TreeSel tree_step_body(const TreeDev& t, int sim, int
             qtransform<LPT, APL>(t, g, r, t.raw_values[nb + node], need_var ? t.raw_var[nb + node] : 0.0f, beta, cq);
             if (depth == 0) {
                 // gumbel_muzero_root_action_selection
-                int lvalid = 0, lsumN = 0;
+                int lsumN = 0;
 #pragma unroll
                 for (int j = 0; j < APL; ++j)
-                    if (g.ok[j]) { lvalid += 1 - static_cast<int>(t.root_invalid[static_cast<long>(g.b) * A + g.act[j]]); lsumN += r.visits[j]; }
-                const int nvalid = gsumi<LPT>(lvalid);
+                    if (g.ok[j]) lsumN += r.visits[j];
+                const int nvalid = gsumi<LPT>(lvalid0);
                 int simidx = gsumi<LPT>(lsumN);
                 const int nc = nvalid < t.max_considered ? nvalid : t.max_considered;
                 simidx = simidx > t.S - 1 ? t.S - 1 : simidx;
                 const float cvis = static_cast<float>(t.table[static_cast<long>(nc) * t.S + simidx]);
-                action = root_pick<LPT, APL>(t, g, r, cq, cvis);
+                action = root_pick<LPT, APL>(t, g, r, cq, cvis, r_gumbel, r_invalid);
             } else {
                 // gumbel_muzero_interior_action_selection
                 float x[APL], pr[APL];
