@@ -359,11 +359,14 @@ def run_rank(args):
             xargs.workload, xargs.selfplay_steps = name, xt
             wl = meas = None
             torch.cuda.empty_cache()
-            wl = build_workload(name, xargs, device, rank)
-            meas = measure(wl, xargs, rank, None, False, dev, steps=xs, warmup=xw)
-            result["extra"][name] = dict({"metric": wl["metric"], "value": wl["B"] * wl["T"] * xs / meas["dt"], "unit": "env-steps/s",
-                                          "steps": xs, "warmup": xw, "ms_per_step": 1e3 * meas["dt"] / xs,
-                                          "config": {"workload": wl["desc"]}}, **meas["fields"])
+            try:  # a side measurement must never cost the headline line
+                wl = build_workload(name, xargs, device, rank)
+                meas = measure(wl, xargs, rank, None, False, dev, steps=xs, warmup=xw)
+                result["extra"][name] = dict({"metric": wl["metric"], "value": wl["B"] * wl["T"] * xs / meas["dt"], "unit": "env-steps/s",
+                                              "steps": xs, "warmup": xw, "ms_per_step": 1e3 * meas["dt"] / xs,
+                                              "config": {"workload": wl["desc"]}}, **meas["fields"])
+            except Exception as exc:  # noqa: BLE001
+                result["extra"][name] = {"error": f"{type(exc).__name__}: {exc}"}
         wl = meas = None
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload, rank 0 at N = 1 only -------------------
