@@ -356,11 +356,10 @@ __device__ unsigned long long g_sq_stamps[16];
 
 // One environment on one wavefront: state at sp -> state at dp (environment index b of the batch: key folding and the [b] outputs).
 // `action`: the action of a plain step (wavefront-uniform).
-// index_out (optional): the caller looks the novelty up itself (subleq16_novelty) from the hash index left there.
 __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* sp, char* dp, const int b, const int lane, const int action,
                                                    const int mode, const Key key_arg, const Key* key_ptr, char* out_copy, float* next_reward,
                                                    uint8_t* next_term, uint8_t* next_legal, const int mem_copy, uint8_t* obs_out,
-                                                   const NoveltyFuse& nf, uint32_t* index_out = nullptr) {
+                                                   const NoveltyFuse& nf) {
     constexpr int W = 16;
     EAZ_WSTAMP(0);
     const bool copy_mem = reinterpret_cast<const void*>(sp) != reinterpret_cast<const void*>(dp);
@@ -515,8 +514,7 @@ __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* 
             h += 40u;  // :226 (stripe count)
             h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;  // :190-197
             const uint32_t index = h >> (32 - nf.hash_bits);             // :229
-            if (index_out) { if (lane == 0) *index_out = index; }
-            else if (lane == 0) subleq16_novelty(nf, b, index);
+            if (lane == 0) subleq16_novelty(nf, b, index);
         }
     }
     EAZ_WSTAMP(6);
