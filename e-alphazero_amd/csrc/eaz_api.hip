@@ -962,8 +962,8 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
             }
         }
 #ifdef EAZ_FC_STAMPS
-        DALLOC(s->d_stamps, 256 * 32);
-        HIP_OK(hipMemset(s->d_stamps, 0, 256 * 32 * sizeof(unsigned long long)));
+        DALLOC(s->d_stamps, 2 * 256 * 32);  // [256][32] phase stamps + [256][8 waves][4] interpreter-phase stamps (search_subleq.hpp)
+        HIP_OK(hipMemset(s->d_stamps, 0, 2 * 256 * 32 * sizeof(unsigned long long)));
 #endif
     }
     *out = s;
@@ -1696,6 +1696,11 @@ extern "C" int eaz_random_play(eaz_env* env, int B, int T, uint64_t key, void* d
 extern "C" __attribute__((visibility("default"))) int eaz_diag_tree_stamps(unsigned long long* h_out /* [1024*8] */) {
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_tree_stamps), sizeof(unsigned long long) * 1024 * 8));
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int eaz_diag_persist_stamps2(eaz_search* s, unsigned long long* h_out /* [256*32] */) {
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(h_out, s->d_stamps + 256 * 32, sizeof(unsigned long long) * 256 * 32, hipMemcpyDeviceToHost));
     return 0;
 }
 extern "C" __attribute__((visibility("default"))) int eaz_diag_persist_stamps(eaz_search* s, unsigned long long* h_out /* [256*32] */) {

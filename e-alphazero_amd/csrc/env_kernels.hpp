@@ -233,39 +233,45 @@ __global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src,
 // ---- Subleq, word_size 16: one wavefront per environment -----------------------------------------------------------------
 // A launch of the per-lane kernel above lasts as long as the slowest interpreter run in the batch, a few programs in every
 // thousand run all 200 cycles, and a VALU cycle body costs ~450 clocks of a lone wavefront.  Here the machine state of ONE
-// environment lives in scalar registers (cursor, counters, flags) and in the lanes of three VGPRs (lane l of `vmem` = program word l,
-// lanes 0..7 of `vin` / `vout` = the IO buffers): an operand fetch is a v_readlane, the write-back a compare-and-select on the lane id, everything else
-// SALU, the branches are real (no divergence: one program per wavefront), and the memory comparison of the periodicity test is one
-// v_cmp.  Results are bit-identical to subleq_simulate (same test suite); the state / observation stores use the 64 lanes.
+// environment is wavefront-uniform, i.e. lives in scalar registers: the sixteen 4-bit words of the program as ONE 64-bit value (an
+// operand fetch is a scalar shift + mask, the write-back a scalar bit-field insert), the cursor, counters and flags; the branches
+// are real (no divergence: one program per wavefront) and the memory comparison of the periodicity test is one 64-bit compare.  Only
+// the IO buffers, which few cycles touch, sit in the lanes of VGPRs (lanes 0..7 of `vin` / `vout`, v_readlane / select on the lane id).
+// (A first version kept the program in the lanes of a VGPR too: five v_readlane per cycle, each a VALU -> SGPR round trip in the
+// cycle's dependency chain, 260 clocks per cycle.)  Results are bit-identical to subleq_simulate (same test suite); the state /
+// observation stores use the 64 lanes.
 __device__ __forceinline__ int sq_rl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 
-// subleq.py:297-398 `simulate` for one environment per wavefront.  vmem: lane l < 16 = word l (< 16).  vin / vtout: lane l = input l /
-// expected output l, W in every lane beyond the valid ones.  Returns `correct`; v_in_after / v_out: lanes 0..7 = input_after /
+// subleq.py:297-398 `simulate` for one environment per wavefront.  smem: word l (< 16) in bits 4 l .. 4 l + 3.  vin / vtout: lane l =
+// input l / expected output l, W in every lane beyond the valid ones.  Returns `correct`; v_in_after / v_out: lanes 0..7 = input_after /
 // output_after.  The inner loop runs the cycles that touch memory words only (both operand addresses <= ADDRESS_MAX, cursor in
 // bounds): nothing of the IO state moves there, `all_eq` (:341) included, so halting is folded into the cycle increment `inc`.
-// Brent snapshots (iterations 1, 2, 4, ...; any growing schedule is exact) hold the memory in `vsnap` and the cursor in `s_cur`; an
+// Brent snapshots (iterations 1, 2, 4, ...; any growing schedule is exact) hold the memory in `ssnap` and the cursor in `s_cur`; an
 // IO event invalidates the snapshot (the input cursor and the output only move forward, so the state before it cannot recur).
-__device__ __forceinline__ bool subleq16_wave_run(int vmem, const int vin, const int vtout, const int lane, int& v_in_after, int& v_out,
-                                                  int& bytes_used) {
+__device__ __forceinline__ bool subleq16_wave_run(unsigned long long smem, const int vin, const int vtout, const int lane, int& v_in_after,
+                                                  int& v_out, int& bytes_used) {
     constexpr int W = 16, AMAX = 12, AIN = 13, AOUT = 14, kStop = 1000;
-    int vout = W, vsnap = -1;
+    int vout = W;
+    unsigned long long ssnap = 0ull;
     int cur = 0, cycles = 0, in_cur = 0, out_cursor = 0, top_cur = -3;  // top_cur: highest cursor of an executed cycle (:311)
     int s_cur = -1, s_cycle = 0, it = 0, next_snap = 1;
     int error = 0;
     int inc = (__builtin_amdgcn_ballot_w64(vout == vtout) & 0xFFull) == 0xFFull ? kStop : 1;  // :341 halts
+    auto word = [&](int i) { return static_cast<int>(smem >> (4 * i)) & 15; };
+    auto store = [&](int i, int v) { smem = (smem & ~(15ull << (4 * i))) | (static_cast<unsigned long long>(v) << (4 * i)); };
     // end of a cycle (:297-299 MAX_CYCLE_COUNT = 200): count it, close a period (state == snapshot => periodic with period
     // cycles - s_cycle; whole periods are skipped), snapshot
     auto cycle_end = [&]() {
         cycles += inc;
         it += 1;
         if (cur == s_cur) {
-            if (cycles < 200 && (__builtin_amdgcn_ballot_w64(vmem == vsnap) & 0xFFFFull) == 0xFFFFull) {
+            if (cycles < 200 && smem == ssnap) {
                 const int p = cycles - s_cycle;
                 cycles += ((200 - cycles) / p) * p;
             }
         }
         if (it == next_snap) {
-            vsnap = vmem; s_cur = cur; s_cycle = cycles;
+            ssnap = smem; s_cur = cur; s_cycle = cycles;
             next_snap *= 2;
         }
     };
@@ -276,10 +282,11 @@ __device__ __forceinline__ bool subleq16_wave_run(int vmem, const int vin, const
             oob = cur >= W - 2;  // :364-370
             if (oob) break;
             top_cur = max(top_cur, cur);
-            a = sq_rl(vmem, cur); b = sq_rl(vmem, cur + 1); c = sq_rl(vmem, cur + 2);
+            const unsigned t = static_cast<unsigned>(smem >> (4 * cur));
+            a = t & 15; b = (t >> 4) & 15; c = (t >> 8) & 15;
             if (max(a, b) > AMAX) break;
-            const int v = (sq_rl(vmem, a) - sq_rl(vmem, b)) & 15;  // :322
-            vmem = lane == a ? v : vmem;
+            const int v = (word(a) - word(b)) & 15;  // :322
+            store(a, v);
             cur = static_cast<unsigned>(v - 1) >= 7u ? c : cur + 3;  // :329-330 jump when value == 0 or 2 * value >= 16
             cycle_end();
             if (cycles >= 200) break;
@@ -291,8 +298,8 @@ __device__ __forceinline__ bool subleq16_wave_run(int vmem, const int vin, const
         const int in0 = sq_rl(vin, in_cur);
         const bool in_ok = in0 < W;
         int ra = 0, rb = 0;
-        if (a <= AMAX) ra = sq_rl(vmem, a); else if (a == AIN && in_ok) ra = in0;
-        if (b <= AMAX) rb = sq_rl(vmem, b); else if (b == AIN && in_ok) rb = in0;
+        if (a <= AMAX) ra = word(a); else if (a == AIN && in_ok) ra = in0;
+        if (b <= AMAX) rb = word(b); else if (b == AIN && in_ok) rb = in0;
         const int v = (ra - rb) & 15;
         const bool uses_in = a == AIN || b == AIN;
         if (uses_in) {
@@ -310,7 +317,7 @@ __device__ __forceinline__ bool subleq16_wave_run(int vmem, const int vin, const
                 if ((__builtin_amdgcn_ballot_w64(vout == vtout) & 0xFFull) == 0xFFull) inc = kStop;
             }
         } else if (a <= AMAX) {
-            vmem = lane == a ? v : vmem;
+            store(a, v);
         }
         cur = static_cast<unsigned>(v - 1) >= 7u ? c : cur + 3;
         if (error) break;
@@ -425,7 +432,20 @@ __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* 
     int bytes_used = 0;
     if (run) {
         all_correct = true;
-        const int vmem = lane < W ? (mem_raw & 15) : 0;
+        // the program as sixteen nibbles of one scalar 64-bit value: bytes & 15 of lane 0's (patched) first memory chunk
+        unsigned long long smem = 0ull;
+        {
+            const uint32_t cw[4] = {static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(chunk.x), 0)),
+                                    static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(chunk.y), 0)),
+                                    static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(chunk.z), 0)),
+                                    static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(chunk.w), 0))};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t w = cw[i];
+                const uint32_t n4 = (w & 0xFu) | ((w >> 4) & 0xF0u) | ((w >> 8) & 0xF00u) | ((w >> 12) & 0xF000u);
+                smem |= static_cast<unsigned long long>(n4) << (16 * i);
+            }
+        }
         for (int c = 0; c < 3 && all_correct; ++c) {  // subleq.py:511 vmap; `solved` is the AND (:525), only case 0 feeds the state
             uint16_t tin[8], tout[8];
             subleq_test_case(task, c, W, tin, tout);
@@ -434,7 +454,7 @@ __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* 
             for (int i = 0; i < 8; ++i) { vin = lane == i ? tin[i] : vin; vtout = lane == i ? tout[i] : vtout; }
             int v_after, v_out;
             int bytes_c;
-            const bool correct = subleq16_wave_run(vmem, vin, vtout, lane, v_after, v_out, bytes_c);
+            const bool correct = subleq16_wave_run(smem, vin, vtout, lane, v_after, v_out, bytes_c);
             bytes_used = max(bytes_used, bytes_c);  // :530 results.bytes_used.max()
             if (c == 0) { n_exin = vin; n_exout = vtout; n_exinaf = v_after; n_exoutaf = v_out; }
             all_correct = correct;

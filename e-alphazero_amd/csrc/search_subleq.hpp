@@ -53,8 +53,19 @@ struct Sq16SearchArgs {
         }                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                             \
     } while (0)
+#define EAZ_ESTAMP(i)                                                                                  \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        if (dg.stamps && s == dg.n_sims / 2 && (tid & 63) == 0 && blockIdx.x < 256) {                  \
+            unsigned long long t_;                                                                     \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+            dg.stamps[256 * 32 + blockIdx.x * 32 + (tid >> 6) * 4 + (i)] = t_;                         \
+        }                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    } while (0)
 #else
 #define EAZ_QSTAMP(i)
+#define EAZ_ESTAMP(i)
 #endif
 
 constexpr int kSqWaves = 8;     // 2 per SIMD (<= 256 registers each): T on waves 0-3, E on all, F = one head per 4 waves at a time
@@ -110,6 +121,7 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
             const int lane = phase_tid() & 63;
             const int B = a->t.B, N = a->t.N, sb = a->t.state_bytes;
             char* emb = a->t.embeddings;
+            EAZ_ESTAMP(0);
 #pragma unroll 1
             for (int j = wave; j < 16; j += kSqWaves) {
                 const int b = b0 + j;
@@ -120,6 +132,7 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
                     subleq16_wave_body(a->e, base + static_cast<long>(node) * sb, base + static_cast<long>(dst) * sb, b, lane, action, 0, Key{0, 0},
                                        nullptr, nullptr, a->next_reward, a->next_term, a->next_legal, 16, a->obs, a->nf);
                 }
+                EAZ_ESTAMP(j < kSqWaves ? 1 : 2);
             }
         }
         EAZ_QSTAMP(3);

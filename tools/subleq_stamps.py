@@ -77,3 +77,16 @@ seg("expand: loads + new node stores", tb[:, 1] - tb[:, 0])
 seg("backward", tb[:, 2] - tb[:, 1])
 seg("select walk", tb[:, 3] - tb[:, 2])
 seg("result stores", tb[:, 4] - tb[:, 3])
+
+# interpreter phase per wave (8 waves x [start, after its first environment, after its second])
+lib.eaz_diag_persist_stamps2.argtypes = [C.c_void_p, C.c_void_p]
+eb = np.zeros(256 * 32, np.uint64)
+lib.eaz_diag_persist_stamps2(search.h, eb.ctypes.data)
+eb = eb.reshape(256, 8, 4).astype(np.int64)
+eb = eb[eb[:, 0, 0] > 0]
+print("interpreter phase, all 8 waves of every workgroup:")
+seg("first environment of a wave", (eb[:, :, 1] - eb[:, :, 0]).reshape(-1))
+seg("second environment of a wave", (eb[:, :, 2] - eb[:, :, 1]).reshape(-1))
+seg("slowest wave of the workgroup (both)", (eb[:, :, 2] - eb[:, :, 0]).max(axis=1))
+seg("fastest wave of the workgroup (both)", (eb[:, :, 2] - eb[:, :, 0]).min(axis=1))
+seg("slowest single environment of the workgroup", np.maximum(eb[:, :, 1] - eb[:, :, 0], eb[:, :, 2] - eb[:, :, 1]).max(axis=1))
