@@ -944,7 +944,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
         // Subleq-16 one-launch search (search_subleq.hpp): two forward tile sets = 76 KB of dynamic LDS (eligibility is re-checked per run)
         if (env->dev.kind == EAZ_ENV_SUBLEQ && env->dev.W == 16 && net->kind == 0 && fp_eligible(net->dev.in_dim, net->dev.A))
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(subleq16_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kSqHeadGroups * fp_lds_bytes(net->dev.in_dim, net->dev.A)));
+                                       sq16_lds_bytes(net->dev.in_dim, net->dev.A, kSqHeadGroups)));
         // two half-batches on two streams where the env step is the interpreter (Subleq) and the batch is big enough to split
         s->ev_shard_fork = s->ev_shard_join = nullptr;
         int want = g_shards ? g_shards : (env->dev.kind == EAZ_ENV_SUBLEQ && B >= 2048 ? 4 : (env->dev.kind == EAZ_ENV_SUBLEQ && B >= 1024 ? 2 : 1));
@@ -1067,7 +1067,7 @@ static int sq16_persist_launch(eaz_search* s, int sim0, int n_sims, bool expand_
     a.nf = NoveltyFuse{a.net.bitset, s->d_novelty, a.net.hash_bits, a.net.nov_scale};
     a.sim0 = sim0; a.n_sims = n_sims; a.expand_first = expand_first; a.expand_last = expand_last;
     a.stamps = s->d_stamps;
-    subleq16_search_kernel<<<cdiv(s->B, 16), kSqThreads, kSqHeadGroups * fp_lds_bytes(a.net.in_dim, a.net.A), st>>>(a);
+    subleq16_search_kernel<<<cdiv(s->B, 16), kSqThreads, sq16_lds_bytes(a.net.in_dim, a.net.A, kSqHeadGroups), st>>>(a);
     LAUNCH_OK();
     return 0;
 }

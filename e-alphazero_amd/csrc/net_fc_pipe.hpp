@@ -25,19 +25,48 @@ __host__ __device__ inline int fp_lds_bytes(int K, int A) {
     const int x = fp_xfloats(K) * 4;
     return (x > kF16HBytes ? x : kF16HBytes) + kF16HBytes + 4 * 16 * 16 * 4;
 }
+// dynamic LDS of subleq16_search_kernel (search_subleq.hpp): the forward tiles of its head groups + the shared observation tile
+__host__ __device__ inline int sq16_lds_bytes(int in_dim, int A, int head_groups) { return head_groups * fp_lds_bytes(in_dim, A) + fp_xfloats(in_dim) * 4; }
 __host__ inline bool fp_eligible(int in_dim, int A) { return in_dim <= kFpMaxK && A <= kFcW3Cols && kPsDepth == 16; }
 
 // grid = (row tiles, heads): one workgroup = 16 rows x one head (40 KB of LDS at the C3 shape, 148 VGPRs: three workgroups per CU, whose
 // barriers / staging / layer-3 chains overlap each other's MFMA streams)
 // The forward of head `head` for the 16 rows from `row0` on, by 256 threads `tid` = 0..255 (three workgroup barriers; `lds` = fp_lds_bytes).
 // Called once per workgroup by fc16p_forward_kernel and once per head and simulation by the persistent Subleq search kernel.
+// fp_convert_tile: the uint8 observation rows row0 .. row0 + 15 -> the f32 K-major tile X (the MFMA A-operand layout of the hidden tiles),
+// zero beyond in_dim / beyond the batch; `nthreads` threads `tid` share the work.  fc16p_body does it itself unless the caller hands it a
+// tile (Xshared): the persistent Subleq search converts the 16 new rows once per simulation for all three heads.
+__device__ __forceinline__ void fp_convert_tile(const uint8_t* __restrict__ obs, const int B, const int K1, const int row0, float* X, const int tid,
+                                                const int nthreads) {
+    const int Kp = fp_kpad(K1);
+    if ((K1 & 15) == 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0) {
+        const int cpr = Kp >> 4, nch = kF16M * cpr;
+        for (int c = tid; c < nch; c += nthreads) {
+            const int row = c / cpr, k0 = (c - row * cpr) << 4;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (row0 + row < B && k0 < K1) v = *reinterpret_cast<const uint4*>(obs + static_cast<long>(row0 + row) * K1 + k0);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) X[h16_off(k0 + i, row)] = static_cast<float>((w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+        }
+    } else {
+        for (int row = 0; row < kF16M; ++row) {
+            const bool rok = row0 + row < B;
+            const uint8_t* orow = obs + static_cast<long>(rok ? row0 + row : 0) * K1;
+            for (int k = tid; k < Kp; k += nthreads) X[h16_off(k, row)] = (rok && k < K1) ? static_cast<float>(orow[k]) : 0.0f;
+        }
+    }
+}
+
 __device__ __forceinline__ void fc16p_body(const NetDev& net, const uint8_t* __restrict__ obs, const int B, const NetOut& out, const int head,
-                                           const int row0, uint8_t* lds, const int tid, unsigned long long* kstep_counter) {
+                                           const int row0, uint8_t* lds, const int tid, unsigned long long* kstep_counter,
+                                           const float* Xshared = nullptr) {
     const int K1 = net.in_dim, Kp = fp_kpad(K1);
-    float* X = reinterpret_cast<float*>(lds);
-    float* H2 = X;  // aliases the observation tile
+    float* Xown = reinterpret_cast<float*>(lds);
+    const float* X = Xshared ? Xshared : Xown;
+    float* H2 = Xown;  // aliases the workgroup's own observation tile (dead once layer 1 is done); a shared tile is left alone
     const int xf = fp_xfloats(K1) > kF16HFloats ? fp_xfloats(K1) : kF16HFloats;
-    float* H1 = X + xf;
+    float* H1 = Xown + xf;
     float* part = H1 + kF16HFloats;      // [4 waves][16 rows][16 outputs]
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 15, kq = lane >> 4;
     const int n0 = wave * 64, col = n0 + 4 * r, voff = (kq * kFcH + col) * 4;
@@ -59,7 +88,10 @@ __device__ __forceinline__ void fc16p_body(const NetDev& net, const uint8_t* __r
     const int erow = tid & 15, eo = tid >> 4;
     const float b3v = pb3[eo < No ? eo : 0];
     // observation tile -> f32, K-major (the MFMA A-operand layout of the hidden tiles), zero beyond in_dim / beyond the batch
-    if ((K1 & 15) == 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0) {
+    if (Xshared) {
+#pragma unroll
+        for (int i = 0; i < kPsDepth; ++i) Bq[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs1, voff, i * 4096, 0));
+    } else if ((K1 & 15) == 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0) {
         // 16 bytes per load: chunk c of the tile = row c / (Kp / 16), inputs 16 (c % (Kp / 16)) .. +15
         const int cpr = Kp >> 4, nch = kF16M * cpr;
         auto chunk_load = [&](int c) {
@@ -73,7 +105,7 @@ __device__ __forceinline__ void fc16p_body(const NetDev& net, const uint8_t* __r
             const int row = c / cpr, k0 = (c - row * cpr) << 4;
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int i = 0; i < 16; ++i) X[h16_off(k0 + i, row)] = static_cast<float>((w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+            for (int i = 0; i < 16; ++i) Xown[h16_off(k0 + i, row)] = static_cast<float>((w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
         };
         const uint4 v0 = chunk_load(tid);
         // the weight stream's first 16 k-steps go out BEHIND the tile / constant loads: vmcnt is in order, and the tile must not wait for
@@ -88,7 +120,7 @@ __device__ __forceinline__ void fc16p_body(const NetDev& net, const uint8_t* __r
         for (int row = 0; row < kF16M; ++row) {
             const bool rok = row0 + row < B;
             const uint8_t* orow = obs + static_cast<long>(rok ? row0 + row : 0) * K1;
-            for (int k = tid; k < Kp; k += 256) X[h16_off(k, row)] = (rok && k < K1) ? static_cast<float>(orow[k]) : 0.0f;
+            for (int k = tid; k < Kp; k += 256) Xown[h16_off(k, row)] = (rok && k < K1) ? static_cast<float>(orow[k]) : 0.0f;
         }
     }
     __syncthreads();  // X

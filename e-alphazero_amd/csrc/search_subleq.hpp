@@ -142,10 +142,16 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
         EAZ_QSTAMP(4);
         {
             SqArgsPtr a = sq_args();
-            const int hg = wave >> 2, pt = phase_tid() & 255;
+            const int ft = phase_tid();
+            const int hg = wave >> 2, pt = ft & 255;
+            // the 16 new observation rows as ONE f32 tile for all three heads (behind the head groups' own tiles); the first barrier of
+            // the bodies below publishes it
+            float* Xs = reinterpret_cast<float*>(lds + kSqHeadGroups * fp_lds_bytes(240, 16));
+            fp_convert_tile(a->obs, a->t.B, a->net.in_dim, b0, Xs, ft, kSqThreads);
 #pragma unroll 1
             for (int h0 = 0; h0 < a->heads.n; h0 += kSqHeadGroups) {
-                if (h0 + hg < a->heads.n) fc16p_body(a->net, a->obs, a->t.B, a->out, a->heads.id[h0 + hg], b0, lds + hg * fp_lds_bytes(240, 16), pt, nullptr);
+                if (h0 + hg < a->heads.n)
+                    fc16p_body(a->net, a->obs, a->t.B, a->out, a->heads.id[h0 + hg], b0, lds + hg * fp_lds_bytes(240, 16), pt, nullptr, Xs);
                 else { __syncthreads(); __syncthreads(); __syncthreads(); }  // the three barriers of fc16p_body
             }
         }
