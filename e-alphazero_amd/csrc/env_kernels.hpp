@@ -366,7 +366,7 @@ __device__ unsigned long long g_sq_stamps[16];
 __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* sp, char* dp, const int b, const int lane, const int action,
                                                    const int mode, const Key key_arg, const Key* key_ptr, char* out_copy, float* next_reward,
                                                    uint8_t* next_term, uint8_t* next_legal, const int mem_copy, uint8_t* obs_out,
-                                                   const NoveltyFuse& nf) {
+                                                   const NoveltyFuse& nf, uint8_t* words_out = nullptr) {
     constexpr int W = 16;
     EAZ_WSTAMP(0);
     const bool copy_mem = reinterpret_cast<const void*>(sp) != reinterpret_cast<const void*>(dp);
@@ -495,7 +495,17 @@ __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* 
         if (next_legal) *reinterpret_cast<uint4*>(next_legal + static_cast<long>(b) * 16) = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);  // all legal (subleq.py:626)
     }
     EAZ_WSTAMP(4);
-    if (obs_out) {
+    if (words_out) {
+        // the caller builds the observation and its hash from the 48 row-words itself (subleq16_search_kernel: straight into the forward's
+        // tile, the hash on lanes that would otherwise idle): lane w < 48 leaves row-word w (memory | input | input_after | output |
+        // output_after, subleq.py:679-707) as the five bits its observation bytes are made of
+        const int src_lane = lane & 7;
+        const int r0 = __shfl(n_exin, src_lane), r1 = __shfl(n_exinaf, src_lane), r2 = __shfl(n_exout, src_lane), r3 = __shfl(n_exoutaf, src_lane);
+        const int row = (lane - 16) >> 3;
+        const uint32_t v = lane < 16 ? static_cast<uint32_t>(mem_raw) : (row == 0 ? r0 : row == 1 ? r1 : row == 2 ? r2 : r3) & 0xFFFFu;
+        // bits 0..3 = v mod 16, bit 4 = (v == 16): everything the five observation bytes of a word are made of
+        if (lane < 48) words_out[lane] = static_cast<uint8_t>((v & 15u) | (v == 16u ? 16u : 0u));
+    } else if (obs_out) {
         // binary encoding: the 48 x 5 observation (subleq.py:679-707 rows = memory | input | input_after | output | output_after;
         // :88-98 columns = 4 little-endian bits of v mod 16, then v == 16); lane w < 48 holds row-word w and stores its 5 bytes
         const int src_lane = lane & 7;

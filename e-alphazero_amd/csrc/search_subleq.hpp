@@ -86,6 +86,7 @@ __device__ __forceinline__ SqArgsPtr sq_args() {
 __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchArgs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ int sel_node[16], sel_action[16], sel_dst[16];
+    __shared__ __attribute__((aligned(16))) uint8_t sq_words[16][48];  // row-words of the 16 new states, 5 observation bits each
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * 16;
     // every phase derives its lane roles from a thread id the compiler cannot trace to threadIdx: otherwise the address arithmetic and
@@ -95,6 +96,11 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
     {
         SqArgsPtr a = sq_args();
         n_sims = a->n_sims; sim0 = a->sim0; expand_first = a->expand_first; expand_last = a->expand_last;
+    }
+    {
+        // inputs 240 .. 255 of the shared observation tile stay zero for the whole launch (layer 1 runs whole rounds of 16 k-steps)
+        float* Xs = reinterpret_cast<float*>(lds + kSqHeadGroups * fp_lds_bytes(240, 16));
+        for (int idx = tid; idx < 16 * 16; idx += kSqThreads) Xs[h16_off(240 + (idx >> 4), idx & 15)] = 0.0f;
     }
 #ifdef EAZ_FC_STAMPS
     struct { unsigned long long* stamps; int n_sims; } dg{sq_args()->stamps, n_sims};  // what EAZ_QSTAMP names
@@ -130,7 +136,7 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
                     const int dst = __builtin_amdgcn_readfirstlane(sel_dst[j]);
                     char* base = emb + static_cast<long>(b) * N * sb;
                     subleq16_wave_body(a->e, base + static_cast<long>(node) * sb, base + static_cast<long>(dst) * sb, b, lane, action, 0, Key{0, 0},
-                                       nullptr, nullptr, a->next_reward, a->next_term, a->next_legal, 16, a->obs, a->nf);
+                                       nullptr, nullptr, a->next_reward, a->next_term, a->next_legal, 16, nullptr, a->nf, &sq_words[j][0]);
                 }
                 EAZ_ESTAMP(j < kSqWaves ? 1 : 2);
             }
@@ -144,15 +150,48 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
             SqArgsPtr a = sq_args();
             const int ft = phase_tid();
             const int hg = wave >> 2, pt = ft & 255;
-            // the 16 new observation rows as ONE f32 tile for all three heads (behind the head groups' own tiles); the first barrier of
-            // the bodies below publishes it
+            // the 16 new observations as ONE f32 tile for all three heads, straight from the row-words the interpreters left in LDS
+            // (element (5 w + j, row) = bit j of word w: subleq.py:88-98); the first barrier of the bodies below publishes it.  The
+            // observation rows never go through memory.
             float* Xs = reinterpret_cast<float*>(lds + kSqHeadGroups * fp_lds_bytes(240, 16));
-            fp_convert_tile(a->obs, a->t.B, a->net.in_dim, b0, Xs, ft, kSqThreads);
+            for (int idx = ft; idx < 16 * 48; idx += kSqThreads) {
+                const int row = idx / 48, w = idx - row * 48;
+                const uint32_t code = sq_words[row][w];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) Xs[h16_off(5 * w + j, row)] = (code >> j) & 1u ? 1.0f : 0.0f;
+            }
 #pragma unroll 1
             for (int h0 = 0; h0 < a->heads.n; h0 += kSqHeadGroups) {
-                if (h0 + hg < a->heads.n)
+                if (h0 + hg < a->heads.n) {
                     fc16p_body(a->net, a->obs, a->t.B, a->out, a->heads.id[h0 + hg], b0, lds + hg * fp_lds_bytes(240, 16), pt, nullptr, Xs);
-                else { __syncthreads(); __syncthreads(); __syncthreads(); }  // the three barriers of fc16p_body
+                } else {
+                    // this head group has no head left: one of its waves looks the 16 observations' novelty up meanwhile (XXHash variant,
+                    // hashes.py:162-229: lane = (environment, stripe), stripe i = IO row i = 8 words x 5 bytes that are 0 or 1)
+                    if ((wave & 3) == 0) {
+                        const uint32_t P1 = 0x9E3779B1u, P2 = 0x85EBCA77u, P3 = 0xC2B2AE3Du, SEED = 1u, ONE = 0x3F800000u * P2;
+                        const int lane = ft & 63, e = lane >> 2, i = lane & 3;
+                        uint32_t acc = i == 0 ? SEED + P1 + P2 : (i == 1 ? SEED + P2 : (i == 2 ? SEED : SEED - P1));  // :217-220
+                        const uint2 ww = *reinterpret_cast<const uint2*>(&sq_words[e][16 + 8 * i]);
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) {
+                            const uint32_t code = ((w < 4 ? ww.x : ww.y) >> (8 * (w & 3))) & 0xFFu;
+#pragma unroll
+                            for (int j = 0; j < 5; ++j) {
+                                const uint32_t t = acc + ((code >> j) & 1u ? ONE : 0u);
+                                acc = ((t << 13) | (t >> 19)) * P1;  // :176-181
+                            }
+                        }
+                        const int rot = i == 0 ? 1 : (i == 1 ? 7 : (i == 2 ? 12 : 18));  // :184-187
+                        uint32_t h = (acc << rot) | (acc >> (32 - rot));
+                        h += __shfl_xor(h, 1);
+                        h += __shfl_xor(h, 2);
+                        h += 40u;  // :226 (stripe count)
+                        h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;  // :190-197
+                        const uint32_t index = h >> (32 - a->nf.hash_bits);          // :229
+                        if (i == 0 && b0 + e < a->t.B) subleq16_novelty(a->nf, b0 + e, index);
+                    }
+                    __syncthreads(); __syncthreads(); __syncthreads();  // the three barriers of fc16p_body
+                }
             }
         }
         EAZ_QSTAMP(5);
