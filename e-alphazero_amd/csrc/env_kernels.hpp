@@ -345,7 +345,8 @@ __device__ __forceinline__ void subleq16_novelty(const NoveltyFuse& nf, const in
 }
 
 #ifdef EAZ_FC_STAMPS
-// Diagnostic build only: shader-clock stamps inside the last subleq16_wave_body call of workgroup 0, wave 0 (tools/subleq_stamps.py)
+// Diagnostic build only: shader-clock time between the stamps inside subleq16_wave_body, summed over every call of workgroup 0's
+// first wave ([i] = cycles between stamp i and i + 1, [15] = calls; tools/subleq_stamps.py)
 __device__ unsigned long long g_sq_stamps[16];
 #define EAZ_WSTAMP(i)                                                                                  \
     do {                                                                                               \
@@ -353,12 +354,15 @@ __device__ unsigned long long g_sq_stamps[16];
         if (blockIdx.x == 0 && threadIdx.x == 0) {                                                     \
             unsigned long long t_;                                                                     \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
-            g_sq_stamps[i] = t_;                                                                       \
+            if ((i) > 0) g_sq_stamps[(i)-1] += t_ - wst_prev; else g_sq_stamps[15] += 1;               \
+            wst_prev = t_;                                                                             \
         }                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                             \
     } while (0)
+#define EAZ_WSTAMP_DECL unsigned long long wst_prev = 0
 #else
 #define EAZ_WSTAMP(i)
+#define EAZ_WSTAMP_DECL
 #endif
 
 // One environment on one wavefront: state at sp -> state at dp (environment index b of the batch: key folding and the [b] outputs).
@@ -368,6 +372,7 @@ __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* 
                                                    uint8_t* next_term, uint8_t* next_legal, const int mem_copy, uint8_t* obs_out,
                                                    const NoveltyFuse& nf, uint8_t* words_out = nullptr) {
     constexpr int W = 16;
+    EAZ_WSTAMP_DECL;
     EAZ_WSTAMP(0);
     const bool copy_mem = reinterpret_cast<const void*>(sp) != reinterpret_cast<const void*>(dp);
     // ---- the source state, lane-distributed: header (uniform), IO rows (lanes 0..7), memory bytes (lanes 0..15) and the
@@ -497,14 +502,17 @@ __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* 
     EAZ_WSTAMP(4);
     if (words_out) {
         // the caller builds the observation and its hash from the 48 row-words itself (subleq16_search_kernel: straight into the forward's
-        // tile, the hash on lanes that would otherwise idle): lane w < 48 leaves row-word w (memory | input | input_after | output |
-        // output_after, subleq.py:679-707) as the five bits its observation bytes are made of
-        const int src_lane = lane & 7;
-        const int r0 = __shfl(n_exin, src_lane), r1 = __shfl(n_exinaf, src_lane), r2 = __shfl(n_exout, src_lane), r3 = __shfl(n_exoutaf, src_lane);
-        const int row = (lane - 16) >> 3;
-        const uint32_t v = lane < 16 ? static_cast<uint32_t>(mem_raw) : (row == 0 ? r0 : row == 1 ? r1 : row == 2 ? r2 : r3) & 0xFFFFu;
-        // bits 0..3 = v mod 16, bit 4 = (v == 16): everything the five observation bytes of a word are made of
-        if (lane < 48) words_out[lane] = static_cast<uint8_t>((v & 15u) | (v == 16u ? 16u : 0u));
+        // tile, the hash on lanes that would otherwise idle): row-word w (memory | input | input_after | output | output_after,
+        // subleq.py:679-707) as the five bits its observation bytes are made of -- bits 0..3 = v mod 16, bit 4 = (v == 16).  Stored by the
+        // lanes that hold the values (no shuffles: the rows live on lanes 0..7, the memory words on lanes 0..15).
+        auto code = [](uint32_t v) { return static_cast<uint8_t>((v & 15u) | (v == 16u ? 16u : 0u)); };
+        if (lane < 16) words_out[lane] = code(static_cast<uint32_t>(mem_raw));
+        if (lane < 8) {
+            words_out[16 + lane] = code(static_cast<uint32_t>(n_exin) & 0xFFFFu);
+            words_out[24 + lane] = code(static_cast<uint32_t>(n_exinaf) & 0xFFFFu);
+            words_out[32 + lane] = code(static_cast<uint32_t>(n_exout) & 0xFFFFu);
+            words_out[40 + lane] = code(static_cast<uint32_t>(n_exoutaf) & 0xFFFFu);
+        }
     } else if (obs_out) {
         // binary encoding: the 48 x 5 observation (subleq.py:679-707 rows = memory | input | input_after | output | output_after;
         // :88-98 columns = 4 little-endian bits of v mod 16, then v == 16); lane w < 48 holds row-word w and stores its 5 bytes

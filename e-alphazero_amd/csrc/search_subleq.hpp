@@ -3,15 +3,16 @@
 // Reference: the simulation loop of emctx [EXT] search as called from src/selfplay.py:107-117, with the recurrent fn
 // of src/context.py:117-155 (env.step of src/envs/subleq.py + forward of src/network/fully_connected.py:41-101).
 //
-// One workgroup of 768 threads owns 16 trees for all S simulations.  Per simulation it runs the three device functions the
+// One workgroup of 512 threads (8 waves) owns 16 trees for all S simulations.  Per simulation it runs the three device functions the
 // per-simulation path launches as kernels, over its own 16 trees only, separated by workgroup barriers:
 //   T  tree_step_body<16, 1>  (tree.hpp): expand + backward of simulation s-1, select of simulation s; 16 lanes per tree, 4 trees
 //      per wave; the trees stay in global memory (133 words per node at A = 16: 16 trees x 65 nodes do not fit in LDS) but no other
 //      workgroup touches them, so they are served from this CU's L1 / the XCD's L2;
-//   E  subleq16_wave_body     (env_kernels.hpp): env.step of the chosen edges, one environment per wavefront (12 waves: the first
-//      four take a second one), with the observation row and its novelty;
-//   F  fc16p_body             (net_fc_pipe.hpp): the forward of the three heads self-play reads for the 16 new observation rows, one
-//      head per group of four waves, side by side (one head alone leaves the MFMA pipes idle during its staging / layer-3 phases).
+//   E  subleq16_wave_body     (env_kernels.hpp): env.step of the chosen edges, one environment per wavefront at a time, claimed from a
+//      work queue by the 8 waves; the 48 row-words of each new state stay in LDS;
+//   F  fc16p_body             (net_fc_pipe.hpp): the forward of the three heads self-play reads for the 16 new observations (one f32 tile
+//      built from the row-words), one head per group of four waves at a time, two side by side; the group without a head in the second
+//      round looks the observations' novelty up.
 // Same arithmetic, same order as the per-simulation kernels (parity suites run both).  What changes is the schedule:
 //   * no launches inside a search (the per-simulation path pays two dependent graph edges of ~9 us per simulation);
 //   * a slow interpreter run holds up its own 16 trees for one simulation, not the whole batch: the per-simulation launch waits for
@@ -86,6 +87,7 @@ __device__ __forceinline__ SqArgsPtr sq_args() {
 __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchArgs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ int sel_node[16], sel_action[16], sel_dst[16];
+    __shared__ int env_next;  // environments kSqWaves + env_next .. 15 of the simulation in flight are not claimed yet
     __shared__ __attribute__((aligned(16))) uint8_t sq_words[16][48];  // row-words of the 16 new states, 5 observation bits each
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * 16;
@@ -111,6 +113,7 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
         const int mode = kTreeSelect | ((s > 0 || expand_first) ? kTreeExpand : 0);
         // ---- T ----
         EAZ_QSTAMP(0);
+        if (tid == 0) env_next = 0;  // nobody is in the interpreter phase: between the barrier that ended F and the one that ends T
         if (wave < 4) {
             SqArgsPtr a = sq_args();
             const int pt = phase_tid(), sub = pt & 15;
@@ -120,16 +123,22 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __syncthreads();
-        // ---- E: environments wave and wave + 8 (a work queue over the waves measured no better: the phase ends with its slowest run) ----
+        // ---- E: the interpreters, one environment per wave at a time ----
         EAZ_QSTAMP(2);
         {
             SqArgsPtr a = sq_args();
             const int lane = phase_tid() & 63;
             const int B = a->t.B, N = a->t.N, sb = a->t.state_bytes;
             char* emb = a->t.embeddings;
+            // every wave takes its own environment first, then whatever is left, one at a time: a few interpreter runs are 3x the median
+            // and the phase ends with its last wave.  The claim is ONE LDS atomic per wave and environment, written as the instruction itself:
+            // `atomicAdd` goes through the compiler's atomic optimizer, which turned a lane-0 form into a loop that never ended and an
+            // all-lane form into a 64-iteration scan behind `s_waitcnt vmcnt(0)` (+6 k cycles per claim).
             EAZ_ESTAMP(0);
+            int j = wave, taken = 0;
+            const uint32_t env_next_off = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) int*)(&env_next)));
 #pragma unroll 1
-            for (int j = wave; j < 16; j += kSqWaves) {
+            while (j < 16) {
                 const int b = b0 + j;
                 if (b < B) {
                     const int node = __builtin_amdgcn_readfirstlane(sel_node[j]), action = __builtin_amdgcn_readfirstlane(sel_action[j]);
@@ -138,7 +147,12 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
                     subleq16_wave_body(a->e, base + static_cast<long>(node) * sb, base + static_cast<long>(dst) * sb, b, lane, action, 0, Key{0, 0},
                                        nullptr, nullptr, a->next_reward, a->next_term, a->next_legal, 16, nullptr, a->nf, &sq_words[j][0]);
                 }
-                EAZ_ESTAMP(j < kSqWaves ? 1 : 2);
+                taken += 1;
+                EAZ_ESTAMP(taken < 3 ? taken : 3);
+                // one ds_add_rtn by all 64 lanes (lane 0 reads the counter before this wave's 64 increments: the counter runs in units of 64)
+                int got;
+                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(env_next_off), "v"(1) : "memory");
+                j = kSqWaves + (__builtin_amdgcn_readfirstlane(got) >> 6);
             }
         }
         EAZ_QSTAMP(3);

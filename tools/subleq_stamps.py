@@ -62,10 +62,11 @@ lib.eaz_diag_sq_stamps.argtypes = [C.c_void_p]
 q = np.zeros(16, np.uint64)
 lib.eaz_diag_sq_stamps(q.ctypes.data)
 q = q.astype(np.int64)
-print("inside one subleq16_wave_body call (workgroup 0, wave 0, last call of the launch):")
+n = max(int(q[15]), 1)
+print(f"inside subleq16_wave_body, mean over the {n} calls of workgroup 0's first wave (all launches of this process):")
 for name, i in (("loads of the parent state", 0), ("decision + program patch", 1), ("test cases + interpreter", 2), ("assemble + state stores", 3),
-                ("observation row", 4), ("hash", 5)):
-    print(f"   {name:40s} {q[i + 1] - q[i]:8d} cycles")
+                ("row-words / observation row", 4), ("hash (per-simulation kernels only)", 5)):
+    print(f"   {name:40s} {q[i] / n:8.0f} cycles")
 
 # tree_step_body's own stamps (tree.hpp EAZ_TSTAMP): the last call with a select phase = simulation S-1, thread 0 of each workgroup
 lib.eaz_diag_tree_stamps.argtypes = [C.c_void_p]
