@@ -91,3 +91,13 @@ seg("second environment of a wave", (eb[:, :, 2] - eb[:, :, 1]).reshape(-1))
 seg("slowest wave of the workgroup (both)", (eb[:, :, 2] - eb[:, :, 0]).max(axis=1))
 seg("fastest wave of the workgroup (both)", (eb[:, :, 2] - eb[:, :, 0]).min(axis=1))
 seg("slowest single environment of the workgroup", np.maximum(eb[:, :, 1] - eb[:, :, 0], eb[:, :, 2] - eb[:, :, 1]).max(axis=1))
+
+# fc16p_body's own stamps (net_fc.hpp EAZ_STAMP), thread 0 of each workgroup: its last call = the head that runs alone in round 2
+lib.eaz_diag_fc_stamps.argtypes = [C.c_void_p]
+fb = np.zeros(1024 * 8, np.uint64)
+lib.eaz_diag_fc_stamps(fb.ctypes.data)
+fb = fb.reshape(1024, 8).astype(np.int64)[:256]
+print("fc16p_body, last head of the last simulation (runs alone on its four waves):")
+for name, i in (("constants + weight prologue -> tile barrier", 0), ("layer 1", 1), ("H1 store + barrier", 2), ("layer 2", 3),
+                ("H2 store + quarter chain + barrier", 4), ("emit", 5)):
+    seg(name, fb[:, i + 1] - fb[:, i])
