@@ -289,13 +289,15 @@ EAZ_API int eaz_profile_replay(eaz_search* s, int kernel_class, int iters, doubl
  *                        0 = automatic (spread until the launch has one wavefront per CU) */
 #define EAZ_TUNE_TREE_BLOCK 2
 #define EAZ_TUNE_TREE_SPREAD 3
-/*   EAZ_TUNE_PERSIST     1 (default) = eaz_search_run of a DeepSea + FC search with two actions whose trees fit into LDS runs all
- *                        simulations in ONE persistent launch (16 trees per workgroup, csrc/search_persist.hpp); 0 = one tree kernel +
- *                        one forward per simulation.  eaz_search_simulate always uses the per-simulation kernels. */
+/*   EAZ_TUNE_PERSIST     1 (default) = eaz_search_run runs all simulations in ONE launch, 16 trees per workgroup, where a kernel for it
+ *                        exists: DeepSea + FC network with two actions whose trees fit into LDS (csrc/search_persist.hpp; eaz_selfplay_run
+ *                        then runs the whole call in one launch), and Subleq word_size 16 with binary observations + FC network with the
+ *                        XXHash novelty over the IO rows (csrc/search_subleq.hpp); 0 = tree kernel(s) + one forward per simulation.
+ *                        eaz_search_simulate always uses the per-simulation kernels. */
 #define EAZ_TUNE_PERSIST 4
 /*   EAZ_TUNE_SHARDS      sub-batch pipelining of the per-simulation path, read by eaz_search_create: 2 / 4 = the batch is searched as that many
  *                        sub-batches on as many streams (one sub-batch's env-step launch overlaps another's forward), 1 = off,
- *                        0 (default) = 4 for Subleq batches of >= 2048 environments, 2 from 1024, else 1 */
+ *                        0 (default) = 4 for Subleq batches of >= 2048 environments, 2 from 1024, else 1 (not used by the one-launch searches) */
 #define EAZ_TUNE_SHARDS 5
 EAZ_API int eaz_tune_set(int knob, int value);
 
