@@ -236,27 +236,32 @@ __global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src,
 // environment is wavefront-uniform, i.e. lives in scalar registers: the sixteen 4-bit words of the program as ONE 64-bit value (an
 // operand fetch is a scalar shift + mask, the write-back a scalar bit-field insert), the cursor, counters and flags; the branches
 // are real (no divergence: one program per wavefront) and the memory comparison of the periodicity test is one 64-bit compare.  Only
-// the IO buffers, which few cycles touch, sit in the lanes of VGPRs (lanes 0..7 of `vin` / `vout`, v_readlane / select on the lane id).
+// the IO buffers are bytes of 64-bit scalars as well.
 // (A first version kept the program in the lanes of a VGPR too: five v_readlane per cycle, each a VALU -> SGPR round trip in the
 // cycle's dependency chain, 260 clocks per cycle.)  Results are bit-identical to subleq_simulate (same test suite); the state /
 // observation stores use the 64 lanes.
 __device__ __forceinline__ int sq_rl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 
-// subleq.py:297-398 `simulate` for one environment per wavefront.  smem: word l (< 16) in bits 4 l .. 4 l + 3.  vin / vtout: lane l =
-// input l / expected output l, W in every lane beyond the valid ones.  Returns `correct`; v_in_after / v_out: lanes 0..7 = input_after /
-// output_after.  The inner loop runs the cycles that touch memory words only (both operand addresses <= ADDRESS_MAX, cursor in
-// bounds): nothing of the IO state moves there, `all_eq` (:341) included, so halting is folded into the cycle increment `inc`.
-// Brent snapshots (iterations 1, 2, 4, ...; any growing schedule is exact) hold the memory in `ssnap` and the cursor in `s_cur`; an
-// IO event invalidates the snapshot (the input cursor and the output only move forward, so the state before it cannot recur).
-__device__ __forceinline__ bool subleq16_wave_run(unsigned long long smem, const int vin, const int vtout, const int lane, int& v_in_after,
-                                                  int& v_out, int& bytes_used) {
+#ifdef EAZ_FC_STAMPS
+extern __device__ unsigned long long g_sq_stamps[16];
+#endif
+// subleq.py:297-398 `simulate` for one environment per wavefront, every piece of machine state a scalar.  smem: word l (< 16) in bits
+// 4 l .. 4 l + 3.  sin / stout: input l / expected output l in byte l, W (= 16) in every byte beyond the valid ones.  Returns `correct`;
+// in_after / out: input_after / output_after, same packing.  The inner loop runs the cycles that touch memory words only (both operand
+// addresses <= ADDRESS_MAX, cursor in bounds): nothing of the IO state moves there, `all_eq` (:341) included, so halting is folded into
+// the cycle increment `inc`.  Brent snapshots (iterations 1, 2, 4, ...; any growing schedule is exact) hold the memory in `ssnap` and
+// the cursor in `s_cur`; an IO event invalidates the snapshot (the input cursor and the output only move forward, so the state before
+// it cannot recur).  The IO buffers are bytes of 64-bit scalars as well (first version: lanes of VGPRs -- every IO cycle then paid
+// three VALU <-> SALU round trips, and the programs the search likes best are the ones full of IO instructions).
+__device__ __forceinline__ bool subleq16_wave_run(unsigned long long smem, const unsigned long long sin, const unsigned long long stout,
+                                                  unsigned long long& in_after, unsigned long long& out, int& bytes_used) {
     constexpr int W = 16, AMAX = 12, AIN = 13, AOUT = 14, kStop = 1000;
-    int vout = W;
-    unsigned long long ssnap = 0ull;
+    constexpr unsigned long long kAllW = 0x1010101010101010ull;
+    unsigned long long sout = kAllW, ssnap = 0ull;
     int cur = 0, cycles = 0, in_cur = 0, out_cursor = 0, top_cur = -3;  // top_cur: highest cursor of an executed cycle (:311)
     int s_cur = -1, s_cycle = 0, it = 0, next_snap = 1;
     int error = 0;
-    int inc = (__builtin_amdgcn_ballot_w64(vout == vtout) & 0xFFull) == 0xFFull ? kStop : 1;  // :341 halts
+    int inc = sout == stout ? kStop : 1;  // :341 halts
     auto word = [&](int i) { return static_cast<int>(smem >> (4 * i)) & 15; };
     auto store = [&](int i, int v) { smem = (smem & ~(15ull << (4 * i))) | (static_cast<unsigned long long>(v) << (4 * i)); };
     // end of a cycle (:297-299 MAX_CYCLE_COUNT = 200): count it, close a period (state == snapshot => periodic with period
@@ -294,8 +299,9 @@ __device__ __forceinline__ bool subleq16_wave_run(unsigned long long smem, const
         if (cycles >= 200) break;
         if (oob) { error = 1; break; }  // nothing else changes
         // ---- a cycle that names IN, OUT or word 15 ------------------------------------------------------------------
-        // read_memory :187-232 (both reads see the pre-advance input state; the input cursor stands for the rolled array :333-338)
-        const int in0 = sq_rl(vin, in_cur);
+        // read_memory :187-232 (both reads see the pre-advance input state; the input cursor stands for the rolled array :333-338:
+        // in_cur <= 8, and position 8 reads as W)
+        const int in0 = in_cur < 8 ? static_cast<int>(sin >> (8 * in_cur)) & 0xFF : W;
         const bool in_ok = in0 < W;
         int ra = 0, rb = 0;
         if (a <= AMAX) ra = word(a); else if (a == AIN && in_ok) ra = in0;
@@ -310,11 +316,12 @@ __device__ __forceinline__ bool subleq16_wave_run(unsigned long long smem, const
         if (a == AOUT) {
             if (out_cursor >= 8) error = 1;
             else {
-                vout = lane == out_cursor ? v : vout;
-                if (v != sq_rl(vtout, out_cursor)) error = 1;  // :346-350
+                const int sh = 8 * out_cursor;
+                sout = (sout & ~(0xFFull << sh)) | (static_cast<unsigned long long>(v) << sh);
+                if (v != (static_cast<int>(stout >> sh) & 0xFF)) error = 1;  // :346-350
                 out_cursor += 1;
                 s_cur = -1;
-                if ((__builtin_amdgcn_ballot_w64(vout == vtout) & 0xFFull) == 0xFFull) inc = kStop;
+                if (sout == stout) inc = kStop;
             }
         } else if (a <= AMAX) {
             store(a, v);
@@ -324,10 +331,14 @@ __device__ __forceinline__ bool subleq16_wave_run(unsigned long long smem, const
         cycle_end();
         if (cycles >= 200) break;
     }
-    v_in_after = __shfl(vin, (lane + in_cur) & 63);  // lanes 0..7 read lanes <= 15, all W beyond the inputs
-    v_out = vout;
+    // the rolled input (:333-338): bytes in_cur .. 7 move down, W comes in at the top
+#ifdef EAZ_FC_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_sq_stamps[8] += static_cast<unsigned long long>(it); g_sq_stamps[9] += 1; if (static_cast<unsigned long long>(it) > g_sq_stamps[10]) g_sq_stamps[10] = it; }
+#endif
+    in_after = in_cur == 0 ? sin : (in_cur >= 8 ? kAllW : ((sin >> (8 * in_cur)) | (kAllW << (64 - 8 * in_cur))));
+    out = sout;
     bytes_used = top_cur + 3;
-    return error == 0 && (__builtin_amdgcn_ballot_w64(vout == vtout) & 0xFFull) == 0xFFull;
+    return error == 0 && sout == stout;
 }
 
 // Novelty lookup of the observation this kernel writes (obs_out != null, XXHash variant over the IO rows = bytes 80..239): saves the
@@ -452,16 +463,19 @@ __device__ __forceinline__ void subleq16_wave_body(const EnvDev& e, const char* 
             }
         }
         for (int c = 0; c < 3 && all_correct; ++c) {  // subleq.py:511 vmap; `solved` is the AND (:525), only case 0 feeds the state
-            uint16_t tin[8], tout[8];
-            subleq_test_case(task, c, W, tin, tout);
-            int vin = W, vtout = W;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { vin = lane == i ? tin[i] : vin; vtout = lane == i ? tout[i] : vtout; }
-            int v_after, v_out;
+            // subleq.py:398-501 get_test_cases (lax.switch clamps the branch index): the packed vectors of the compile-time table
+            const int branch = task - 1 < 0 ? 0 : (task - 1 > 5 ? 5 : task - 1);
+            const unsigned long long sin = kSq16Cases.v[branch][c][0], stout = kSq16Cases.v[branch][c][1];
+            unsigned long long s_after, s_out;
             int bytes_c;
-            const bool correct = subleq16_wave_run(smem, vin, vtout, lane, v_after, v_out, bytes_c);
+            const bool correct = subleq16_wave_run(smem, sin, stout, s_after, s_out, bytes_c);
             bytes_used = max(bytes_used, bytes_c);  // :530 results.bytes_used.max()
-            if (c == 0) { n_exin = vin; n_exout = vtout; n_exinaf = v_after; n_exoutaf = v_out; }
+            if (c == 0) {
+                // back to the lane-distributed rows of the state (lane l < 8 = element l)
+                const int sh = 8 * (lane & 7);
+                n_exin = static_cast<int>(sin >> sh) & 0xFF; n_exout = static_cast<int>(stout >> sh) & 0xFF;
+                n_exinaf = static_cast<int>(s_after >> sh) & 0xFF; n_exoutaf = static_cast<int>(s_out >> sh) & 0xFF;
+            }
             all_correct = correct;
         }
     }

@@ -144,6 +144,58 @@ __device__ __forceinline__ void subleq_test_case(int task, int c, int W, uint16_
     }
 }
 
+// The test vectors of word_size 16, packed for the one-wavefront interpreter (env_kernels.hpp): [branch][case][0 = input, 1 = expected
+// output], element i in byte i, W (= 16) beyond the valid ones -- subleq_test_case evaluated at compile time (its branch tree is ~300
+// scalar instructions, ~2 k clocks of a lone wavefront per case, most of what an interpreter run used to cost).
+struct Sq16CaseTable {
+    unsigned long long v[6][3][2];
+};
+constexpr int sq16_pymod(int x) { return ((x % 16) + 16) % 16; }
+constexpr Sq16CaseTable sq16_make_cases() {
+    Sq16CaseTable t{};
+    for (int branch = 0; branch < 6; ++branch)
+        for (int c = 0; c < 3; ++c) {
+            int in[8] = {0, 0, 0, 0, 0, 0, 0, 0}, out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int nin = 0, nout = 0;
+            if (branch == 0) {  // NEGATION_POSITIVE :406-411
+                const int t1[8] = {5, 4, 4, 5, 1, 2, 3, 1}, t2[8] = {1, 1, 6, 2, 4, 4, 5, 3};
+                if (c == 0) { nin = 7; for (int i = 0; i < 7; ++i) in[i] = i + 1; }
+                else { nin = 8; for (int i = 0; i < 8; ++i) in[i] = c == 1 ? t1[i] : t2[i]; }
+                nout = nin;
+                for (int i = 0; i < 8; ++i) out[i] = -in[i];
+            } else if (branch == 1 || branch == 2) {  // NEGATION :413-418 / IDENTITY :420-421
+                const int t2[5] = {0, -1, 2, -3, 4};
+                if (c == 0) { nin = 8; for (int i = 0; i < 8; ++i) in[i] = -4 + i; }
+                else if (c == 1) { nin = 7; for (int i = 0; i < 7; ++i) in[i] = i + 1; }
+                else { nin = 5; for (int i = 0; i < 5; ++i) in[i] = t2[i]; }
+                nout = nin;
+                for (int i = 0; i < 8; ++i) out[i] = branch == 1 ? -in[i] : in[i];
+            } else if (branch == 3 || branch == 4) {  // SUBTRACTION :423-432 / ADDITION :434-443
+                const int a0[6] = {1, 1, 5, 4, 0, -3}, a1[6] = {2, 3, 0, 0, -1, -2}, a2[8] = {1, 2, 3, 4, 4, 3, 2, 1};
+                const int s0[3] = {0, 1, 3}, s1[3] = {-1, 0, 1}, s2[4] = {-1, -1, 1, 1};
+                const int p0[3] = {2, 9, -3}, p1[3] = {5, 0, -3}, p2[4] = {3, 7, 7, 3};
+                if (c == 0) { nin = 6; nout = 3; for (int i = 0; i < 6; ++i) in[i] = a0[i]; for (int i = 0; i < 3; ++i) out[i] = branch == 3 ? s0[i] : p0[i]; }
+                else if (c == 1) { nin = 6; nout = 3; for (int i = 0; i < 6; ++i) in[i] = a1[i]; for (int i = 0; i < 3; ++i) out[i] = branch == 3 ? s1[i] : p1[i]; }
+                else { nin = 8; nout = 4; for (int i = 0; i < 8; ++i) in[i] = a2[i]; for (int i = 0; i < 4; ++i) out[i] = branch == 3 ? s2[i] : p2[i]; }
+            } else {  // MULTIPLICATION :445-454
+                const int m0[6] = {1, 2, 2, 3, -7, 4}, m1[6] = {-1, -5, 5, 2, 0, 1}, m2[6] = {0, 0, 1, 1, -3, 3};
+                const int o0[3] = {2, 6, -28}, o1[3] = {5, 10, 0}, o2[3] = {0, 1, -9};
+                nin = 6; nout = 3;
+                for (int i = 0; i < 6; ++i) in[i] = c == 0 ? m0[i] : (c == 1 ? m1[i] : m2[i]);
+                for (int i = 0; i < 3; ++i) out[i] = c == 0 ? o0[i] : (c == 1 ? o1[i] : o2[i]);
+            }
+            unsigned long long pi = 0, po = 0;
+            for (int i = 0; i < 8; ++i) {
+                pi |= static_cast<unsigned long long>(i < nin ? sq16_pymod(in[i]) : 16) << (8 * i);
+                po |= static_cast<unsigned long long>(i < nout ? sq16_pymod(out[i]) : 16) << (8 * i);
+            }
+            t.v[branch][c][0] = pi;
+            t.v[branch][c][1] = po;
+        }
+    return t;
+}
+__device__ constexpr Sq16CaseTable kSq16Cases = sq16_make_cases();
+
 // subleq.py:156-395 simulate.  `mem` is a private, mutable copy of the program (W bytes, LDS or scratch).
 // Returns correct (:394); in/out hold input_after / output_after on return.
 // Eight uint16 values (test input / expected output / produced output) packed into two 64-bit registers: element i lives in

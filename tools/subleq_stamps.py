@@ -67,6 +67,7 @@ print(f"inside subleq16_wave_body, mean over the {n} calls of workgroup 0's firs
 for name, i in (("loads of the parent state", 0), ("decision + program patch", 1), ("test cases + interpreter", 2), ("assemble + state stores", 3),
                 ("row-words / observation row", 4), ("hash (per-simulation kernels only)", 5)):
     print(f"   {name:40s} {q[i] / n:8.0f} cycles")
+print(f"   interpreter runs per call {q[9] / n:.2f}, executed cycles per run {q[8] / max(int(q[9]), 1):.1f} (longest run seen: {q[10]})")
 
 # tree_step_body's own stamps (tree.hpp EAZ_TSTAMP): the last call with a select phase = simulation S-1, thread 0 of each workgroup
 lib.eaz_diag_tree_stamps.argtypes = [C.c_void_p]
