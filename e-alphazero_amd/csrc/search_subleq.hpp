@@ -135,6 +135,18 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
             // `atomicAdd` goes through the compiler's atomic optimizer, which turned a lane-0 form into a loop that never ended and an
             // all-lane form into a 64-iteration scan behind `s_waitcnt vmcnt(0)` (+6 k cycles per claim).
             EAZ_ESTAMP(0);
+            {
+                // the parent states of two of the workgroup's environments: touched now, all 16 in flight together across the 8 waves, so that
+                // whichever wave interprets one starts from L2 / L1 instead of paying a memory round trip in turn
+                int touch = 0;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int jt = wave + kSqWaves * k, bt = b0 + jt < B ? b0 + jt : B - 1;
+                    const char* spt = emb + (static_cast<long>(bt) * N + sel_node[jt]) * sb;
+                    if (lane < 24) touch ^= reinterpret_cast<const int*>(spt)[lane];
+                }
+                asm volatile("" ::"v"(touch));
+            }
             int j = wave, taken = 0;
             const uint32_t env_next_off = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) int*)(&env_next)));
 #pragma unroll 1
