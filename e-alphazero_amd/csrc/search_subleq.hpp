@@ -141,8 +141,9 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
                 int touch = 0;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const int jt = wave + kSqWaves * k, bt = b0 + jt < B ? b0 + jt : B - 1;
-                    const char* spt = emb + (static_cast<long>(bt) * N + sel_node[jt]) * sb;
+                    const int jt = wave + kSqWaves * k;
+                    const bool in_batch = b0 + jt < B;  // a tree beyond the batch: its selection is tree 0's (tree_step_body), never a real edge
+                    const char* spt = emb + (static_cast<long>(in_batch ? b0 + jt : B - 1) * N + (in_batch ? sel_node[jt] : 0)) * sb;
                     if (lane < 24) touch ^= reinterpret_cast<const int*>(spt)[lane];
                 }
                 asm volatile("" ::"v"(touch));
