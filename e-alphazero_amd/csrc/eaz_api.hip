@@ -223,6 +223,17 @@ extern "C" int eaz_env_set_subleq_reward(eaz_env* env, int reward_fn) {
     return 0;
 }
 
+extern "C" int eaz_subleq16_test_vectors(int task, int c, uint16_t in[8], uint16_t expected_out[8]) {
+    ARG_OK(in && expected_out && c >= 0 && c < 3);
+    static constexpr Sq16CaseTable kHost = sq16_make_cases();  // the same constant expression the device table is initialised with
+    const int branch = task - 1 < 0 ? 0 : (task - 1 > 5 ? 5 : task - 1);
+    for (int i = 0; i < 8; ++i) {
+        in[i] = static_cast<uint16_t>((kHost.v[branch][c][0] >> (8 * i)) & 0xFF);
+        expected_out[i] = static_cast<uint16_t>((kHost.v[branch][c][1] >> (8 * i)) & 0xFF);
+    }
+    return 0;
+}
+
 extern "C" int eaz_env_create_connect4(eaz_ctx* ctx, eaz_env** out) {
     ARG_OK(ctx && out);
     eaz_env* e = new eaz_env();

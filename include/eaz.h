@@ -92,6 +92,10 @@ EAZ_API int eaz_env_create_subleq(eaz_ctx* ctx, int word_size, const int32_t* h_
  * bytes_used = the highest cursor + 3 any executed cycle of the three test runs reached, :311,:530).  Set before the first init / step. */
 enum { EAZ_SUBLEQ_REWARD_SOLVED_OR_NOT = 0, EAZ_SUBLEQ_REWARD_LOWEST_BYTES = 1 };
 EAZ_API int eaz_env_set_subleq_reward(eaz_env* env, int reward_fn);
+/* Inspection (host only, no device): the test vectors the word_size-16 interpreter reads for `task`, test case c in 0..2 -- the
+ * compile-time table of csrc/envs.hpp, i.e. get_test_cases (subleq.py:398-501) with the branch index clamped like lax.switch; 8 values
+ * each, W = 16 beyond the valid ones.  tests/test_abi_and_host.py holds it against the oracle's generator for every task. */
+EAZ_API int eaz_subleq16_test_vectors(int task, int c, uint16_t in[8], uint16_t expected_out[8]);
 /* pgx.make("connect_four") [EXT] main.py:190-194 */
 EAZ_API int eaz_env_create_connect4(eaz_ctx* ctx, eaz_env** out);
 EAZ_API int eaz_env_destroy(eaz_env* env);

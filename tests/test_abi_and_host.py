@@ -96,3 +96,22 @@ def test_params_layout_and_npz_roundtrip(eaz, tmp_path):
     p2, s2 = eaz.params.load_npz(path)
     assert all(np.array_equal(p[k]["w"], p2[k]["w"]) and np.array_equal(p[k]["b"], p2[k]["b"]) for k in p)
     assert np.array_equal(s2["fc_az_net/xxhash32"]["binary_set"], bs)
+
+
+def test_subleq16_test_vector_table_matches_the_oracle_generator(eaz, oracle):
+    """The one-wavefront Subleq interpreter reads its test vectors from a compile-time table (csrc/envs.hpp kSq16Cases) instead of
+    running get_test_cases (subleq.py:398-501) per environment.  Most entries never decide a GPU parity test (cases 1 and 2 only run
+    when case 0 passed), so the table is held here, entry by entry, against the oracle's generator -- every SubleqTask, the tasks beyond
+    the last branch included (lax.switch clamps the index)."""
+    import ctypes as C
+
+    lib = eaz.load_library()
+    for task in range(0, 16):
+        tin = np.zeros((3, 8), np.int32)
+        tout = np.zeros((3, 8), np.int32)
+        oracle.lib().eazo_subleq_test_cases(task, 16, tin.ctypes.data, tout.ctypes.data)
+        for c in range(3):
+            a = np.zeros(8, np.uint16)
+            b = np.zeros(8, np.uint16)
+            assert lib.eaz_subleq16_test_vectors(task, c, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)) == 0
+            assert np.array_equal(a.astype(np.int32), tin[c]) and np.array_equal(b.astype(np.int32), tout[c]), (task, c)
