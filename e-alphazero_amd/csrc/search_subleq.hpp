@@ -77,6 +77,7 @@ constexpr int kSqHeadGroups = kSqWaves / 4;
 // (an empty asm redefines it per phase): a by-value struct has all its loads hoisted to the kernel entry as loop invariants, and
 // the ~250 SGPRs the three phases need between them then spill through VGPR lanes into scratch memory -- inside the latency chains of
 // the tree walk (measured: tree phase 28 k -> 53 k cycles).  Re-issued scalar loads hit the scalar cache.
+// (Sq16SearchArgs is the kernel's ONLY parameter, so it sits at offset 0 of the kernarg segment.)
 typedef const Sq16SearchArgs* SqArgsPtr;
 __device__ __forceinline__ SqArgsPtr sq_args() {
     auto p = __builtin_amdgcn_kernarg_segment_ptr();
