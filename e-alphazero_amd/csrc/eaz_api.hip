@@ -19,6 +19,7 @@
 #include "search_persist.hpp"
 #include "net_fc_pipe.hpp"
 #include "search_subleq.hpp"
+#include "search_subleq_persist.hpp"
 
 using namespace eaz;
 
@@ -139,6 +140,9 @@ struct eaz_search {
     hipEvent_t ev_shard_fork, ev_shard_join;
     PersistSelfplay last_sp;   // arguments of the last fused self-play launch (eaz_profile_replay)
     char* d_replay_states;     // scratch states for that replay
+    // Subleq-16 fused self-play (search_subleq_persist.hpp): one launch per selfplay() call, trees and states in LDS
+    int sqp_lds;               // dynamic LDS bytes of that launch (0: the trees of a workgroup do not fit)
+    float* d_sq_logits;        // [ceil16(B), N, 16] prior-logit scratch rows
 };
 
 extern "C" int eaz_ctx_create(int device, eaz_ctx** out) {
@@ -645,7 +649,8 @@ extern "C" int eaz_tune_set(int knob, int value) {
         return 0;
     }
     if (knob == EAZ_TUNE_PERSIST) {
-        g_persist = value != 0;
+        ARG_OK(value == 0 || value == 1 || value == 2);  // 2: one launch per SEARCH only (Subleq-16: subleq16_search_kernel + the per-step kernels)
+        g_persist = value;
         return 0;
     }
     if (knob == EAZ_TUNE_SHARDS) {
@@ -881,6 +886,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     s->prof_on = 0; s->step_graph = nullptr; s->graph_states = nullptr; s->graph_flags = -1; s->pending_expand = -1;
     s->persist_ok = 0; s->persist_lds = 0; s->clear_pending = 0; s->sims_done = 0; s->d_stamps = nullptr;
     std::memset(&s->last_sp, 0, sizeof s->last_sp); s->d_replay_states = nullptr;
+    s->sqp_lds = 0; s->d_sq_logits = nullptr;
     HIP_OK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&s->main, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
@@ -953,9 +959,19 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(search_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
         if (s->persist_ok) DALLOC(s->d_replay_states, static_cast<size_t>(B) * env->dev.state_bytes);
         // Subleq-16 one-launch search (search_subleq.hpp): two forward tile sets = 76 KB of dynamic LDS (eligibility is re-checked per run)
-        if (env->dev.kind == EAZ_ENV_SUBLEQ && env->dev.W == 16 && net->kind == 0 && fp_eligible(net->dev.in_dim, net->dev.A))
+        if (env->dev.kind == EAZ_ENV_SUBLEQ && env->dev.W == 16 && net->kind == 0 && fp_eligible(net->dev.in_dim, net->dev.A)) {
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(subleq16_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        sq16_lds_bytes(net->dev.in_dim, net->dev.A, kSqHeadGroups)));
+            // ... and the whole selfplay() call in one launch while the 16 trees + states of a workgroup fit beside the forward tiles
+            // (node ids are bytes with 0xFF = none; eligibility of the network / hash class is re-checked per run)
+            const QpLds QL = qp_lds(s->N, s->S);
+            if (net->dev.in_dim == 240 && A == kQpA && s->N <= 250 && QL.total <= 160 * 1024) {
+                s->sqp_lds = QL.total;
+                HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(subleq16_selfplay_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, QL.total));
+                DALLOC(s->d_sq_logits, static_cast<size_t>(cdiv(B, kQpTrees)) * kQpTrees * s->N * kQpA);
+                DALLOC(s->d_replay_states, static_cast<size_t>(B) * env->dev.state_bytes);
+            }
+        }
         // two half-batches on two streams where the env step is the interpreter (Subleq) and the batch is big enough to split
         s->ev_shard_fork = s->ev_shard_join = nullptr;
         int want = g_shards ? g_shards : (env->dev.kind == EAZ_ENV_SUBLEQ && B >= 2048 ? 4 : (env->dev.kind == EAZ_ENV_SUBLEQ && B >= 1024 ? 2 : 1));
@@ -1079,6 +1095,23 @@ static int sq16_persist_launch(eaz_search* s, int sim0, int n_sims, bool expand_
     a.sim0 = sim0; a.n_sims = n_sims; a.expand_first = expand_first; a.expand_last = expand_last;
     a.stamps = s->d_stamps;
     subleq16_search_kernel<<<cdiv(s->B, 16), kSqThreads, sq16_lds_bytes(a.net.in_dim, a.net.A, kSqHeadGroups), st>>>(a);
+    LAUNCH_OK();
+    return 0;
+}
+
+// Subleq-16 fused self-play: T real steps in one launch (search_subleq_persist.hpp)
+static bool sqp_eligible(const eaz_search* s) { return s->sqp_lds > 0 && sq16_persist_eligible(s) && s->tree.max_depth >= 1; }
+static int sqp_launch(eaz_search* s, const PersistSelfplay& sp, hipStream_t st) {
+    Sq16SelfplayArgs a;
+    a.sp = sp;
+    a.t = s->tree;
+    a.e = s->env->dev;
+    a.net = s->net->dev;
+    a.out = NetOut{s->opts.exploration ? nullptr : s->d_exploit, s->opts.exploration ? s->d_explore : nullptr, s->d_v, s->d_u};
+    a.heads = HeadList{3, {0, 1, s->opts.exploration ? 3 : 2, 0}};  // context.py:132
+    a.logits = s->d_sq_logits;
+    a.stamps = s->d_stamps;
+    subleq16_selfplay_kernel<<<cdiv(s->B, kQpTrees), kQpThreads, s->sqp_lds, st>>>(a);
     LAUNCH_OK();
     return 0;
 }
@@ -1534,6 +1567,23 @@ extern "C" int eaz_selfplay_run(eaz_search* s, const eaz_selfplay_cfg* cfg, uint
         ProfScope ps(s, EAZ_K_SEARCH, S(stream));
         return persist_launch(s, S(stream), &sp);
     }
+    if (g_persist == 1 && sqp_eligible(s)) {
+        // Subleq-16 + FC network: likewise the whole call in ONE launch (csrc/search_subleq_persist.hpp)
+        if (cfg->selfplay_steps == 0) return 0;
+        PersistSelfplay sp;
+        std::memset(&sp, 0, sizeof sp);
+        sp.on = 1; sp.T = cfg->selfplay_steps; sp.key = k;
+        sp.flags = (cfg->uniform_search_policy ? kSpUniform : 0) | (cfg->sample_actions ? kSpSampleVisits : 0) |
+                   (cfg->sample_from_improved_policy ? kSpSampleImproved : 0);
+        sp.sbeta = cfg->directed_exploration ? cfg->exploration_beta : 0.0f;  // selfplay.py:92
+        sp.gumbel_scale = s->opts.gumbel_scale;
+        sp.states = static_cast<char*>(d_states); sp.gumbel = d_gumbel;
+        sp.out_states = static_cast<char*>(d_out_states); sp.out_root_value = d_out_root_value; sp.out_root_std = d_out_root_std;
+        sp.out_value_pred = d_out_value_pred; sp.out_ube_pred = d_out_ube_pred; sp.out_qvar = d_out_qvar; sp.out_action = d_out_action;
+        s->last_sp = sp;
+        ProfScope ps(s, EAZ_K_SEARCH, S(stream));
+        return sqp_launch(s, sp, S(stream));
+    }
     // graph replay needs a capturable stream: work runs on the search's own stream, ordered after/before the caller's by events
     const bool use_graph = cfg->use_graph && !s->prof_on;
     hipStream_t user = S(stream), st = user;
@@ -1757,7 +1807,8 @@ extern "C" int eaz_profile_replay(eaz_search* s, int cls, int iters, double* ms_
         return fail("eaz_profile_replay: the standalone leaf gather exists for unfused DeepSea searches only");
     HeadList hl{3, {0, 1, s->opts.exploration ? 3 : 2, 0}};
     NetOut o{s->opts.exploration ? nullptr : s->d_exploit, s->opts.exploration ? s->d_explore : nullptr, s->d_v, s->d_u};
-    if (cls == EAZ_K_SEARCH && !(s->persist_ok && g_persist))
+    const bool sqp = g_persist == 1 && sqp_eligible(s);
+    if (cls == EAZ_K_SEARCH && !(s->persist_ok && g_persist) && !(sqp && s->last_sp.on))
         return fail("eaz_profile_replay: this search does not run as one persistent launch (EAZ_TUNE_PERSIST, eligibility: eaz.h)");
     auto once = [&]() -> int {
         // the persistent search re-reads the root that the last eaz_search_begin left in the tree arrays (timing only: the statistics of
@@ -1769,6 +1820,7 @@ extern "C" int eaz_profile_replay(eaz_search* s, int cls, int iters, double* ms_
             sp.states = s->d_replay_states; sp.gumbel = nullptr;
             sp.out_states = nullptr; sp.out_root_value = sp.out_root_std = sp.out_value_pred = sp.out_ube_pred = sp.out_qvar = nullptr;
             sp.out_action = nullptr;
+            if (sqp) return sqp_launch(s, sp, st);
             return persist_launch(s, st, &sp);
         }
         if (cls == EAZ_K_NET) return fused ? fc_onehot_launch(s->net, s->B, s->d_leaf_hot, s->d_novelty, o, hl, st) : fc_launch(s->net, s->B, s->d_obs, o, hl, st);

@@ -28,6 +28,9 @@ __host__ __device__ inline int fp_lds_bytes(int K, int A) {
 // dynamic LDS of subleq16_search_kernel (search_subleq.hpp): the forward tiles of its head groups + the shared observation tile
 __host__ __device__ inline int sq16_lds_bytes(int in_dim, int A, int head_groups) { return head_groups * fp_lds_bytes(in_dim, A) + fp_xfloats(in_dim) * 4; }
 __host__ inline bool fp_eligible(int in_dim, int A) { return in_dim <= kFpMaxK && A <= kFcW3Cols && kPsDepth == 16; }
+// workgroup barriers inside fc16p_body: a caller whose other wavefronts do not run the body must issue exactly this many (search_subleq*.hpp);
+// tests/test_isa_guard.py counts the s_barrier instructions of fc16p_forward_kernel against it
+constexpr int kFpBarriers = 3;
 
 // grid = (row tiles, heads): one workgroup = 16 rows x one head (40 KB of LDS at the C3 shape, 148 VGPRs: three workgroups per CU, whose
 // barriers / staging / layer-3 chains overlap each other's MFMA streams)

@@ -218,7 +218,8 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
                         const uint32_t index = h >> (32 - a->nf.hash_bits);          // :229
                         if (i == 0 && b0 + e < a->t.B) subleq16_novelty(a->nf, b0 + e, index);
                     }
-                    __syncthreads(); __syncthreads(); __syncthreads();  // the three barriers of fc16p_body
+#pragma unroll
+                    for (int k = 0; k < kFpBarriers; ++k) __syncthreads();  // the barriers of fc16p_body
                 }
             }
         }

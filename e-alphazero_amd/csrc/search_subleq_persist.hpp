@@ -1,0 +1,714 @@
+// search_subleq_persist.hpp -- subleq16_selfplay_kernel: a whole selfplay() call for Subleq word_size 16 in ONE launch (C3 production path).
+//
+// Reference: step_fn of src/selfplay.py:86-143 (root inference :89-91, root preparation :92-106, emctx policy :107-117 [EXT] = SURVEY.md
+// A.2-A.7, action choice :118-134, auto-reset env.step :135, SelfplayOutput :136-143), with the recurrent fn of src/context.py:117-155
+// (env.step of src/envs/subleq.py:648-677 + forward of src/network/fully_connected.py:41-101 + XXHash novelty of hashes.py:162-229).
+//
+// One workgroup of 512 threads (8 waves) owns 16 environments / trees for all T real steps.  Nothing of a tree lives in global memory
+// except the prior logits of its nodes (a [N,16] f32 scratch row set per tree, read back only for the nodes of the backed-up path):
+//   trees   LDS node records (QN_WORDS words).  A tree of N nodes has at most N - 1 edges whatever A is, so the [N,A] child arrays of
+//           mctx collapse into per-NODE fields: children_values / _visits / _variance[p, a] are always the node value / visit count /
+//           variance of the child itself (the backward pass copies them on every visit, A.6), the edge's reward and "discount is zero"
+//           flag sit in the child's record, and children_index is 16 bytes per node.
+//   states  LDS, 32 bytes per node: the sixteen 4-bit words of the program as one 64-bit value, input_after / output_after as 8 bytes
+//           each, a header word; example_input / example_output are constants of the task (subleq.py:398-501).
+// Per simulation (lanes 32 ti .. 32 ti + 31 belong to tree ti, i.e. a tree never leaves its wavefront during the tree phase):
+//   T  expand + backward of the previous leaf (lane = level of the recorded path, as search_persist.hpp), re-score of the D + 1 nodes whose
+//      selection inputs changed (4 lanes x 4 actions per node: Group<4,4>, the reductions are two DPP quad permutes), select = a walk
+//      through the cached choices;
+//   E  env.step of the 16 chosen edges by the all-scalar interpreter of env_kernels.hpp (subleq16_wave_run), one environment per
+//      wavefront at a time from a work queue, LDS to LDS;
+//   F  the forward of the three heads self-play reads for the 16 new observations.
+// Same float operations in the same order as tree_step_kernel<16,1> / fc16p_forward_kernel (the 16-slot butterfly sum is
+// lsum<4> + two quad exchanges), so results are bit-identical to the per-simulation path and to the oracle (tests/conftest.py variants).
+#pragma once
+#include "net_fc_pipe.hpp"
+#include "search_kernels.hpp"
+
+namespace eaz {
+
+constexpr int kQpTrees = 16;
+constexpr int kQpThreads = 512;
+constexpr int kQpA = 16;
+
+// node record in LDS (32-bit words)
+enum : int {
+    QN_RAW_VALUE = 0, QN_NODE_VALUE = 1, QN_RAW_VAR = 2, QN_NODE_VAR = 3,
+    QN_REWARD = 4,  // children_rewards[parent, action_from_parent]
+    QN_META = 5,    // node_visits (bits 0-7) | parent (8-15) | action_from_parent (16-19) | edge discount is zero (20)
+    QN_SEL = 6,     // cached selection: action << 8 | child (0xFF: unvisited)
+    QN_CHILD = 7,   // children_index as 16 bytes (0xFF: unvisited), action a in byte a & 3 of word a >> 2
+    QN_WORDS = 11
+};
+// compact Subleq-16 state (32-bit words): the program as 16 nibbles, input_after / output_after as bytes (W = 16 beyond the valid ones)
+enum : int { QS_MEM = 0, QS_INAF = 2, QS_OUTAF = 4, QS_HDR = 6, QS_REWARD = 7, QS_WORDS = 8 };
+// header: step_count (bits 0-7) | terminated 8 | truncated 9 | solved 10 | rows-from-root 11 | task (12..31, signed)
+// rows-from-root: example_input / example_output of this state are the root blob's (never recomputed since); otherwise the task's table
+
+struct QpMisc {
+    int D[kQpTrees], parent[kQpTrees], action[kQpTrees], dst[kQpTrees];
+    float o_nov[kQpTrees], o_reward[kQpTrees];
+    int o_term[kQpTrees];
+    float gumbel[kQpTrees][kQpA];
+    float root_logits[kQpTrees][kQpA];  // masked prior logits of node 0
+    float new_logits[kQpTrees][kQpA];   // masked prior logits of the node expanded by this simulation
+    float edge[kQpTrees][16][2];        // backward: (reward, discount) of the 16 path levels of the chunk being folded
+    float root_v[kQpTrees], root_u[kQpTrees];
+    uint32_t root_state[kQpTrees][QS_WORDS];
+    uint32_t root_ex[kQpTrees][4];      // example_input / example_output rows of the root blob (bytes)
+    int real_action[kQpTrees];
+    int env_next;
+    int pad[3];
+    uint8_t words[kQpTrees][48];        // row-words of the 16 observations in flight, 5 observation bits each (subleq.py:88-98)
+};
+
+struct QpLds {
+    int tstride;  // words per tree
+    int off_fwd, off_x, off_tree, off_state, off_path, off_misc, total;
+};
+__host__ __device__ inline QpLds qp_lds(int N, int S) {
+    QpLds L;
+    int o = 0;
+    L.off_fwd = o; o += fp_lds_bytes(240, kQpA);
+    L.off_x = o; o += fp_xfloats(240) * 4;
+    L.tstride = (N * QN_WORDS) | 1;
+    L.off_tree = o; o += kQpTrees * L.tstride * 4;
+    o = (o + 15) & ~15;
+    L.off_state = o; o += kQpTrees * N * QS_WORDS * 4;
+    L.off_path = o; o += (kQpTrees * S * 2 + 15) & ~15;
+    L.off_misc = o; o += (static_cast<int>(sizeof(QpMisc)) + 15) & ~15;
+    L.total = o;
+    return L;
+}
+
+struct Sq16SelfplayArgs {
+    PersistSelfplay sp;  // search_persist.hpp: the call's T, key, flags, beta, state / noise / output pointers
+    TreeDev t;           // options, table; children_prior_logits is NOT used (see `logits`)
+    EnvDev e;
+    NetDev net;
+    NetOut out;          // [B] / [B,16] scratch the forward's heads write their outputs to
+    HeadList heads;
+    float* logits;       // [ceil16(B), N, 16] prior-logit scratch rows of the trees
+    unsigned long long* stamps;
+};
+
+#ifdef EAZ_FC_STAMPS
+// diagnostic build: shader-clock stamps of simulation S / 2 of the first real step, lane 0 of every wave: [256 workgroups][8 waves][8]
+#define EAZ_QPSTAMP(i)                                                                                 \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        if (step == 0 && s == 1 + S / 2 && (tid & 63) == 0 && blockIdx.x < 256 && qp_args()->stamps) { \
+            unsigned long long t_;                                                                     \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+            qp_args()->stamps[(blockIdx.x * 8 + (tid >> 6)) * 8 + (i)] = t_;                           \
+        }                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    } while (0)
+#else
+#define EAZ_QPSTAMP(i)
+#endif
+
+__device__ __forceinline__ unsigned long long qp_u64(uint32_t lo, uint32_t hi) { return static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32); }
+// sixteen bytes (one program word each) -> sixteen nibbles
+__device__ __forceinline__ unsigned long long qp_nibbles(const uint4& c) {
+    const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+    unsigned long long m = 0ull;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t w = cw[i];
+        const uint32_t n4 = (w & 0xFu) | ((w >> 4) & 0xF0u) | ((w >> 8) & 0xF00u) | ((w >> 12) & 0xF000u);
+        m |= static_cast<unsigned long long>(n4) << (16 * i);
+    }
+    return m;
+}
+// eight uint16 values (two uint4) -> eight bytes
+__device__ __forceinline__ unsigned long long qp_row_bytes(const uint4& r) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    unsigned long long v = 0ull;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v |= static_cast<unsigned long long>((w[i] & 0xFFu) | ((w[i] >> 8) & 0xFF00u)) << (16 * i);
+    return v;
+}
+__device__ __forceinline__ int qp_hdr_task(uint32_t hdr) { return static_cast<int>(hdr) >> 12; }
+__device__ __forceinline__ uint32_t qp_hdr(int step, int task, int term, int trunc, int solved, int exroot) {
+    return static_cast<uint32_t>(step & 0xFF) | (static_cast<uint32_t>(term != 0) << 8) | (static_cast<uint32_t>(trunc != 0) << 9) |
+           (static_cast<uint32_t>(solved != 0) << 10) | (static_cast<uint32_t>(exroot != 0) << 11) | (static_cast<uint32_t>(task) << 12);
+}
+// observation code of a row-word: bits 0..3 = v mod 16, bit 4 = (v == 16)  (subleq.py:88-98)
+__device__ __forceinline__ uint8_t qp_code(uint32_t v) { return static_cast<uint8_t>((v & 15u) | (v == 16u ? 16u : 0u)); }
+
+// The 48 row-words of a state (memory | example_input | input_after | example_output | output_after, subleq.py:679-707): lane w < 48 stores
+// the code of row-word w.
+__device__ __forceinline__ void qp_emit_words(uint8_t* words, unsigned long long mem, unsigned long long exin, unsigned long long inaf,
+                                              unsigned long long exout, unsigned long long outaf, int lane) {
+    if (lane < 16) {
+        words[lane] = static_cast<uint8_t>((mem >> (4 * lane)) & 15ull);
+    } else if (lane < 48) {
+        const int row = (lane - 16) >> 3, sh = 8 * (lane & 7);
+        const unsigned long long src = row == 0 ? exin : (row == 1 ? inaf : (row == 2 ? exout : outaf));
+        words[lane] = qp_code(static_cast<uint32_t>(src >> sh) & 0xFFu);
+    }
+}
+
+// pgx.Env.step (A.1) around subleq.py:648-677 for ONE environment on one wavefront, compact state `src` (LDS) -> `dst` (LDS), everything
+// wavefront-uniform.  mode 0: plain step (search), 1: auto_reset(env.step, env.init) (selfplay.py:26-75), as subleq16_wave_body.
+// blob: also the 336-byte state of include/eaz.h (real steps); words: the observation's row-words.  Returns the reward / terminated flag.
+__device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src, uint32_t* dst, const uint32_t* root_ex, uint8_t* words,
+                                            const int action, const int mode, const Key envkey, const int b, const int lane, char* blob0,
+                                            char* blob1, float& reward_out, int& term_out) {
+    uint32_t s[QS_WORDS];
+#pragma unroll
+    for (int i = 0; i < QS_WORDS; ++i) s[i] = __builtin_amdgcn_readfirstlane(src[i]);
+    unsigned long long mem = qp_u64(s[QS_MEM], s[QS_MEM + 1]);
+    unsigned long long inaf = qp_u64(s[QS_INAF], s[QS_INAF + 1]), outaf = qp_u64(s[QS_OUTAF], s[QS_OUTAF + 1]);
+    const uint32_t hdr = s[QS_HDR];
+    const int h_step = hdr & 0xFF, s_term = (hdr >> 8) & 1, s_trunc = (hdr >> 9) & 1, s_solved = (hdr >> 10) & 1;
+    int exroot = (hdr >> 11) & 1;
+    // ---- decide what this environment does (pgx wrapper A.1, auto_reset selfplay.py:66-71, _step subleq.py:671-677)
+    const bool done = (s_term | s_trunc) != 0;
+    const bool do_init = mode == 1 && done;
+    bool finish = false, run = false;
+    int step_count, task = qp_hdr_task(hdr);
+    if (do_init) {
+        const Key ki = fold(fold(envkey, static_cast<uint32_t>(b)), 1u);
+        const int idx = e.n_tasks > 1 ? static_cast<int>(rbits(ki, 0) % static_cast<uint32_t>(e.n_tasks)) : 0;  // subleq.py:624
+        task = __builtin_amdgcn_readfirstlane(e.tasks[idx]);
+        step_count = 0;
+        run = true;
+        mem = 0ull;
+    } else if (done) {
+        step_count = h_step;  // same state, zero rewards
+    } else {
+        step_count = h_step + 1;
+        if (step_count >= 16 - 3 || s_solved) finish = true;  // subleq.py:671-673
+        else run = true;
+    }
+    const int branch = task - 1 < 0 ? 0 : (task - 1 > 5 ? 5 : task - 1);  // get_test_cases: lax.switch clamps the branch index
+    const unsigned long long t_in = kSq16Cases.v[branch][0][0], t_out = kSq16Cases.v[branch][0][1];
+    unsigned long long exin = exroot ? qp_u64(root_ex[0], root_ex[1]) : t_in, exout = exroot ? qp_u64(root_ex[2], root_ex[3]) : t_out;
+    bool all_correct = false;
+    int bytes_used = 0;
+    if (run) {
+        const int idx = step_count - 1;  // the action is word step_count - 1 (subleq.py:654)
+        if (!do_init && idx >= 0 && idx < 16) mem = (mem & ~(15ull << (4 * idx))) | (static_cast<unsigned long long>(action & 15) << (4 * idx));
+        all_correct = true;
+        for (int c = 0; c < 3 && all_correct; ++c) {  // subleq.py:511 vmap; `solved` is the AND (:525), only case 0 feeds the state
+            const unsigned long long sin = kSq16Cases.v[branch][c][0], stout = kSq16Cases.v[branch][c][1];
+            unsigned long long s_after, s_out;
+            int bytes_c;
+            const bool correct = subleq16_wave_run(mem, sin, stout, s_after, s_out, bytes_c);
+            bytes_used = max(bytes_used, bytes_c);  // :530
+            if (c == 0) { inaf = s_after; outaf = s_out; }
+            all_correct = correct;
+        }
+        exin = t_in; exout = t_out; exroot = 0;
+    }
+    float reward;
+    int terminated, solved;
+    if (run) {
+        solved = all_correct ? 1 : 0;                           // subleq.py:525
+        reward = solved ? subleq_reward(e, bytes_used) : 0.0f;  // :535-537 / :540-542
+        terminated = do_init ? 0 : s_term;                      // _step never sets terminated on this branch (:661-669)
+    } else {
+        solved = s_solved;
+        reward = 0.0f;                                          // terminal no-op (A.1) or subleq.py:673
+        terminated = finish ? 1 : s_term;
+    }
+    const int truncated = do_init ? 0 : s_trunc;
+    if (lane == 0) {
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        d4[0] = make_uint4(static_cast<uint32_t>(mem), static_cast<uint32_t>(mem >> 32), static_cast<uint32_t>(inaf), static_cast<uint32_t>(inaf >> 32));
+        d4[1] = make_uint4(static_cast<uint32_t>(outaf), static_cast<uint32_t>(outaf >> 32), qp_hdr(step_count, task, terminated, truncated, solved, exroot),
+                           __builtin_bit_cast(uint32_t, reward));
+    }
+    if (words) qp_emit_words(words, mem, exin, inaf, exout, outaf, lane);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        char* blob = k == 0 ? blob0 : blob1;
+        if (!blob) continue;
+        // the 336-byte blob of include/eaz.h: header, four rows of eight uint16, 256 memory bytes (zero beyond the 16 words)
+        if (lane == 0)
+            *reinterpret_cast<uint4*>(blob) = make_uint4(static_cast<uint32_t>(step_count), static_cast<uint32_t>(task), __builtin_bit_cast(uint32_t, reward),
+                                                         static_cast<uint32_t>(terminated) | (static_cast<uint32_t>(truncated) << 8) | (static_cast<uint32_t>(solved) << 16));
+        if (lane < 32) {
+            const int row = lane >> 3, sh = 8 * (lane & 7);
+            const unsigned long long srcv = row == 0 ? exin : (row == 1 ? inaf : (row == 2 ? exout : outaf));
+            reinterpret_cast<uint16_t*>(blob + 16)[lane] = static_cast<uint16_t>((srcv >> sh) & 0xFFull);
+        }
+        if (lane < 16) {
+            uint4 c = make_uint4(0u, 0u, 0u, 0u);
+            if (lane == 0) {
+                uint32_t w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t n4 = static_cast<uint32_t>(mem >> (16 * i)) & 0xFFFFu;
+                    w[i] = (n4 & 0xFu) | ((n4 & 0xF0u) << 4) | ((n4 & 0xF00u) << 8) | ((n4 & 0xF000u) << 12);
+                }
+                c = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            *reinterpret_cast<uint4*>(blob + 80 + 16 * lane) = c;
+        }
+    }
+    reward_out = reward;
+    term_out = terminated;
+}
+
+// novelty of the 16 observations whose row-words are in M.words (XXHash variant, hashes.py:162-229: lane = (environment, stripe), stripe i =
+// IO row i = 8 words x 5 bytes that are 0 or 1), one wavefront
+__device__ __forceinline__ void qp_novelty(const NetDev& net, QpMisc& M, const int lane) {
+    // novelty of the 16 observations (XXHash variant, hashes.py:162-229: lane = (environment, stripe), stripe i = IO row i =
+    // 8 words x 5 bytes that are 0 or 1)
+    const uint32_t P1 = 0x9E3779B1u, P2 = 0x85EBCA77u, P3 = 0xC2B2AE3Du, SEED = 1u, ONE = 0x3F800000u * P2;
+    const int ev = lane >> 2, i = lane & 3;
+    uint32_t acc = i == 0 ? SEED + P1 + P2 : (i == 1 ? SEED + P2 : (i == 2 ? SEED : SEED - P1));  // :217-220
+    const uint2 ww = *reinterpret_cast<const uint2*>(&M.words[ev][16 + 8 * i]);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const uint32_t code = ((w < 4 ? ww.x : ww.y) >> (8 * (w & 3))) & 0xFFu;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const uint32_t tt = acc + ((code >> j) & 1u ? ONE : 0u);
+            acc = ((tt << 13) | (tt >> 19)) * P1;  // :176-181
+        }
+    }
+    const int rot = i == 0 ? 1 : (i == 1 ? 7 : (i == 2 ? 12 : 18));  // :184-187
+    uint32_t hsh = (acc << rot) | (acc >> (32 - rot));
+    hsh += __shfl_xor(hsh, 1);
+    hsh += __shfl_xor(hsh, 2);
+    hsh += 40u;  // :226 (stripe count)
+    hsh ^= hsh >> 15; hsh *= P2; hsh ^= hsh >> 13; hsh *= P3; hsh ^= hsh >> 16;  // :190-197
+    const uint32_t index = hsh >> (32 - net.hash_bits);                        // :229
+    if (i == 0) {
+        const bool seen = net.bitset ? ((net.bitset[index >> 3] >> (index & 7u)) & 1u) != 0 : false;  // hashes.py:29-38
+        M.o_nov[ev] = (seen ? 0.0f : 1.0f) * net.nov_scale;                                            // fully_connected.py:90
+    }
+}
+
+// The kernel's arguments live in the kernarg segment and every phase reads them through a pointer the compiler cannot see through (an
+// empty asm redefines it per phase): a by-value struct has all its loads hoisted to the kernel entry as loop invariants, and the SGPRs
+// the phases need between them then spill through VGPR lanes (first build: 193 SGPR spills).  Re-issued scalar loads hit the scalar
+// cache.  Sq16SelfplayArgs is the kernel's ONLY parameter, so it sits at offset 0 of the kernarg segment (tests/test_isa_guard.py).
+typedef const Sq16SelfplayArgs* QpArgsPtr;
+__device__ __forceinline__ QpArgsPtr qp_args() {
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (const Sq16SelfplayArgs*)p;  // constant -> generic; the loads are inferred back to scalar loads after inlining
+}
+#define EAZ_QP_ARGS                          \
+    const Sq16SelfplayArgs& a = *qp_args();  \
+    const TreeDev& t = a.t
+
+__global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16SelfplayArgs) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    int N, S, B, n_steps, nc, max_depth;
+    float sbeta;
+    float* logits_base;
+    {
+        EAZ_QP_ARGS;
+        N = t.N; S = t.S; B = t.B; n_steps = a.sp.T; max_depth = t.max_depth;
+        nc = kQpA < t.max_considered ? kQpA : t.max_considered;  // every action is legal (subleq.py:626): 16 valid root actions
+        sbeta = a.sp.sbeta;
+        logits_base = a.logits;
+    }
+    const QpLds L = qp_lds(N, S);
+    uint8_t* fwd = lds + L.off_fwd;
+    float* Xs = reinterpret_cast<float*>(lds + L.off_x);
+    uint32_t* trees = reinterpret_cast<uint32_t*>(lds + L.off_tree);
+    uint32_t* states = reinterpret_cast<uint32_t*>(lds + L.off_state);
+    uint16_t* path = reinterpret_cast<uint16_t*>(lds + L.off_path);  // [16][S]: node | action << 8
+    QpMisc& M = *reinterpret_cast<QpMisc*>(lds + L.off_misc);
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int b0 = blockIdx.x * kQpTrees;
+    // tree lanes: 32 per tree; re-score: slot = node of the path, q = quarter of the actions
+    const int ti = tid >> 5, tl = tid & 31, slot = tl >> 2, q = tl & 3;
+    uint32_t* T = trees + ti * L.tstride;
+    uint32_t* ST = states + ti * N * QS_WORDS;
+    uint16_t* P = path + ti * S;
+    const bool tree_live = b0 + ti < B;
+    const int gb = tree_live ? b0 + ti : B - 1;  // trees beyond the batch mirror the last environment; they never store outside LDS / their scratch rows
+    float* LG = logits_base + static_cast<long>(b0 + ti) * N * kQpA;
+    const Group<4, 4> g = make_group<4, 4>(gb, q, kQpA);
+    const float beta = sbeta * (B > 1 ? static_cast<float>(gb) / static_cast<float>(B - 1) : 0.0f);  // selfplay.py:105
+    const bool need_var = beta != 0.0f;
+
+    // ---------------------------------------------------------------- prologue ----------------------------------------------------
+    for (int idx = tid; idx < 16 * 16; idx += kQpThreads) Xs[h16_off(240 + (idx >> 4), idx & 15)] = 0.0f;  // inputs 240..255: zero for the whole launch
+    for (int k = 0; k < 2; ++k) {
+        EAZ_QP_ARGS;
+        // the current states of two of the workgroup's environments: 336-byte blob -> compact root state + the observation's row-words
+        const int j = 2 * wave + k;
+        const int bj = b0 + j < B ? b0 + j : B - 1;
+        const char* sp = a.sp.states + static_cast<long>(bj) * sizeof(eaz_subleq_state);
+        const uint4 hv = *reinterpret_cast<const uint4*>(sp);
+        const uint4 r0 = *reinterpret_cast<const uint4*>(sp + 16), r1 = *reinterpret_cast<const uint4*>(sp + 32);
+        const uint4 r2 = *reinterpret_cast<const uint4*>(sp + 48), r3 = *reinterpret_cast<const uint4*>(sp + 64);
+        const uint4 mc = *reinterpret_cast<const uint4*>(sp + 80);
+        // rows are eight uint16 = two uint4 halves: ex_in = (r0), ex_in_after = (r1), ex_out = (r2), ex_out_after = (r3) -- 16 bytes each
+        auto row = [](const uint4& r) { return qp_row_bytes(r); };
+        const unsigned long long mem = qp_nibbles(mc), exin = row(r0), inaf = row(r1), exout = row(r2), outaf = row(r3);
+        if (lane == 0) {
+            uint32_t* rs = M.root_state[j];
+            rs[QS_MEM] = static_cast<uint32_t>(mem); rs[QS_MEM + 1] = static_cast<uint32_t>(mem >> 32);
+            rs[QS_INAF] = static_cast<uint32_t>(inaf); rs[QS_INAF + 1] = static_cast<uint32_t>(inaf >> 32);
+            rs[QS_OUTAF] = static_cast<uint32_t>(outaf); rs[QS_OUTAF + 1] = static_cast<uint32_t>(outaf >> 32);
+            rs[QS_HDR] = qp_hdr(static_cast<int>(hv.x), static_cast<int>(hv.y), hv.w & 0xFF, (hv.w >> 8) & 0xFF, (hv.w >> 16) & 0xFF, 1);
+            rs[QS_REWARD] = hv.z;
+            M.root_ex[j][0] = static_cast<uint32_t>(exin); M.root_ex[j][1] = static_cast<uint32_t>(exin >> 32);
+            M.root_ex[j][2] = static_cast<uint32_t>(exout); M.root_ex[j][3] = static_cast<uint32_t>(exout >> 32);
+        }
+        qp_emit_words(M.words[j], mem, exin, inaf, exout, outaf, lane);
+    }
+    __syncthreads();
+
+    const int n_iter = n_steps * (S + 1);
+#pragma unroll 1
+    for (int it = 0; it <= n_iter; ++it) {
+        const int step = it / (S + 1), s = it - step * (S + 1);  // s = 0: root of real step `step`; s >= 1: simulation s - 1
+        int env_mode = 0;
+        Key env_key{0u, 0u};
+        if (s >= 2 || (s == 0 && it > 0)) {
+            // ---- expand + backward of the simulation evaluated last (simulation s - 2; at s == 0: simulation S - 1 of the step before) ----
+            EAZ_QP_ARGS;
+            EAZ_QPSTAMP(0);
+            const float* net_logits = a.heads.id[2] == 2 ? a.out.exploit : a.out.explore;
+            const int D = M.D[ti], dst = M.dst[ti], parent = M.parent[ti], action = M.action[ti];
+            {
+                // epistemic_recurrent_fn (src/context.py:132-153) on the forward's outputs; mctx update_tree_node + topology (A.3)
+                float lgv = tl < 16 ? net_logits[static_cast<long>(gb) * kQpA + tl] : -kInf;
+                const float m = gmax<16>(lgv);                                                    // :135
+                lgv = lgv - m;                                                                     // :137 (every action legal, subleq.py:626)
+                if (tl < 16) { M.new_logits[ti][tl] = lgv; LG[dst * kQpA + tl] = lgv; }
+                if (tl == 0) {
+                    const bool term = M.o_term[ti] != 0;
+                    const float value = term ? 0.0f : a.out.value[gb];                             // :140
+                    const float var = term ? 0.0f : ube_combine(a.out.ube[gb], M.o_nov[ti], t.max_u);  // :141
+                    uint32_t* Rn = T + dst * QN_WORDS;
+                    Rn[QN_RAW_VALUE] = f2u(value); Rn[QN_NODE_VALUE] = f2u(value);
+                    Rn[QN_RAW_VAR] = f2u(var); Rn[QN_NODE_VAR] = f2u(var);
+                    Rn[QN_REWARD] = f2u(M.o_reward[ti]);                                           // :139
+                    const uint32_t visits = (Rn[QN_META] & 0xFFu) + 1u;
+                    Rn[QN_META] = visits | (static_cast<uint32_t>(parent) << 8) | (static_cast<uint32_t>(action) << 16) | (term ? 1u << 20 : 0u);  // :142-144
+                    uint8_t* ch = reinterpret_cast<uint8_t*>(T + parent * QN_WORDS + QN_CHILD);
+                    ch[action] = static_cast<uint8_t>(dst);
+                }
+            }
+            ps_wave_sync();
+            // ---- backward (A.6): lane = level of the recorded path ----
+            const float disc_live = t.two_player ? (1.0f * t.discount) * -1.0f : 1.0f * t.discount;       // context.py:142-143
+            const float leaf_v = u2f(T[dst * QN_WORDS + QN_RAW_VALUE]), leaf_u = u2f(T[dst * QN_WORDS + QN_RAW_VAR]);
+            float Gin = leaf_v, Uin = leaf_u;
+            if (tl < 16) {
+                const int tj = tl;
+                for (int c = (D - 1) >> 4; c >= 0; --c) {
+                    const int d = c * 16 + tj;
+                    const bool valid = d < D;
+                    const int pn = P[valid ? d : 0] & 0xFF;
+                    const int cn = (valid && d + 1 < D) ? (P[d + 1] & 0xFF) : dst;  // the child this level's edge leads to
+                    uint32_t* R = T + pn * QN_WORDS;
+                    const uint32_t* Cn = T + cn * QN_WORDS;
+                    const float er = u2f(Cn[QN_REWARD]), ed = (Cn[QN_META] >> 20) & 1u ? 0.0f : disc_live;
+                    const int cnt_i = static_cast<int>(R[QN_META] & 0xFFu);
+                    const float nv = u2f(R[QN_NODE_VALUE]), nvar = u2f(R[QN_NODE_VAR]);
+                    const int top = (D - c * 16 < 16 ? D - c * 16 : 16) - 1;  // deepest level of this chunk
+                    *reinterpret_cast<float2*>(&M.edge[ti][tj][0]) = make_float2(er, ed);
+                    ps_wave_sync();
+                    float ers[16], eds[16];
+#pragma unroll
+                    for (int s4 = 0; s4 < 8; ++s4) {
+                        const floatx4 v = *reinterpret_cast<const floatx4*>(&M.edge[ti][2 * s4][0]);
+                        ers[2 * s4] = v[0]; eds[2 * s4] = v[1]; ers[2 * s4 + 1] = v[2]; eds[2 * s4 + 1] = v[3];
+                    }
+                    float G = Gin, U = Uin;
+#pragma unroll
+                    for (int lv = 15; lv >= 0; --lv) {
+                        const float rs = ers[lv], dd = eds[lv];
+                        if (lv <= top && lv >= tj) {
+                            G = rs + dd * G;
+                            U = 0.0f + (dd * dd) * U;  // children_rewards_epistemic_variance == 0 (context.py:149)
+                        }
+                    }
+                    const float cnt = static_cast<float>(cnt_i);
+                    const float pv = (nv * cnt + G) / (cnt + 1.0f);
+                    const float pvar = var_backup_update(t.var_backup, nvar, cnt, U);
+                    if (valid) {
+                        R[QN_NODE_VALUE] = f2u(pv);
+                        R[QN_NODE_VAR] = f2u(pvar);
+                        R[QN_META] = (R[QN_META] & ~0xFFu) | static_cast<uint32_t>(cnt_i + 1);
+                    }
+                    Gin = __shfl(G, 0, 16); Uin = __shfl(U, 0, 16);
+                    ps_wave_sync();
+                }
+            }
+            ps_wave_sync();
+            EAZ_QPSTAMP(1);
+        }
+        if (s == 0 && it > 0) {
+            // ---- the search of real step `step - 1` is complete: gumbel_muzero_policy tail (A.2, tree_finish_kernel), epistemic_summary
+            // (A.7, tree_summary_kernel), action choice (selfplay.py:118-134), SelfplayOutput[t] except the state ----
+            EAZ_QP_ARGS;
+            const int pstep = step - 1;
+            const Key kt = fold(a.sp.key, kTagStep + static_cast<uint32_t>(pstep));
+            if (slot == 0) {
+                NodeRows<4> rw;
+                const uint32_t cw = T[QN_CHILD + q];
+                float gum[4];
+                const uint8_t inv[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = (cw >> (8 * j)) & 0xFFu;
+                    const bool has = c != 0xFF;
+                    const uint32_t* Cn = T + (has ? c : 0) * QN_WORDS;
+                    const uint32_t meta = Cn[QN_META];
+                    rw.logits[j] = M.root_logits[ti][4 * q + j];
+                    rw.values[j] = has ? u2f(Cn[QN_NODE_VALUE]) : 0.0f;
+                    rw.rewards[j] = has ? u2f(Cn[QN_REWARD]) : 0.0f;
+                    rw.discounts[j] = has ? ((meta >> 20) & 1u ? 0.0f : (t.two_player ? (1.0f * t.discount) * -1.0f : 1.0f * t.discount)) : 0.0f;
+                    rw.visits[j] = has ? static_cast<int>(meta & 0xFFu) : 0;
+                    rw.index[j] = has ? c : -1;
+                    rw.var[j] = has ? u2f(Cn[QN_NODE_VAR]) : 0.0f;
+                    rw.rvar[j] = 0.0f;
+                    gum[j] = M.gumbel[ti][4 * q + j];
+                }
+                float cq[4];
+                qtransform<4, 4>(t, g, rw, u2f(T[QN_RAW_VALUE]), u2f(T[QN_RAW_VAR]), beta, cq);
+                int lmax = 0, lsumN = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { lmax = rw.visits[j] > lmax ? rw.visits[j] : lmax; lsumN += rw.visits[j]; }
+                const int maxN = gmaxi<4>(lmax);
+                const int totN = gsumi<4>(lsumN);
+                int act = root_pick<4, 4>(t, g, rw, cq, static_cast<float>(maxN), gum, inv);
+                float x[4], aw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = rw.logits[j] + cq[j];
+                const float mx = g.vmax(x);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = x[j] - mx;  // no invalid actions
+                g.softmax(x, aw);
+                const float ftot = static_cast<float>(totN);
+                float qvar[4], vprob[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = rw.discounts[j];
+                    qvar[j] = 0.0f + (d * d) * rw.var[j];  // children_rewards_epistemic_variance == 0
+                    vprob[j] = static_cast<float>(rw.visits[j]) / (ftot > 1.0f ? ftot : 1.0f);
+                }
+                // action choice: categorical over visit PROBABILITIES / action weights used as logits (reproduced literally) = argmax(x + Gumbel)
+                if (a.sp.flags & kSpSampleVisits) {
+                    const Key kvis = fold(kt, kTagSampleVisits);
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = vprob[j] + gumbel(kvis, static_cast<uint32_t>(gb * kQpA + 4 * q + j));
+                    act = g.argmax(v);
+                }
+                if (a.sp.flags & kSpSampleImproved) {
+                    const Key kimp = fold(kt, kTagSampleImproved);
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = aw[j] + gumbel(kimp, static_cast<uint32_t>(gb * kQpA + 4 * q + j));
+                    act = g.argmax(v);
+                }
+                const long o = static_cast<long>(pstep) * B + gb;
+                if (tree_live && a.sp.out_qvar) *reinterpret_cast<floatx4*>(a.sp.out_qvar + o * kQpA + 4 * q) = floatx4{qvar[0], qvar[1], qvar[2], qvar[3]};
+                if (q == 0) {
+                    M.real_action[ti] = act;
+                    if (tree_live) {
+                        if (a.sp.out_value_pred) a.sp.out_value_pred[o] = M.root_v[ti];
+                        if (a.sp.out_ube_pred) a.sp.out_ube_pred[o] = M.root_u[ti];
+                        if (a.sp.out_root_value) a.sp.out_root_value[o] = u2f(T[QN_NODE_VALUE]);
+                        if (a.sp.out_root_std) a.sp.out_root_std[o] = __builtin_sqrtf(u2f(T[QN_NODE_VAR]));
+                        if (a.sp.out_action) a.sp.out_action[o] = act;
+                    }
+                }
+            }
+            env_mode = 1;
+            env_key = fold(kt, kTagEnv);
+        } else if (s >= 1) {
+            // ---- re-score the nodes whose selection inputs changed: the path's levels 0 .. D-1 and the (re-)expanded node (s == 1: the root) ----
+            EAZ_QP_ARGS;
+            const int D = s >= 2 ? M.D[ti] : 0, dst = s >= 2 ? M.dst[ti] : 0;
+            const int nl = D + 1;
+            for (int l = slot; l < nl; l += 8) {
+                const int node = l < D ? (P[l] & 0xFF) : dst;
+                uint32_t* R = T + node * QN_WORDS;
+                NodeRows<4> rw;
+                const uint32_t cw = R[QN_CHILD + q];
+                floatx4 lg4;
+                if (node == 0) lg4 = *reinterpret_cast<const floatx4*>(&M.root_logits[ti][4 * q]);
+                else if (l == D) lg4 = *reinterpret_cast<const floatx4*>(&M.new_logits[ti][4 * q]);
+                else lg4 = *reinterpret_cast<const floatx4*>(LG + node * kQpA + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = (cw >> (8 * j)) & 0xFFu;
+                    const bool has = c != 0xFF;
+                    const uint32_t* Cn = T + (has ? c : 0) * QN_WORDS;
+                    const uint32_t meta = Cn[QN_META];
+                    rw.logits[j] = lg4[j];
+                    rw.values[j] = has ? u2f(Cn[QN_NODE_VALUE]) : 0.0f;
+                    rw.rewards[j] = has ? u2f(Cn[QN_REWARD]) : 0.0f;
+                    rw.discounts[j] = has ? ((meta >> 20) & 1u ? 0.0f : (t.two_player ? (1.0f * t.discount) * -1.0f : 1.0f * t.discount)) : 0.0f;
+                    rw.visits[j] = has ? static_cast<int>(meta & 0xFFu) : 0;
+                    rw.index[j] = has ? c : -1;
+                    rw.var[j] = (has && need_var) ? u2f(Cn[QN_NODE_VAR]) : 0.0f;
+                    rw.rvar[j] = 0.0f;
+                }
+                float cq[4];
+                qtransform<4, 4>(t, g, rw, u2f(R[QN_RAW_VALUE]), need_var ? u2f(R[QN_RAW_VAR]) : 0.0f, beta, cq);
+                int lsumN = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lsumN += rw.visits[j];
+                const int sumN = gsumi<4>(lsumN);
+                int act;
+                if (node == 0) {
+                    // gumbel_muzero_root_action_selection (A.4)
+                    float gum[4];
+                    const uint8_t inv[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gum[j] = M.gumbel[ti][4 * q + j];
+                    const int simidx = sumN > S - 1 ? S - 1 : sumN;
+                    const float cvis = static_cast<float>(t.table[static_cast<long>(nc) * S + simidx]);
+                    act = root_pick<4, 4>(t, g, rw, cq, cvis, gum, inv);
+                } else {
+                    // gumbel_muzero_interior_action_selection (A.4)
+                    float x[4], pr[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[j] = rw.logits[j] + cq[j];
+                    g.softmax(x, pr);
+                    const float den = static_cast<float>(1 + sumN);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[j] = pr[j] - static_cast<float>(rw.visits[j]) / den;
+                    act = g.argmax(x);
+                }
+                int mine = -2147483647 - 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * q + j == act) mine = rw.index[j];
+                const int nx = gmaxi<4>(mine);
+                if (q == 0) R[QN_SEL] = (static_cast<uint32_t>(act) << 8) | (static_cast<uint32_t>(nx) & 0xFFu);
+            }
+            ps_wave_sync();
+            EAZ_QPSTAMP(2);
+            // ---- select (A.4): walk the cached choices ----
+            if (tl == 0) {
+                int node = 0, depth = 0, act, nx;
+                while (true) {
+                    const uint32_t sw = T[node * QN_WORDS + QN_SEL];
+                    act = static_cast<int>((sw >> 8) & 0xFu);
+                    nx = static_cast<int>(sw & 0xFFu);
+                    P[depth] = static_cast<uint16_t>(node | (act << 8));
+                    depth += 1;
+                    if (nx == 0xFF || depth >= max_depth) break;
+                    node = nx;
+                }
+                M.parent[ti] = node; M.action[ti] = act; M.dst[ti] = nx == 0xFF ? s : nx; M.D[ti] = depth;  // simulation s - 1 expands node s
+            }
+            EAZ_QPSTAMP(3);
+        }
+        if (it > 0) {
+            // ---- E: env.step of the 16 chosen edges (s >= 1) or the real auto-reset step (s == 0), one environment per wave at a time ----
+            if (tid == 0) M.env_next = 0;
+            __syncthreads();
+            EAZ_QPSTAMP(4);
+            {
+                EAZ_QP_ARGS;
+                int j = wave;
+                const uint32_t env_next_off = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) int*)(&M.env_next)));
+#pragma unroll 1
+                while (j < kQpTrees) {
+                    const int bj = b0 + j < B ? b0 + j : B - 1;
+                    const bool jlive = b0 + j < B;
+                    uint32_t* SJ = states + j * N * QS_WORDS;
+                    float rew;
+                    int term;
+                    if (env_mode == 0) {
+                        const int node = __builtin_amdgcn_readfirstlane(M.parent[j]), action = __builtin_amdgcn_readfirstlane(M.action[j]);
+                        const int dstn = __builtin_amdgcn_readfirstlane(M.dst[j]);
+                        qp_env_step(a.e, SJ + node * QS_WORDS, SJ + dstn * QS_WORDS, M.root_ex[j], M.words[j], action, 0, env_key, bj, lane, nullptr, nullptr,
+                                    rew, term);
+                        if (lane == 0) { M.o_reward[j] = rew; M.o_term[j] = term; }  // rewards[b, current_player], single player
+                    } else {
+                        // vmap(auto_reset(env.step, env.init)) (selfplay.py:26-75,135) on the environment's current state
+                        const int action = __builtin_amdgcn_readfirstlane(M.real_action[j]);
+                        const long o = static_cast<long>(step - 1) * B + bj;
+                        char* blob0 = (jlive && a.sp.out_states) ? a.sp.out_states + o * sizeof(eaz_subleq_state) : nullptr;
+                        char* blob1 = (jlive && step == n_steps) ? a.sp.states + static_cast<long>(bj) * sizeof(eaz_subleq_state) : nullptr;
+                        qp_env_step(a.e, M.root_state[j], M.root_state[j], M.root_ex[j], M.words[j], action, 1, env_key, bj, lane, blob0, blob1, rew, term);
+                    }
+                    int got;
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(env_next_off), "v"(1) : "memory");
+                    j = 8 + (__builtin_amdgcn_readfirstlane(got) >> 6);
+                }
+            }
+            EAZ_QPSTAMP(5);
+            __syncthreads();
+            if (it == n_iter) break;
+        }
+        if (s == 0) {
+            // ---- a new real step: empty tree (mctx instantiate_tree_from_root, A.3) ----
+            for (int n = tl; n < N; n += 32) {
+                uint32_t* R = T + n * QN_WORDS;
+#pragma unroll
+                for (int w = 0; w < QN_WORDS; ++w) R[w] = w >= QN_SEL ? 0xFFFFFFFFu : 0u;
+            }
+        }
+        // ---- F: the forward of the three heads for the 16 observations whose row-words are in M.words ----
+        EAZ_QPSTAMP(6);
+        {
+            EAZ_QP_ARGS;
+            for (int idx = tid; idx < 16 * 48; idx += kQpThreads) {
+                const int row = idx / 48, w = idx - row * 48;
+                const uint32_t code = M.words[row][w];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) Xs[h16_off(5 * w + j, row)] = (code >> j) & 1u ? 1.0f : 0.0f;
+            }
+#pragma unroll 1
+            for (int h = 0; h < 3; ++h) {
+                if (wave < 4) {
+                    fc16p_body(a.net, nullptr, B, a.out, a.heads.id[h], b0, fwd, tid & 255, nullptr, Xs);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kFpBarriers; ++k) {
+                        __syncthreads();  // the barriers of fc16p_body
+                        if (k == 0 && h == 0 && wave == 4) {
+                            // behind the barrier that publishes the observation tile, so that the MFMA waves do not wait for the bit-set load
+                            qp_novelty(a.net, M, lane);
+                        }
+                    }
+                }
+            }
+        }
+        EAZ_QPSTAMP(7);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __syncthreads();
+        if (s == 0) {
+            // ---- root of real step `step`: selfplay.py:92-106,113 (root_prep_kernel) + mctx instantiate_tree_from_root (tree_root_kernel) ----
+            EAZ_QP_ARGS;
+            const float* net_logits = a.heads.id[2] == 2 ? a.out.exploit : a.out.explore;
+            const Key kt = fold(a.sp.key, kTagStep + static_cast<uint32_t>(step));
+            const Key gkey = fold(kt, kTagGumbel);
+            float lgv = -kInf;
+            if (tl < 16) {
+                lgv = (a.sp.flags & kSpUniform) ? 1.0f : net_logits[static_cast<long>(gb) * kQpA + tl];  // :96-98
+                const long gi = static_cast<long>(gb) * kQpA + tl;
+                const float gn = a.sp.gumbel ? a.sp.gumbel[static_cast<long>(step) * B * kQpA + gi] : gumbel(gkey, static_cast<uint32_t>(gi));
+                M.gumbel[ti][tl] = a.sp.gumbel_scale * gn;
+            }
+            const float m = gmax<16>(lgv);  // mask_invalid_actions (A.2): every action legal (subleq.py:626)
+            if (tl < 16) M.root_logits[ti][tl] = lgv - m;
+            if (tl == 0) {
+                const float root_v = a.out.value[gb];
+                const float root_u = ube_combine(a.out.ube[gb], M.o_nov[ti], t.max_u);  // fully_connected.py:92-96
+                T[QN_RAW_VALUE] = f2u(root_v); T[QN_NODE_VALUE] = f2u(root_v);
+                T[QN_RAW_VAR] = f2u(root_u); T[QN_NODE_VAR] = f2u(root_u);
+                T[QN_META] = 1u | (0xFFu << 8);
+                M.root_v[ti] = root_v; M.root_u[ti] = root_u;
+                M.D[ti] = 0; M.parent[ti] = 0; M.action[ti] = 0; M.dst[ti] = 0;
+            }
+            if (tl < QS_WORDS) ST[tl] = M.root_state[ti][tl];
+            ps_wave_sync();
+        }
+    }
+}
+
+}  // namespace eaz

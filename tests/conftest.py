@@ -31,7 +31,8 @@ def eaz():
 # Every GPU test runs once per kernel selection (include/eaz.h eaz_tune_set): all of them must give identical results.
 KERNEL_VARIANTS = {
     # name: (fc_tile, fused_leaf, tree_block, tree_spread, persist, shards)
-    "persist": (0, 1, 64, 0, 1, 0),           # default: eligible searches (DeepSea, FC, trees fit LDS) run as ONE persistent launch
+    "persist": (0, 1, 64, 0, 1, 0),           # default: eligible self-play calls (DeepSea / Subleq-16, FC, trees fit LDS) run as ONE launch
+    "persist-step": (0, 1, 64, 0, 2, 0),      # one launch per SEARCH: Subleq-16 subleq16_search_kernel + the per-real-step kernels around it
     "auto-fused": (0, 1, 64, 0, 0, 1),        # 16-row FC tiles, DeepSea leaf step fused into the tree kernel + one-hot forward
     "tile16-unfused": (16, 0, 128, 4, 0, 1),  # 16-row FC tiles on dense observation rows, separate leaf-gather launch
     "tile64-sharded": (64, 0, 256, 1, 0, 2),  # 64-row FC tiles, separate leaf-gather launch, 256-thread tree workgroups; every search of

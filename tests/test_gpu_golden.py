@@ -165,6 +165,38 @@ def test_wide_action_sets_selfplay_matches_oracle(oracle, eaz, torch, W, B, S):
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
 
 
+@pytest.mark.parametrize("flags", [{}, dict(directed_exploration=True, exploration_beta=1.0), dict(sample_actions=True),
+                                   dict(sample_from_improved_policy=True, uniform_search_policy=True)])
+def test_subleq16_selfplay_crosses_episode_boundaries(oracle, eaz, torch, flags):
+    """Subleq-16 self-play over more real steps than an episode has (episodes end at _step_count >= 13, subleq.py:671-673): searches from
+    terminated roots, the auto-reset inside selfplay (selfplay.py:26-75,135) with a task drawn per reset (subleq.py:624), a ragged batch
+    (40 = 2.5 workgroups of the one-launch kernel), every action-choice flag.  Generated Gumbel noise (the engine's key derivation)."""
+    from e_alphazero_amd import engine
+
+    W, B, S, T = 16, 40, 24, 17
+    tasks = (1, 2, 3)
+    dims, params, state = subleq_setup(eaz, W, seed=11, fill=0.4)
+    env = engine.EnvHandle.subleq(W, tasks, True, device=0)
+    net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
+    oenv = oracle.OracleEnv.subleq(W, tasks, True)
+    onet = oracle.OracleNet(dims["in_dim"], 256, W, eaz.params.fc_weight_list(params), hash_off=dims["hash_off"],
+                            hash_len=dims["hash_len"], bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+    explore = bool(flags.get("directed_exploration", False))
+    search = engine.Search(env, net, B, S, discount=0.97, exploration=explore)
+    st = env.init(B, key=13)
+    ost = oenv.init(B, key=(13, 0))
+    assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost)
+    out = search.selfplay(st, T, key=57, **flags)
+    ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(57, 0), discount=0.97, **flags)
+    assert np.array_equal(out["action"].cpu().numpy(), ref["action"])
+    assert np.array_equal(subleq_device_to_oracle(out["state"].cpu().numpy(), W), ref["state"])
+    assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost)
+    for k in ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction", "q_values_epistemic_variance"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
+    sc = ref["state"].view(np.uint8)[..., 0:4].copy().view(np.int32)[..., 0]
+    assert (np.diff(sc.astype(np.int64), axis=0) < 0).any(), "no episode ended inside the window: the test lost its point"
+
+
 def test_empty_batches_are_no_ops(eaz, torch):
     """B = 0 through the C ABI: every batched entry point accepts an empty batch (null data pointers included)."""
     from e_alphazero_amd import engine

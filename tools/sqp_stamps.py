@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Phase breakdown of subleq16_selfplay_kernel at C3 from the diagnostic build (make -C e-alphazero_amd/csrc diag): s_memtime stamps of
+simulation S/2 of the first real step, lane 0 of each of the eight waves of every workgroup (search_subleq_persist.hpp EAZ_QPSTAMP).
+Stamp slots that a wave never wrote stay 0 and are dropped, never subtracted."""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("EAZ_LIB", os.path.join(ROOT, "e-alphazero_amd", "libeaz_diag.so"))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import e_alphazero_amd as eaz  # noqa: E402
+from e_alphazero_amd import engine  # noqa: E402
+
+W, B, S, T = 16, int(os.environ.get("B", 4096)), 64, int(os.environ.get("T", 8))
+BETA = float(os.environ.get("BETA", 0.0))
+cols, rows = 5, W + 32
+in_dim, hash_off = rows * cols, W * cols
+params = eaz.params.init_fc_params(in_dim, 256, W, seed=0)
+env = engine.EnvHandle.subleq(W, (1,), True, device=0)
+net = engine.FCNet(env.ctx, in_dim, 256, W, params, eaz.params.init_hash_state(fill=0.5), hash_off=hash_off, hash_len=in_dim - hash_off)
+search = engine.Search(env, net, B, S, discount=0.97, exploration=BETA != 0.0)
+states = env.init(B, key=0)
+kw = dict(directed_exploration=True, exploration_beta=BETA) if BETA else {}
+search.selfplay(states, 6, key=0, **kw)   # mid-episode states
+for rep in range(2):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    search.selfplay(states.clone(), T, key=1 + rep, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+print(f"selfplay(T={T}): {1e3 * dt:.3f} ms = {1e6 * dt / (T * (S + 1)):.2f} us per forward (host-timed, one launch), {B * T / dt:.0f} env-steps/s")
+lib = eaz.load_library()
+buf = np.zeros(2 * 256 * 32, np.uint64)
+for fn, off in ((lib.eaz_diag_persist_stamps, 0), (lib.eaz_diag_persist_stamps2, 256 * 32)):
+    fn.argtypes = [C.c_void_p, C.c_void_p]
+    fn(search.h, buf[off:].ctypes.data)
+st = buf.reshape(256, 8, 8).astype(np.int64)
+st = st[(st[:, :, 4] > 0).all(axis=1)]
+
+
+def seg(name, d):
+    d = np.asarray(d).reshape(-1)
+    print(f"   {name:62s} median {np.median(d):8.0f}   p10 {np.percentile(d, 10):8.0f}   p90 {np.percentile(d, 90):8.0f} cycles")
+
+
+def diff(a, b):
+    """stamps[..., b] - stamps[..., a] over the waves that wrote both"""
+    x, y = st[:, :, a], st[:, :, b]
+    ok = (x > 0) & (y > 0)
+    return (y - x)[ok]
+
+
+print(f"{len(st)} workgroups, simulation {S // 2} of the first real step (shader-clock ticks of s_memtime)")
+seg("T: expand + backward (every wave: its two trees)", diff(0, 1))
+seg("T: re-score of the path's nodes", diff(1, 2))
+seg("T: select walk", diff(2, 3))
+seg("T -> E barrier", diff(3, 4))
+seg("E: interpreters of one wave (work queue)", diff(4, 5))
+seg("E: slowest wave of the workgroup", (st[:, :, 5] - st[:, :, 4]).max(axis=1))
+seg("E -> F barrier (wait for the slowest wave)", diff(5, 6))
+seg("F: observation tile + three heads in turn", diff(6, 7))
+t0 = st[:, :, 0].min(axis=1)
+seg("T (first wave in -> last wave at the T/E barrier)", st[:, :, 4].max(axis=1) - t0)
+seg("E (barrier to barrier)", st[:, :, 6].max(axis=1) - st[:, :, 4].max(axis=1))
+seg("one simulation (T start -> F end, wave 0)", st[:, 0, 7] - st[:, 0, 0])
