@@ -18,10 +18,11 @@ one-GPU box) the ranks share the card and the process group is gloo; the JSON li
 
 Before anything is timed the parity gate runs 16 environments of the benchmark's inputs through the engine and the CPU oracle and
 aborts on any difference.  Prints ONE JSON line on rank 0 (see the task contract), with `roofline` for the dominant kernel against the
-f32-MFMA peak (C2: search_persist_kernel, one launch per selfplay() call; C3: subleq16_search_kernel, one launch per real step; C4:
-resnet_forward_kernel), measured live with HIP events on the launch stream, `leaf_gather` / `roofline_gather` for the leaf-gather class,
-`extra.c3` / `extra.c4` (short passes of the other two configurations, default run only) and `cpu_baseline` = the CPU oracle timed on
-this host on a bounded sample of the same workload.
+f32-MFMA peak (C2: search_persist_kernel, C3: subleq16_selfplay_kernel, both one launch per selfplay() call; C4: resnet_forward_kernel),
+measured live with HIP events on the launch stream, `leaf_gather` / `roofline_gather` for the leaf-gather class, `extra.c3` / `extra.c4`
+(short passes of the other two configurations) plus `extra.c3_beta1` (directed exploration, beta = 1: the reference's experiment setting,
+slurm_experiment_submitter.py:203,209) and `extra.c2_empty_set` (SURVEY 8d's second C2 input), each behind its own parity gate (default
+run only), and `cpu_baseline` = the CPU oracle timed on this host on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -98,12 +99,15 @@ def cpu_share():
     return max(1, min(n, 16))
 
 
-def build_workload(name, args, device, rank):
-    """-> dict(env, net, search, selfplay kwargs, description strings, oracle factory for the CPU baseline)."""
+def build_workload(name, args, device, rank, beta=0.0):
+    """-> dict(env, net, search, selfplay kwargs, description strings, oracle factory for the CPU baseline).
+    beta != 0: directed exploration (config.py:38,172): exploration policy head in the search, beta * linspace(0, 1, B) per environment."""
     w = dict(WORKLOADS[name])
     B = args.batch or w["B"]
     S = args.sims or w["S"]
     T = args.selfplay_steps or w["T"]
+    explore = beta != 0.0
+    sp_kw = dict(directed_exploration=True, exploration_beta=float(beta)) if explore else {}
     if name == "c2":
         G, A = args.grid, 2
         # synthetic inputs (SURVEY.md 8d): action_map ~ Bernoulli(0.5) seed 0, random-init FC net seed 0, half-filled bit set
@@ -112,9 +116,10 @@ def build_workload(name, args, device, rank):
         hstate = eaz.params.init_hash_state(fill=args.hash_fill, seed=0)
         env = engine.EnvHandle.deepsea(G, am, device=device)
         net = engine.FCNet(env.ctx, G * G, H, A, params, hstate)
-        search = engine.Search(env, net, B, S, discount=0.997)
+        search = engine.Search(env, net, B, S, discount=0.997, exploration=explore)
         desc = f"DeepSea size={G}, batch={B}/GPU, {S} sims, {T} real steps per selfplay() call, FC H={H} (BASELINE.json configs[1])"
-        data = "synthetic (seeded DeepSea action map, random-init FC net, half-filled novelty set)"
+        fill_txt = "empty" if args.hash_fill == 0 else ("half-filled" if args.hash_fill == 0.5 else f"{args.hash_fill:g}-filled")
+        data = f"synthetic (seeded DeepSea action map, random-init FC net, {fill_txt} novelty set)"
         net_kernel, net_flops = "fc16_forward_kernel", fc_flops_per_eval(G * G, A, (0, 1, 2)) * B
         pmc_tag = f"DeepSea-{G}, B={B}, {S} sims"
         gather_kernel = "leaf_gather_deepsea_kernel"
@@ -131,12 +136,12 @@ def build_workload(name, args, device, rank):
         hstate = eaz.params.init_hash_state(fill=args.hash_fill, seed=0)
         env = engine.EnvHandle.subleq(W, (1,), True, device=device)     # task NEGATION_POSITIVE (config.py:18)
         net = engine.FCNet(env.ctx, in_dim, H, W, params, hstate, hash_off=hash_off, hash_len=in_dim - hash_off)
-        search = engine.Search(env, net, B, S, discount=0.97)
+        search = engine.Search(env, net, B, S, discount=0.97, exploration=explore)
         A = W
         desc = f"Subleq word_size={W} task=1 binary obs, batch={B}/GPU, {S} sims, {T} real steps per selfplay() call, FC H={H} (BASELINE.json configs[2])"
         data = "synthetic (random-init FC net, half-filled novelty set)"
         net_kernel, net_flops = "fc16p_forward_kernel", fc_flops_per_eval(in_dim, A, (0, 1, 2)) * B   # dense rows, narrow heads: the pipelined kernel
-        pmc_tag, gather_kernel = None, "subleq16_tree_leaf_kernel (tree step + env step + observation row + novelty)"
+        pmc_tag, gather_kernel = f"Subleq-{W}, B={B}, {S} sims", "subleq16_tree_leaf_kernel (tree step + env step + observation row + novelty)"
 
         def oracle(O):
             oenv = O.OracleEnv.subleq(W, (1,), True)
@@ -159,7 +164,9 @@ def build_workload(name, args, device, rank):
             onet = O.OracleNet.resnet(6, 7, 2, A, eaz.params.resnet_array_list(params, state, nb), num_blocks=nb)
             return oenv, onet, dict(discount=0.997, two_player=True), "connect_four"
     disc = {"c2": 0.997, "c3": 0.97, "c4": 0.997}[name]
-    return dict(w, name=name, B=B, S=S, T=T, A=A, env=env, net=net, search=search, desc=desc, data=data, net_kernel=net_kernel,
+    if explore:
+        desc += f", directed exploration beta={beta:g}"
+    return dict(w, sp_kw=sp_kw, beta=float(beta), name=name, B=B, S=S, T=T, A=A, env=env, net=net, search=search, desc=desc, data=data, net_kernel=net_kernel,
                 net_flops=net_flops, pmc_tag=pmc_tag, gather_kernel=gather_kernel, oracle=oracle, discount=disc, two_player=name == "c4",
                 in_dim=env.obs_dim)
 
@@ -356,19 +363,24 @@ def run_rank(args):
     # ---- the other single-GPU configurations of BASELINE.json, short passes after the timed region (driver-visible C3 / C4 numbers) ----
     if rank == 0 and n_gpus == 1 and args.workload == "c2" and not args.no_extra and not args.batch and not args.sims:
         result["extra"] = {}
-        for name, (xs, xw, xt) in (("c3", (3, 1, 0)), ("c4", (1, 1, 2))):
+        #                tag              workload (steps, warmup, T)  beta  hash fill
+        for tag, name, (xs, xw, xt), xbeta, xfill in (("c3", "c3", (3, 1, 0), 0.0, None), ("c3_beta1", "c3", (3, 1, 0), 1.0, None),
+                                                      ("c2_empty_set", "c2", (3, 1, 0), 0.0, 0.0), ("c4", "c4", (1, 1, 2), 0.0, None)):
             xargs = argparse.Namespace(**vars(args))
             xargs.workload, xargs.selfplay_steps = name, xt
+            if xfill is not None:
+                xargs.hash_fill = xfill
             wl = meas = None
             torch.cuda.empty_cache()
             try:  # a side measurement must never cost the headline line
-                wl = build_workload(name, xargs, device, rank)
+                wl = build_workload(name, xargs, device, rank, beta=xbeta)
+                gate = parity_gate(wl, xargs) if not args.no_cpu_baseline else None   # raises: the pass is then reported as an error, not timed
                 meas = measure(wl, xargs, rank, None, False, dev, steps=xs, warmup=xw)
-                result["extra"][name] = dict({"metric": wl["metric"], "value": wl["B"] * wl["T"] * xs / meas["dt"], "unit": "env-steps/s",
-                                              "steps": xs, "warmup": xw, "ms_per_step": 1e3 * meas["dt"] / xs,
-                                              "config": {"workload": wl["desc"]}}, **meas["fields"])
-            except Exception as exc:  # noqa: BLE001
-                result["extra"][name] = {"error": f"{type(exc).__name__}: {exc}"}
+                result["extra"][tag] = dict({"metric": wl["metric"], "value": wl["B"] * wl["T"] * xs / meas["dt"], "unit": "env-steps/s",
+                                             "steps": xs, "warmup": xw, "ms_per_step": 1e3 * meas["dt"] / xs,
+                                             "config": {"workload": wl["desc"]}, "data": wl["data"], "parity_gate": gate}, **meas["fields"])
+            except (Exception, SystemExit) as exc:  # noqa: BLE001
+                result["extra"][tag] = {"error": f"{type(exc).__name__}: {exc}"}
         wl = meas = None
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload, rank 0 at N = 1 only -------------------
@@ -402,14 +414,14 @@ def parity_gate(wl, args):
 
     nb, nt = 16, 2 if wl["name"] != "c4" else 1
     S = wl["S"] if wl["name"] != "c4" else 32      # connect_four on the CPU: a shorter search keeps the gate at a few seconds
-    kw = dict(discount=wl["discount"], two_players_game=wl["two_player"])
+    kw = dict(discount=wl["discount"], two_players_game=wl["two_player"], exploration=wl["beta"] != 0.0)
     search = engine.Search(wl["env"], wl["net"], nb, S, **kw)
     st = wl["env"].init(nb, key=0)
-    out = search.selfplay(st, nt, key=4242)
+    out = search.selfplay(st, nt, key=4242, **wl["sp_kw"])
     torch.cuda.synchronize()
     oenv, onet, okw, oname = wl["oracle"](O)
     ost = oenv.init(nb)
-    ref = O.selfplay(oenv, onet, ost, T=nt, S=S, key=engine.key_pair(4242), **okw)
+    ref = O.selfplay(oenv, onet, ost, T=nt, S=S, key=engine.key_pair(4242), **okw, **wl["sp_kw"])
     ok_int = bool(np.array_equal(out["action"].cpu().numpy(), ref["action"]) and np.array_equal(out["state"].cpu().numpy(), ref["state"])
                   and np.array_equal(st.cpu().numpy(), ost))
     err = max(float(np.max(np.abs(out[k].cpu().numpy() - ref[k]))) for k in
@@ -417,6 +429,8 @@ def parity_gate(wl, args):
     if not ok_int or not err <= 1e-5:
         raise SystemExit(f"bench.py parity gate FAILED on {oname}: integer results identical = {ok_int}, max float error = {err:.3g}")
     del search
+    if wl["beta"]:
+        oname += f", directed exploration beta={wl['beta']:g}"
     return {"checked": f"{oname}: {nb} environments x {nt} real steps x {S} simulations, engine vs CPU oracle (in-repo restatement; emctx parity unpinned)",
             "actions_states_bit_identical": ok_int, "max_abs_float_error": err, "tolerance": 1e-5}
 
@@ -431,7 +445,7 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
 
     def one_step(i):
         nonlocal outputs, gathered
-        outputs = search.selfplay(states, T, key=(1000 * rank + i), outputs=outputs)
+        outputs = search.selfplay(states, T, key=(1000 * rank + i), outputs=outputs, **wl["sp_kw"])
         if dist is not None:
             # pool the trajectories of all ranks (replay-buffer landing zone): ONE all-gather of the packed block
             block = pool.pack(outputs)
@@ -450,9 +464,9 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
     if warmup == 0:
         # graph capture, kernel module loading and (N > 1) the all-gather's buffers are one-time set-up: with --warmup 0 run one
         # single real step through the same path before the clock starts (not a step of the workload: T = 1)
-        search.selfplay(states, 1, key=(1000 * rank + 999))
+        search.selfplay(states, 1, key=(1000 * rank + 999), **wl["sp_kw"])
         if dist is not None:
-            blk = pool.pack(search.selfplay(states, 1, key=(1000 * rank + 998)))
+            blk = pool.pack(search.selfplay(states, 1, key=(1000 * rank + 998), **wl["sp_kw"]))
             pool.all_gather_trajectories(blk.cpu() if rehearsal else blk)
     # ---- timed region: EXACTLY K steps in the production configuration (one captured hipGraph per real step) ----
     sync()
@@ -475,7 +489,7 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
     n_instr = min(steps, 2) if name != "c4" else 1
     T_instr = T if name != "c4" else 1
     for i in range(n_instr):
-        search.selfplay(states, T_instr, key=(1000 * rank + 500 + i), outputs=outputs if T_instr == T else None, use_graph=False)
+        search.selfplay(states, T_instr, key=(1000 * rank + 500 + i), outputs=outputs if T_instr == T else None, use_graph=False, **wl["sp_kw"])
     sync()
     dt_instr = time.perf_counter() - t1
     prof = search.profile_read(reset=True)
@@ -490,8 +504,19 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
     A = wl["A"]
     l23 = sum(2 * (H * H + H * (1 if h < 2 else A)) for h in heads) * B
     dense_flops = wl["net_flops"]
-    if persistent and name == "c3":
-        # subleq16_search_kernel: all S simulations of a real step in one launch (tree step + interpreter + forward per simulation, 16 trees per
+    if persistent and name == "c3" and prof["search"]["launches"] == n_instr:
+        # subleq16_selfplay_kernel: ONE launch per selfplay() call = T real steps x (root inference + S simulations): tree phase on LDS node
+        # records, all-scalar interpreter, dense forward of 3 heads per simulation (16 trees per workgroup).  FLOPs: the (S + 1) forwards per
+        # real step, dense (the kernel runs layer 1 as whole rounds of 16 k-steps: the 4 zero-padded k-steps are not counted).
+        kname = "subleq16_selfplay_kernel"
+        n_launch = prof["search"]["launches"]
+        k_ms = search.profile_replay("search", 3)
+        pair_us = 1e3 * prof["search"]["ms"] / n_launch
+        flops = dense = T_instr * (S + 1) * dense_flops
+        algo = (f"{T_instr} real steps x ({S} simulations + root) x {B} rows x dense forward of 3 heads ({dense_flops // B} FLOP per row); the launch "
+                "also walks the trees and runs the Subleq interpreter, during which the MFMA pipes idle")
+    elif persistent and name == "c3":
+        # subleq16_search_kernel (EAZ_TUNE_PERSIST = 2): all S simulations of a real step in one launch (tree step + interpreter + forward per simulation, 16 trees per
         # workgroup).  A ~3 ms launch: the event pair of the instrumented pass is its duration (the ~4 us launch gap is 0.1 %).  FLOPs: the S
         # forwards, dense (the kernel runs whole rounds of layer 1; padded k-steps are not counted).
         kname = "subleq16_search_kernel"
@@ -546,20 +571,18 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
             # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE tallies a wide coalesced streaming read (16 B per lane) at half its
             # bytes -> doubled (the kernel's fetches are its 16-B-per-lane weight streams); WRITE_SIZE is exact for 16-B-per-lane stores
             roof["traffic"] = 1024.0 * (2.0 * k.get("FETCH_SIZE_KB_per_launch", 0.0) + k.get("WRITE_SIZE_KB_per_launch", 0.0))
-            roof["traffic_source"] = f"profiles/{cand} (2 x FETCH_SIZE [gfx950 16-B/lane correction] + WRITE_SIZE, bytes per launch)"
+            roof["traffic_source"] = (f"profiles/{cand} (2 x FETCH_SIZE [gfx950 16-B/lane correction] + WRITE_SIZE, bytes per launch; recorded by "
+                                      "rocprofv3 --pmc passes over this workload, not inside this process)")
             break
     fields["roofline"] = roof
     # ---- leaf gather (north-star: >= 40 % of the HBM roof on the leaf-gather kernel) ----
     gbytes = B * (2 * env.state_bytes + env.obs_dim)
-    if prof["gather"]["launches"] == 0 and args.workload == "c3":
-        sims = max(T_instr * n_instr * S, 1)
+    if prof["gather"]["launches"] == 0 and name == "c3":
         fields["leaf_gather"] = {
-            "status": "fused into the tree kernel for this configuration",
-            "kernel": wl["gather_kernel"],
-            "avg_us_per_simulation_tree_plus_leaf": 1e3 * prof["tree"]["ms"] / sims,
-            "why": "Subleq-16: one wavefront per tree walks the tree, runs the interpreter for the chosen edge (parent slot -> child slot), writes the "
-                   "observation row and looks its novelty up; the launch is bound by the slowest interpreter run (<= 200 cycles of one wavefront), "
-                   "not by the 3.7 MB it moves (DESIGN.md 4.4)"}
+            "status": "retired for this configuration",
+            "why": "Subleq-16: the search kernel keeps every node's state in LDS (32 bytes: the program as sixteen 4-bit words, input_after / "
+                   "output_after, a header), steps the chosen edge with its all-scalar interpreter LDS to LDS, and hands the forward the observation "
+                   "as 240 bits per row -- no gather launch, no state or observation traffic to HBM in the timed path (DESIGN.md 4.4)"}
     elif prof["gather"]["launches"] == 0:
         fields["leaf_gather"] = {
             "status": "retired for this configuration",

@@ -1107,7 +1107,6 @@ static int sqp_launch(eaz_search* s, const PersistSelfplay& sp, hipStream_t st) 
     a.t = s->tree;
     a.e = s->env->dev;
     a.net = s->net->dev;
-    a.out = NetOut{s->opts.exploration ? nullptr : s->d_exploit, s->opts.exploration ? s->d_explore : nullptr, s->d_v, s->d_u};
     a.heads = HeadList{3, {0, 1, s->opts.exploration ? 3 : 2, 0}};  // context.py:132
     a.logits = s->d_sq_logits;
     a.stamps = s->d_stamps;

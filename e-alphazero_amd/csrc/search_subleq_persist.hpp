@@ -18,7 +18,14 @@
 //      through the cached choices;
 //   E  env.step of the 16 chosen edges by the all-scalar interpreter of env_kernels.hpp (subleq16_wave_run), one environment per
 //      wavefront at a time from a work queue, LDS to LDS;
-//   F  the forward of the three heads self-play reads for the 16 new observations.
+//   F  the forward of the three heads self-play reads for the 16 new observations, heads in turn on waves 0-3 (wave w owns 64 hidden
+//      columns) with the weight stream of search_persist.hpp: ONE continuous buffer-load stream W1(h) | W2(h) | W1(h+1) ... 16 k-steps
+//      ahead in registers, cyclic over the heads, so the first k-steps of the next simulation are in flight during T and E.  The
+//      observation never becomes a tile: a Subleq observation is 240 bits, the interpreter's wave leaves them as four 64-bit masks per
+//      row (mask kq, bit ks = input 4 ks + kq: exactly the A operands lane (row, kq) feeds to k-step ks), and layer 1's A operand is
+//      `(float)((mask >> ks) & 1)` -- no LDS traffic in layer 1 at all.  Layer 3 = quarter chains whose operands W3 stay in registers
+//      for the whole launch; a head's chain rides in the first round of the next head (ps_round).  The heads' outputs are never
+//      materialised: expand / root preparation read the four quarter sums and apply ((c0 + c1) + (c2 + c3)) + b themselves.
 // Same float operations in the same order as tree_step_kernel<16,1> / fc16p_forward_kernel (the 16-slot butterfly sum is
 // lsum<4> + two quad exchanges), so results are bit-identical to the per-simulation path and to the oracle (tests/conftest.py variants).
 #pragma once
@@ -59,18 +66,24 @@ struct QpMisc {
     int real_action[kQpTrees];
     int env_next;
     int pad[3];
+    float o_value[kQpTrees], o_ube[kQpTrees];
+    float b3[20];                       // output biases: value, ube, the 16 policy logits
+    float b12[3][2][kFcH];              // hidden-layer biases of the three heads (layer 1, layer 2)
+    unsigned long long xbits[kQpTrees][4];  // observation bits of the 16 rows: [row][kq] bit ks = input 4 ks + kq (the MFMA A operands of layer 1)
     uint8_t words[kQpTrees][48];        // row-words of the 16 observations in flight, 5 observation bits each (subleq.py:88-98)
 };
+constexpr int kQpPartLd = 20;  // quarter sums [4 waves][16 rows][kQpPartLd]: slot 0 value, 1 ube, 2..17 policy logits
 
 struct QpLds {
     int tstride;  // words per tree
-    int off_fwd, off_x, off_tree, off_state, off_path, off_misc, total;
+    int off_h1, off_h2, off_part, off_tree, off_state, off_path, off_misc, total;
 };
 __host__ __device__ inline QpLds qp_lds(int N, int S) {
     QpLds L;
     int o = 0;
-    L.off_fwd = o; o += fp_lds_bytes(240, kQpA);
-    L.off_x = o; o += fp_xfloats(240) * 4;
+    L.off_h1 = o; o += 2 * kF16HBytes;  // two H1 tiles: head h + 1 writes its tile while slower waves may still read head h's
+    L.off_h2 = o; o += kF16HBytes;      // every wave reads back only the 64 columns it wrote
+    L.off_part = o; o += 4 * 16 * kQpPartLd * 4;
     L.tstride = (N * QN_WORDS) | 1;
     L.off_tree = o; o += kQpTrees * L.tstride * 4;
     o = (o + 15) & ~15;
@@ -86,8 +99,7 @@ struct Sq16SelfplayArgs {
     TreeDev t;           // options, table; children_prior_logits is NOT used (see `logits`)
     EnvDev e;
     NetDev net;
-    NetOut out;          // [B] / [B,16] scratch the forward's heads write their outputs to
-    HeadList heads;
+    HeadList heads;      // value, ube, the policy head the search reads (context.py:132)
     float* logits;       // [ceil16(B), N, 16] prior-logit scratch rows of the trees
     unsigned long long* stamps;
 };
@@ -150,11 +162,53 @@ __device__ __forceinline__ void qp_emit_words(uint8_t* words, unsigned long long
     }
 }
 
+// The same observation as the A operands of layer 1: xb[kq] bit ks = observation input 4 ks + kq = bit (4 ks + kq) % 5 of row-word
+// (4 ks + kq) / 5 (subleq.py:88-98; inputs 240..255 are zero).  One ballot per mask; `words` was written by this wavefront.
+__device__ __forceinline__ void qp_emit_bits(unsigned long long* xb, const uint8_t* words, int lane) {
+    ps_wave_sync();
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+        const int k = 4 * lane + kq;
+        const int w = k / 5, j = k - 5 * w;
+        const bool bit = k < 240 && ((words[k < 240 ? w : 0] >> j) & 1u) != 0;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(bit);
+        if (lane == 0) xb[kq] = m;
+    }
+}
+
+// One round of the forward's weight stream (search_persist.hpp ps_round): 16 k-steps of four MFMAs each on the prefetched weights Bq,
+// every k-step followed by the refill of its registers.  ABITS: layer 1, A operand = bit i of `abits` as a float; otherwise layer 2,
+// A operands from the H1 tile kPsARing k-steps ahead.  CHAIN: the round also carries the 16 dependent MFMAs of the previous head's
+// layer-3 quarter chain (A from the H2 columns this wave wrote, B = `w3` in registers).
+template <bool CHAIN, bool ABITS>
+__device__ __forceinline__ void qp_round(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDepth], float (&av)[kPsARing], const float* apn, const uint32_t abits,
+                                         __amdgpu_buffer_rsrc_t rs, int voff, int sbase, floatx4& a3, const float* hpA, const float (&w3)[16]) {
+    static_assert(kPsDepth == 16, "a round is 16 k-steps");
+    float cha[kChRing];
+    if constexpr (CHAIN) {
+#pragma unroll
+        for (int qq = 0; qq < kChRing; ++qq) cha[qq] = hpA[68 * qq];
+    }
+#pragma unroll
+    for (int i = 0; i < kPsDepth; ++i) {
+        const float aop = ABITS ? static_cast<float>((abits >> i) & 1u) : av[i % kPsARing];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, Bq[i][c], acc[c], 0, 0, 0);
+        if constexpr (CHAIN) {
+            a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(cha[i % kChRing], w3[i], a3, 0, 0, 0);
+            if (i + kChRing < 16) cha[i % kChRing] = hpA[68 * (i + kChRing)];
+        }
+        Bq[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sbase + i * 4096, 0));
+        if constexpr (!ABITS) av[i % kPsARing] = apn[i * 68];
+        __builtin_amdgcn_sched_barrier(0);  // keep every refill right behind the k-step that freed its registers
+    }
+}
+
 // pgx.Env.step (A.1) around subleq.py:648-677 for ONE environment on one wavefront, compact state `src` (LDS) -> `dst` (LDS), everything
 // wavefront-uniform.  mode 0: plain step (search), 1: auto_reset(env.step, env.init) (selfplay.py:26-75), as subleq16_wave_body.
 // blob: also the 336-byte state of include/eaz.h (real steps); words: the observation's row-words.  Returns the reward / terminated flag.
 __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src, uint32_t* dst, const uint32_t* root_ex, uint8_t* words,
-                                            const int action, const int mode, const Key envkey, const int b, const int lane, char* blob0,
+                                            unsigned long long* xb, const int action, const int mode, const Key envkey, const int b, const int lane, char* blob0,
                                             char* blob1, float& reward_out, int& term_out) {
     uint32_t s[QS_WORDS];
 #pragma unroll
@@ -221,7 +275,8 @@ __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src
         d4[1] = make_uint4(static_cast<uint32_t>(outaf), static_cast<uint32_t>(outaf >> 32), qp_hdr(step_count, task, terminated, truncated, solved, exroot),
                            __builtin_bit_cast(uint32_t, reward));
     }
-    if (words) qp_emit_words(words, mem, exin, inaf, exout, outaf, lane);
+    qp_emit_words(words, mem, exin, inaf, exout, outaf, lane);
+    qp_emit_bits(xb, words, lane);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         char* blob = k == 0 ? blob0 : blob1;
@@ -311,8 +366,9 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
         logits_base = a.logits;
     }
     const QpLds L = qp_lds(N, S);
-    uint8_t* fwd = lds + L.off_fwd;
-    float* Xs = reinterpret_cast<float*>(lds + L.off_x);
+    float* H1 = reinterpret_cast<float*>(lds + L.off_h1);
+    float* H2 = reinterpret_cast<float*>(lds + L.off_h2);
+    float* part = reinterpret_cast<float*>(lds + L.off_part);
     uint32_t* trees = reinterpret_cast<uint32_t*>(lds + L.off_tree);
     uint32_t* states = reinterpret_cast<uint32_t*>(lds + L.off_state);
     uint16_t* path = reinterpret_cast<uint16_t*>(lds + L.off_path);  // [16][S]: node | action << 8
@@ -334,7 +390,38 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
     const bool need_var = beta != 0.0f;
 
     // ---------------------------------------------------------------- prologue ----------------------------------------------------
-    for (int idx = tid; idx < 16 * 16; idx += kQpThreads) Xs[h16_off(240 + (idx >> 4), idx & 15)] = 0.0f;  // inputs 240..255: zero for the whole launch
+    // ---- the forward's per-lane constants, resident for the whole launch: lane (r, kq) of wave w owns hidden columns 64 w + 4 r .. + 3;
+    // biases of those columns, and the layer-3 weights of the wave's quarter of k as MFMA B operands (W3[64 w + 4 q + kq][r], zero beyond
+    // the head's outputs) ----
+    const int fr = lane & 15, fkq = lane >> 4, fw = wave & 3;
+    const int fn0 = fw * 64, fcol = fn0 + 4 * fr, fvoff = (fkq * kFcH + fcol) * 4;
+    // The two one-output heads share a register set: B column 0 = W3 of the value head, column 1 = W3 of the ube head (a chain then also
+    // produces the other head's column from the wrong hidden tile, which nobody reads).
+    float w3v[2][16];  // [0]: value | ube, [1]: policy
+    floatx4 Bq[kPsDepth];  // the weight stream, 16 k-steps ahead
+    {
+        EAZ_QP_ARGS;
+        {
+            const float* pwv = a.net.w[a.heads.id[fr == 1 ? 1 : 0] * 3 + 2] + (fn0 + fkq);
+            const float* pwp = a.net.w[a.heads.id[2] * 3 + 2] + (fn0 + fkq) * kQpA + fr;
+#pragma unroll
+            for (int qq = 0; qq < 16; ++qq) {
+                const float wv = pwv[4 * qq], wp = pwp[4 * qq * kQpA];
+                w3v[0][qq] = fr < 2 ? wv : 0.0f;
+                w3v[1][qq] = wp;
+            }
+        }
+        for (int i = tid; i < 3 * 2 * kFcH; i += kQpThreads) {
+            const int h = i / (2 * kFcH), l = (i / kFcH) & 1, c = i & (kFcH - 1);
+            M.b12[h][l][c] = a.net.b[a.heads.id[h] * 3 + l][c];
+        }
+        if (tid < 18) M.b3[tid] = tid < 2 ? a.net.b[a.heads.id[tid] * 3 + 2][0] : a.net.b[a.heads.id[2] * 3 + 2][tid - 2];
+        const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.net.w[a.heads.id[0] * 3]), 0, fp_kpad(240) * kFcH * 4, 0x00020000);
+        if (wave < 4) {
+#pragma unroll
+            for (int i = 0; i < kPsDepth; ++i) Bq[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs0, fvoff, i * 4096, 0));
+        }
+    }
     for (int k = 0; k < 2; ++k) {
         EAZ_QP_ARGS;
         // the current states of two of the workgroup's environments: 336-byte blob -> compact root state + the observation's row-words
@@ -359,9 +446,16 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             M.root_ex[j][2] = static_cast<uint32_t>(exout); M.root_ex[j][3] = static_cast<uint32_t>(exout >> 32);
         }
         qp_emit_words(M.words[j], mem, exin, inaf, exout, outaf, lane);
+        qp_emit_bits(M.xbits[j], M.words[j], lane);
     }
     __syncthreads();
 
+    // output `slot` (0 value, 1 ube, 2.. policy logits) of row `row` from the four quarter sums: ((c0 + c1) + (c2 + c3)) + b (o_linear_parts)
+    auto head_out = [&](int row, int slot) {
+        const float* pp = part + row * kQpPartLd + slot;
+        const float c0 = pp[0], c1 = pp[16 * kQpPartLd], c2 = pp[32 * kQpPartLd], c3 = pp[48 * kQpPartLd];
+        return ((c0 + c1) + (c2 + c3)) + M.b3[slot];
+    };
     const int n_iter = n_steps * (S + 1);
 #pragma unroll 1
     for (int it = 0; it <= n_iter; ++it) {
@@ -372,18 +466,21 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             // ---- expand + backward of the simulation evaluated last (simulation s - 2; at s == 0: simulation S - 1 of the step before) ----
             EAZ_QP_ARGS;
             EAZ_QPSTAMP(0);
-            const float* net_logits = a.heads.id[2] == 2 ? a.out.exploit : a.out.explore;
             const int D = M.D[ti], dst = M.dst[ti], parent = M.parent[ti], action = M.action[ti];
             {
                 // epistemic_recurrent_fn (src/context.py:132-153) on the forward's outputs; mctx update_tree_node + topology (A.3)
-                float lgv = tl < 16 ? net_logits[static_cast<long>(gb) * kQpA + tl] : -kInf;
+                const float z = tl < 18 ? head_out(ti, tl < 16 ? 2 + tl : tl - 16) : 0.0f;
+                if (tl == 16) M.o_value[ti] = det_tanh(z);                                        // fully_connected.py:55
+                if (tl == 17) M.o_ube[ti] = (0.5f * (det_tanh(z) + 1.0f)) * a.net.max_u;          // :64, :93
+                float lgv = tl < 16 ? z : -kInf;
                 const float m = gmax<16>(lgv);                                                    // :135
+                ps_wave_sync();
                 lgv = lgv - m;                                                                     // :137 (every action legal, subleq.py:626)
                 if (tl < 16) { M.new_logits[ti][tl] = lgv; LG[dst * kQpA + tl] = lgv; }
                 if (tl == 0) {
                     const bool term = M.o_term[ti] != 0;
-                    const float value = term ? 0.0f : a.out.value[gb];                             // :140
-                    const float var = term ? 0.0f : ube_combine(a.out.ube[gb], M.o_nov[ti], t.max_u);  // :141
+                    const float value = term ? 0.0f : M.o_value[ti];                               // :140
+                    const float var = term ? 0.0f : ube_combine(M.o_ube[ti], M.o_nov[ti], t.max_u);    // :141
                     uint32_t* Rn = T + dst * QN_WORDS;
                     Rn[QN_RAW_VALUE] = f2u(value); Rn[QN_NODE_VALUE] = f2u(value);
                     Rn[QN_RAW_VAR] = f2u(var); Rn[QN_NODE_VAR] = f2u(var);
@@ -414,16 +511,11 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                     const int top = (D - c * 16 < 16 ? D - c * 16 : 16) - 1;  // deepest level of this chunk
                     *reinterpret_cast<float2*>(&M.edge[ti][tj][0]) = make_float2(er, ed);
                     ps_wave_sync();
-                    float ers[16], eds[16];
-#pragma unroll
-                    for (int s4 = 0; s4 < 8; ++s4) {
-                        const floatx4 v = *reinterpret_cast<const floatx4*>(&M.edge[ti][2 * s4][0]);
-                        ers[2 * s4] = v[0]; eds[2 * s4] = v[1]; ers[2 * s4 + 1] = v[2]; eds[2 * s4 + 1] = v[3];
-                    }
                     float G = Gin, U = Uin;
-#pragma unroll
+#pragma unroll 4
                     for (int lv = 15; lv >= 0; --lv) {
-                        const float rs = ers[lv], dd = eds[lv];
+                        const float2 ev = *reinterpret_cast<const float2*>(&M.edge[ti][lv][0]);  // broadcast read
+                        const float rs = ev.x, dd = ev.y;
                         if (lv <= top && lv >= tj) {
                             G = rs + dd * G;
                             U = 0.0f + (dd * dd) * U;  // children_rewards_epistemic_variance == 0 (context.py:149)
@@ -624,8 +716,8 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                     if (env_mode == 0) {
                         const int node = __builtin_amdgcn_readfirstlane(M.parent[j]), action = __builtin_amdgcn_readfirstlane(M.action[j]);
                         const int dstn = __builtin_amdgcn_readfirstlane(M.dst[j]);
-                        qp_env_step(a.e, SJ + node * QS_WORDS, SJ + dstn * QS_WORDS, M.root_ex[j], M.words[j], action, 0, env_key, bj, lane, nullptr, nullptr,
-                                    rew, term);
+                        qp_env_step(a.e, SJ + node * QS_WORDS, SJ + dstn * QS_WORDS, M.root_ex[j], M.words[j], M.xbits[j], action, 0, env_key, bj, lane,
+                                    nullptr, nullptr, rew, term);
                         if (lane == 0) { M.o_reward[j] = rew; M.o_term[j] = term; }  // rewards[b, current_player], single player
                     } else {
                         // vmap(auto_reset(env.step, env.init)) (selfplay.py:26-75,135) on the environment's current state
@@ -633,7 +725,8 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                         const long o = static_cast<long>(step - 1) * B + bj;
                         char* blob0 = (jlive && a.sp.out_states) ? a.sp.out_states + o * sizeof(eaz_subleq_state) : nullptr;
                         char* blob1 = (jlive && step == n_steps) ? a.sp.states + static_cast<long>(bj) * sizeof(eaz_subleq_state) : nullptr;
-                        qp_env_step(a.e, M.root_state[j], M.root_state[j], M.root_ex[j], M.words[j], action, 1, env_key, bj, lane, blob0, blob1, rew, term);
+                        qp_env_step(a.e, M.root_state[j], M.root_state[j], M.root_ex[j], M.words[j], M.xbits[j], action, 1, env_key, bj, lane, blob0, blob1,
+                                    rew, term);
                     }
                     int got;
                     asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(env_next_off), "v"(1) : "memory");
@@ -654,42 +747,107 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
         }
         // ---- F: the forward of the three heads for the 16 observations whose row-words are in M.words ----
         EAZ_QPSTAMP(6);
-        {
+        if (wave < 4) {
+            // ================= waves 0-3: layers 1-3 of the three heads for the 16 rows; barriers: H1 of head 0, 1, 2 | quarter sums =================
             EAZ_QP_ARGS;
-            for (int idx = tid; idx < 16 * 48; idx += kQpThreads) {
-                const int row = idx / 48, w = idx - row * 48;
-                const uint32_t code = M.words[row][w];
+            __amdgpu_buffer_rsrc_t W1r[3], W2r[3];
 #pragma unroll
-                for (int j = 0; j < 5; ++j) Xs[h16_off(5 * w + j, row)] = (code >> j) & 1u ? 1.0f : 0.0f;
-            }
-#pragma unroll 1
             for (int h = 0; h < 3; ++h) {
-                if (wave < 4) {
-                    fc16p_body(a.net, nullptr, B, a.out, a.heads.id[h], b0, fwd, tid & 255, nullptr, Xs);
-                } else {
+                W1r[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.net.w[a.heads.id[h] * 3]), 0, fp_kpad(240) * kFcH * 4, 0x00020000);
+                W2r[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.net.w[a.heads.id[h] * 3 + 1]), 0, kFcH * kFcH * 4, 0x00020000);
+            }
+            const unsigned long long xb = M.xbits[fr][fkq];  // this lane's layer-1 A operands: bit ks = observation input 4 ks + kq of row r
+            const float* hpA = H2 + h16_off(fn0 + fkq, fr);  // quarter chain: H2[h16_off(n0 + 4 q + kq, r)] = hpA[68 q]
+            float av[kPsARing];
 #pragma unroll
-                    for (int k = 0; k < kFpBarriers; ++k) {
-                        __syncthreads();  // the barriers of fc16p_body
-                        if (k == 0 && h == 0 && wave == 4) {
-                            // behind the barrier that publishes the observation tile, so that the MFMA waves do not wait for the bit-set load
-                            qp_novelty(a.net, M, lane);
+            for (int h = 0; h < 3; ++h) {
+                floatx4 acc[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+                floatx4 a3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+                // ---- layer 1: [16 x 256] x [256 x 256], inputs 240..255 zero on both sides (exact); the first round carries the quarter chain
+                // of the head before ----
+                if (h > 0) qp_round<true, true>(acc, Bq, av, nullptr, static_cast<uint32_t>(xb) & 0xFFFFu, W1r[h], fvoff, 4096 * kPsDepth, a3, hpA, w3v[0]);
+                else qp_round<false, true>(acc, Bq, av, nullptr, static_cast<uint32_t>(xb) & 0xFFFFu, W1r[h], fvoff, 4096 * kPsDepth, a3, hpA, w3v[0]);
+                if (h > 0 && fr == h - 1) {  // head 0 = value: output column 0, head 1 = ube: column 1 (shared W3 registers)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) part[(fw * 16 + 4 * fkq + reg) * kQpPartLd + fr] = a3[reg];
+                }
+#pragma unroll 1
+                for (int rd = 1; rd < 4; ++rd) {
+                    const bool same = rd < 3;  // the refills of the last round are the first k-steps of layer 2
+                    qp_round<false, true>(acc, Bq, av, nullptr, static_cast<uint32_t>(xb >> (16 * rd)) & 0xFFFFu, same ? W1r[h] : W2r[h], fvoff,
+                                          same ? 4096 * kPsDepth * (rd + 1) : 0, a3, hpA, w3v[0]);
+                }
+                {
+                    float* Ht = H1 + (h & 1) * kF16HFloats;
+                    const floatx4 bb1 = *reinterpret_cast<const floatx4*>(&M.b12[h][0][fcol]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        floatx4 o;
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const float v = acc[c][reg] + bb1[c];
+                            o[reg] = v > 0.0f ? v : 0.0f;
                         }
+                        *reinterpret_cast<floatx4*>(Ht + h16_off(fcol + c, 4 * fkq)) = o;
                     }
                 }
+                __syncthreads();  // H1 of head h
+                // ---- layer 2: [16 x 256] x [256 x 256]; the refills of the last round are the first k-steps of the next head (next simulation) ----
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+                const float* Ap = H1 + (h & 1) * kF16HFloats + fkq * 16 + fr;  // h16_off(4 ks + kq, r) = 68 ks + 16 kq + r
+#pragma unroll
+                for (int i = 0; i < kPsARing; ++i) av[i] = Ap[i * 68];
+#pragma unroll 1
+                for (int rd = 0; rd < 4; ++rd) {
+                    const bool same = rd < 3;
+                    // reads past k-step 63 land in the next tile and are never used
+                    qp_round<false, false>(acc, Bq, av, Ap + (rd * kPsDepth + kPsARing) * 68, 0u, same ? W2r[h] : W1r[h == 2 ? 0 : h + 1], fvoff,
+                                           same ? 4096 * kPsDepth * (rd + 1) : 0, a3, hpA, w3v[0]);
+                }
+                const floatx4 bb2 = *reinterpret_cast<const floatx4*>(&M.b12[h][1][fcol]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    floatx4 o;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const float v = acc[c][reg] + bb2[c];
+                        o[reg] = v > 0.0f ? v : 0.0f;
+                    }
+                    *reinterpret_cast<floatx4*>(H2 + h16_off(fcol + c, 4 * fkq)) = o;
+                }
+                if (h == 2) {
+                    // the last head's quarter chain has no layer 1 to hide under: 16 dependent MFMAs (k ascending = the oracle's fmaf chain)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    floatx4 z3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int qq = 0; qq < 16; ++qq) z3 = __builtin_amdgcn_mfma_f32_16x16x4f32(hpA[68 * qq], w3v[1][qq], z3, 0, 0, 0);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) part[(fw * 16 + 4 * fkq + reg) * kQpPartLd + 2 + fr] = z3[reg];
+                }
             }
+        } else {
+            // ================= waves 4-7: the same barriers; wave 4 looks the 16 observations' novelty up =================
+            EAZ_QP_ARGS;
+            if (wave == 4) qp_novelty(a.net, M, lane);
+            __syncthreads(); __syncthreads(); __syncthreads();  // H1 of head 0, 1, 2
         }
         EAZ_QPSTAMP(7);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __syncthreads();
+        __syncthreads();  // the quarter sums of the three heads
         if (s == 0) {
             // ---- root of real step `step`: selfplay.py:92-106,113 (root_prep_kernel) + mctx instantiate_tree_from_root (tree_root_kernel) ----
             EAZ_QP_ARGS;
-            const float* net_logits = a.heads.id[2] == 2 ? a.out.exploit : a.out.explore;
             const Key kt = fold(a.sp.key, kTagStep + static_cast<uint32_t>(step));
             const Key gkey = fold(kt, kTagGumbel);
+            const float z = tl < 18 ? head_out(ti, tl < 16 ? 2 + tl : tl - 16) : 0.0f;
+            if (tl == 16) M.o_value[ti] = det_tanh(z);                                // fully_connected.py:55
+            if (tl == 17) M.o_ube[ti] = (0.5f * (det_tanh(z) + 1.0f)) * a.net.max_u;  // :64, :93
+            ps_wave_sync();
             float lgv = -kInf;
             if (tl < 16) {
-                lgv = (a.sp.flags & kSpUniform) ? 1.0f : net_logits[static_cast<long>(gb) * kQpA + tl];  // :96-98
+                lgv = (a.sp.flags & kSpUniform) ? 1.0f : z;                            // :96-98
                 const long gi = static_cast<long>(gb) * kQpA + tl;
                 const float gn = a.sp.gumbel ? a.sp.gumbel[static_cast<long>(step) * B * kQpA + gi] : gumbel(gkey, static_cast<uint32_t>(gi));
                 M.gumbel[ti][tl] = a.sp.gumbel_scale * gn;
@@ -697,8 +855,8 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             const float m = gmax<16>(lgv);  // mask_invalid_actions (A.2): every action legal (subleq.py:626)
             if (tl < 16) M.root_logits[ti][tl] = lgv - m;
             if (tl == 0) {
-                const float root_v = a.out.value[gb];
-                const float root_u = ube_combine(a.out.ube[gb], M.o_nov[ti], t.max_u);  // fully_connected.py:92-96
+                const float root_v = M.o_value[ti];
+                const float root_u = ube_combine(M.o_ube[ti], M.o_nov[ti], t.max_u);  // fully_connected.py:92-96
                 T[QN_RAW_VALUE] = f2u(root_v); T[QN_NODE_VALUE] = f2u(root_v);
                 T[QN_RAW_VAR] = f2u(root_u); T[QN_NODE_VAR] = f2u(root_u);
                 T[QN_META] = 1u | (0xFFu << 8);

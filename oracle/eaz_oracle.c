@@ -1350,9 +1350,11 @@ static int o_categorical(OKey key, int b, const float* logits, int A) { /* jax.r
 
 /* selfplay(): T real steps from `states` (in/out).  Outputs are [T,B,...] like SelfplayOutput (selfplay.py:17-23).
  * gumbel_in (optional, [T,B,A], unscaled) overrides the generated root noise. */
-EXPORT void eazo_selfplay(const OEnv* env, const ONet* net, int B, const OSelfplayCfg* cfg, uint32_t k0, uint32_t k1,
-                          void* states, const float* gumbel_in, void* out_states, float* root_value,
-                          float* root_std, float* value_pred, float* ube_pred, float* qvar, int32_t* actions_out) {
+/* beta_in (optional, [B]): the per-environment beta of selfplay.py:105 given explicitly -- a SUBSET of a larger batch keeps the betas
+ * beta * linspace(0, 1, B_total)[b_global] of its environments (tests/test_gpu_fullsize.py); NULL: beta * linspace(0, 1, B). */
+EXPORT void eazo_selfplay_beta(const OEnv* env, const ONet* net, int B, const OSelfplayCfg* cfg, uint32_t k0, uint32_t k1,
+                               void* states, const float* gumbel_in, const float* beta_in, void* out_states, float* root_value,
+                               float* root_std, float* value_pred, float* ube_pred, float* qvar, int32_t* actions_out) {
     const int A = env->num_actions, D = env->obs_rows * env->obs_cols, SB = env->state_bytes, T = cfg->T;
     OTree* t = eazo_tree_create(env, net, B, cfg->S);
     uint8_t* obs = (uint8_t*)malloc((size_t)B * D);
@@ -1379,7 +1381,7 @@ EXPORT void eazo_selfplay(const OEnv* env, const ONet* net, int B, const OSelfpl
                 invalid[(size_t)b * A + a] = (uint8_t)!o_state_legal(env, (char*)states + (size_t)b * SB, a); /* :113 */
             }
             /* :105 beta * linspace(0, 1, B)[b]; linspace restated as b / (B-1) (endpoint exact) */
-            beta[b] = sbeta * (B > 1 ? (float)b / (float)(B - 1) : 0.0f);
+            beta[b] = beta_in ? (cfg->directed_exploration ? beta_in[b] : 0.0f) : sbeta * (B > 1 ? (float)b / (float)(B - 1) : 0.0f);
         }
         eazo_search_begin(t, logits, v, u, states, beta, invalid, g, cfg->discount, cfg->two_player,
                           cfg->directed_exploration, cfg->rescale, 1, 0.1f, 50.0f, cfg->max_considered, 0);
@@ -1406,6 +1408,12 @@ EXPORT void eazo_selfplay(const OEnv* env, const ONet* net, int B, const OSelfpl
     free(obs); free(ex); free(xp); free(v); free(u); free(beta); free(g); free(aw); free(logits); free(vp);
     free(invalid); free(act); free(nxt);
     eazo_tree_free(t);
+}
+
+EXPORT void eazo_selfplay(const OEnv* env, const ONet* net, int B, const OSelfplayCfg* cfg, uint32_t k0, uint32_t k1,
+                          void* states, const float* gumbel_in, void* out_states, float* root_value,
+                          float* root_std, float* value_pred, float* ube_pred, float* qvar, int32_t* actions_out) {
+    eazo_selfplay_beta(env, net, B, cfg, k0, k1, states, gumbel_in, NULL, out_states, root_value, root_std, value_pred, ube_pred, qvar, actions_out);
 }
 
 /* src/selfplay.py:152-170 (uniformrandomplay): init then T uniformly random auto-reset steps */

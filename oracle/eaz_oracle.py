@@ -87,6 +87,7 @@ def lib():
             "eazo_search_finish": (None, [vp, vp, vp]),
             "eazo_search_summary": (None, [vp, vp, vp, vp, vp, vp, vp]),
             "eazo_selfplay": (None, [vp, vp, i32, vp, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+            "eazo_selfplay_beta": (None, [vp, vp, i32, vp, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
             "eazo_random_play": (None, [vp, i32, i32, u32, u32, vp, vp]),
             "eazo_evaluate": (i32, [vp, vp, i32, i32, f32, i32, f32, i32, vp, vp]),
             "eazo_reanalyze": (None, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -328,8 +329,9 @@ def search(env, net, states, num_simulations, root_logits, root_value, root_var,
 
 def selfplay(env, net, states, T, S, key=(0, 0), gumbel=None, discount=0.997, two_player=False,
              directed_exploration=False, exploration_beta=0.0, uniform_search_policy=False, sample_actions=False,
-             sample_from_improved_policy=False, rescale=True, gumbel_scale=1.0, max_considered=16):
-    """src/selfplay.py:78-149 on the oracle.  `states` is updated in place (last_states)."""
+             sample_from_improved_policy=False, rescale=True, gumbel_scale=1.0, max_considered=16, beta_per_env=None):
+    """src/selfplay.py:78-149 on the oracle.  `states` is updated in place (last_states).
+    beta_per_env ([B] f32, optional): explicit per-environment betas (a subset of a larger batch keeps beta * linspace(0, 1, B_total)[b])."""
     B, A = states.shape[0], env.num_actions
     cfg = SelfplayCfg(T, S, discount, int(two_player), int(directed_exploration), exploration_beta,
                       int(uniform_search_policy), int(sample_actions), int(sample_from_improved_policy), int(rescale),
@@ -341,9 +343,11 @@ def selfplay(env, net, states, T, S, key=(0, 0), gumbel=None, discount=0.997, tw
         action=np.empty((T, B), np.int32),
     )
     g = None if gumbel is None else np.ascontiguousarray(gumbel, np.float32)
-    lib().eazo_selfplay(env.h, net.h, B, C.byref(cfg), key[0], key[1], _p(states), _p(g), _p(out["state"]),
-                        _p(out["root_value"]), _p(out["root_epistemic_std"]), _p(out["value_prediction"]),
-                        _p(out["ube_prediction"]), _p(out["q_values_epistemic_variance"]), _p(out["action"]))
+    bpe = None if beta_per_env is None else np.ascontiguousarray(beta_per_env, np.float32)
+    assert bpe is None or bpe.shape == (B,)
+    lib().eazo_selfplay_beta(env.h, net.h, B, C.byref(cfg), key[0], key[1], _p(states), _p(g), _p(bpe), _p(out["state"]),
+                             _p(out["root_value"]), _p(out["root_epistemic_std"]), _p(out["value_prediction"]),
+                             _p(out["ube_prediction"]), _p(out["q_values_epistemic_variance"]), _p(out["action"]))
     return out
 
 

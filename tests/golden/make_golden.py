@@ -30,10 +30,13 @@ CASES = {
     "c1_deepsea8": ("deepsea", 8, 64, 16, 8, 0, 0.0, {}),                      # BASELINE.json configs[0] shapes
     "c2r_deepsea32": ("deepsea", 32, 32, 64, 3, 1, 0.5, {}),                   # configs[1] reduced in batch/steps
     "c1b_deepsea8_beta": ("deepsea", 8, 48, 16, 6, 2, 0.5, dict(directed_exploration=True, exploration_beta=1.0)),
-    "c3r_subleq16": ("subleq", 16, 24, 32, 5, 3, 0.25, {}),                    # configs[2] reduced
-    "c3b_subleq16_beta": ("subleq", 16, 24, 32, 4, 4, 0.25, dict(directed_exploration=True, exploration_beta=1.0)),
-    # configs[3] reduced: connect_four, two-player discount, residual network with `size` blocks
-    "c4r_connect4": ("connect4", 1, 12, 16, 6, 5, 0.3, dict(two_player=True)),
+    # configs[2] reduced; T = 16 real steps: Subleq-16 episodes end at _step_count >= 13 (subleq.py:671-673), so every environment is searched
+    # from a terminated root and auto-reset (selfplay.py:26-75,135) inside the window
+    "c3r_subleq16": ("subleq", 16, 24, 32, 16, 3, 0.25, {}),
+    "c3b_subleq16_beta": ("subleq", 16, 24, 32, 16, 4, 0.25, dict(directed_exploration=True, exploration_beta=1.0)),
+    # configs[3] reduced: connect_four, two-player discount, residual network with `size` blocks; T = 26: 10 of the 12 games end (win or
+    # full column -> illegal move) and restart inside the window
+    "c4r_connect4": ("connect4", 1, 12, 16, 26, 5, 0.3, dict(two_player=True)),
 }
 
 

@@ -100,25 +100,36 @@ def test_c2_tree_invariants_on_every_tree(oracle, eaz, torch):
     assert (vc[np.arange(B), act.cpu().numpy()] == vc.max(1)).all()
 
 
-def test_c3_selfplay_subset_matches_oracle(oracle, eaz, torch):
+@pytest.mark.parametrize("flags", [{}, dict(directed_exploration=True, exploration_beta=1.0)], ids=["beta0", "beta1"])
+def test_c3_selfplay_subset_matches_oracle(oracle, eaz, torch, flags):
+    """T = 16 real steps: Subleq-16 episodes end at _step_count >= 13 (subleq.py:671-673), so the window holds searches from terminated roots
+    and the auto-reset inside selfplay for every environment; beta1 = the reference's experiment setting (directed exploration, beta = 1,
+    slurm_experiment_submitter.py:203,209) at full size."""
     from e_alphazero_amd import engine
 
-    W, B, S, T, NSUB = 16, 4096, 64, 4, 16
+    W, B, S, T, NSUB = 16, 4096, 64, 16, 16
     dims, params, state = subleq_setup(eaz, W, seed=0, fill=0.5)
     env = engine.EnvHandle.subleq(W, (1,), True, device=0)
     net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
     oenv = oracle.OracleEnv.subleq(W, (1,), True)
     onet = oracle.OracleNet(dims["in_dim"], 256, W, eaz.params.fc_weight_list(params), hash_off=dims["hash_off"],
                             hash_len=dims["hash_len"], bitset=state[eaz.params.HASH_MODULE]["binary_set"])
-    search = engine.Search(env, net, B, S, discount=0.97)
+    search = engine.Search(env, net, B, S, discount=0.97, exploration=bool(flags))
     gum = oracle.gumbel((3, 4), T * B * W).reshape(T, B, W)
     st = env.init(B, key=0)
-    out = search.selfplay(st, T, key=23, gumbel=torch.from_numpy(gum).cuda())
+    out = search.selfplay(st, T, key=23, gumbel=torch.from_numpy(gum).cuda(), **flags)
     idx = np.sort(np.random.default_rng(2).choice(B, NSUB, replace=False))
+    if flags:
+        idx[-1] = B - 1  # beta * linspace(0, 1, B)[b] is per environment (selfplay.py:105): the oracle gets the subset's own betas below
     ost = oenv.init(NSUB)  # one task: init does not depend on the key
-    ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(23, 0), gumbel=np.ascontiguousarray(gum[:, idx]), discount=0.97)
+    okw = dict(flags)
+    if flags:
+        okw["beta_per_env"] = (flags["exploration_beta"] * np.linspace(0, 1, B)[idx]).astype(np.float32)
+    ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(23, 0), gumbel=np.ascontiguousarray(gum[:, idx]), discount=0.97, **okw)
     _check_subset(out, ref, idx, state_cmp=lambda s: subleq_device_to_oracle(s, W))
     assert np.array_equal(subleq_device_to_oracle(st[idx].cpu().numpy(), W), ost)
+    sc = ref["state"].view(np.uint8)[..., 0:4].copy().view(np.int32)[..., 0]
+    assert (np.diff(sc.astype(np.int64), axis=0) < 0).all(axis=0).any() or (np.diff(sc.astype(np.int64), axis=0) < 0).any(), "no episode ended inside the window"
 
 
 def test_c4_selfplay_subset_matches_oracle(oracle, eaz, torch):

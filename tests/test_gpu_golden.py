@@ -167,12 +167,14 @@ def test_wide_action_sets_selfplay_matches_oracle(oracle, eaz, torch, W, B, S):
 
 @pytest.mark.parametrize("flags", [{}, dict(directed_exploration=True, exploration_beta=1.0), dict(sample_actions=True),
                                    dict(sample_from_improved_policy=True, uniform_search_policy=True)])
-def test_subleq16_selfplay_crosses_episode_boundaries(oracle, eaz, torch, flags):
+def test_subleq16_selfplay_crosses_episode_boundaries(oracle, eaz, torch, flags, kernel_variant):
     """Subleq-16 self-play over more real steps than an episode has (episodes end at _step_count >= 13, subleq.py:671-673): searches from
     terminated roots, the auto-reset inside selfplay (selfplay.py:26-75,135) with a task drawn per reset (subleq.py:624), a ragged batch
     (40 = 2.5 workgroups of the one-launch kernel), every action-choice flag.  Generated Gumbel noise (the engine's key derivation)."""
     from e_alphazero_amd import engine
 
+    if kernel_variant in ("tile16-unfused", "tile64-sharded") and flags:
+        pytest.skip("the per-simulation variants run this window once (default flags); the golden c3r / c3b cases cover them at T = 16 as well")
     W, B, S, T = 16, 40, 24, 17
     tasks = (1, 2, 3)
     dims, params, state = subleq_setup(eaz, W, seed=11, fill=0.4)

@@ -1,0 +1,120 @@
+"""Build-time guard of the hand-tuned kernels: cross-compiles csrc/eaz_api.hip to gfx950 assembly (no GPU needed) and checks what the
+one-launch kernels silently depend on -- no scratch, register budgets of the occupancy each kernel is designed for, the MFMA / buffer-load
+streams present, the work-queue claim a single LDS atomic without the atomic optimizer's scan loop around it, the kernarg struct at
+offset 0 (the kernels read their arguments through the laundered kernarg segment pointer), and the barrier count of fc16p_body that the
+idle head group of subleq16_search_kernel mirrors (kFpBarriers).  A regression here used to show up only as a GPU timeout.
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "e-alphazero_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = tmp_path_factory.mktemp("isa") / "eaz.s"
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-S", "--cuda-device-only"]  # csrc/Makefile CXXFLAGS
+    subprocess.run([HIPCC, *flags, "-o", str(out), "eaz_api.hip"], cwd=CSRC, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+def kernel(asm, stem):
+    """-> (body text, metadata dict) of the kernel whose mangled name contains `stem`"""
+    m = re.search(r"^(_ZN3eaz\d+%s\w*):" % stem, asm, re.M)
+    assert m, f"kernel {stem} not found in the assembly"
+    name = m.group(1)
+    end = asm.index(f".amdhsa_kernel {name}")
+    body = asm[asm.index("\n", m.end()):end]
+    i = asm.index(f".name:           {name}")
+    j = asm.rfind("- .agpr_count", 0, i)
+    k = asm.find("- .agpr_count", i)
+    meta_txt = asm[j:k if k > 0 else len(asm)]
+    meta = {key: int(v) for key, v in re.findall(r"\.(\w+):\s+(\d+)\s*$", meta_txt, re.M)}
+    args = re.findall(r"- \.offset:\s+(\d+)\s+\.size:\s+(\d+)\s+\.value_kind:\s+(\w+)", meta_txt)
+    meta["explicit_args"] = [(int(o), int(sz), kind) for o, sz, kind in args if not kind.startswith("hidden")]
+    return body, meta
+
+
+def count(body, mnemonic):
+    return len(re.findall(r"^\s+%s\b" % re.escape(mnemonic), body, re.M))
+
+
+# kernel stem -> VGPR budget of the occupancy it is designed for (MI355X_MICROARCH.md register table: 512 / waves per SIMD, granule 8)
+BUDGET = {
+    "search_persist_kernel": 256,      # 320 threads: five waves on four SIMDs, one SIMD carries two
+    "subleq16_search_kernel": 256,     # 512 threads: two waves per SIMD
+    "subleq16_selfplay_kernel": 256,   # 512 threads: two waves per SIMD
+    "fc16p_forward_kernel": 168,       # three 256-thread workgroups per CU: three waves per SIMD
+    "resnet_forward_kernel": 256,      # two 256-thread workgroups per CU
+}
+
+
+@pytest.mark.parametrize("stem", sorted(BUDGET))
+def test_no_scratch_and_register_budget(asm, stem):
+    body, meta = kernel(asm, stem)
+    assert meta["private_segment_fixed_size"] == 0, f"{stem} uses scratch memory ({meta['private_segment_fixed_size']} bytes per lane)"
+    assert meta["vgpr_spill_count"] == 0, f"{stem} spills {meta['vgpr_spill_count']} VGPRs"
+    assert count(body, "scratch_load_dword") + count(body, "scratch_store_dword") == 0
+    assert meta["vgpr_count"] + meta.get("agpr_count", 0) <= BUDGET[stem], f"{stem}: {meta['vgpr_count']} VGPRs exceed the {BUDGET[stem]} of its occupancy"
+    assert count(body, "v_mfma_f32_16x16x4_f32") > 0, f"{stem} has lost its f32 MFMA stream"
+
+
+@pytest.mark.parametrize("stem", ["search_persist_kernel", "subleq16_search_kernel", "subleq16_selfplay_kernel", "fc16p_forward_kernel"])
+def test_weight_stream_is_buffer_loads(asm, stem):
+    body, _ = kernel(asm, stem)
+    assert count(body, "buffer_load_dwordx4") >= 16, "the weight stream (16 k-steps of 16-byte buffer loads in flight) is gone"
+
+
+@pytest.mark.parametrize("stem", ["subleq16_search_kernel", "subleq16_selfplay_kernel"])
+def test_work_queue_claim_is_one_lds_atomic(asm, stem):
+    """`atomicAdd` went through the compiler's atomic optimizer, which once turned the claim into a loop that never ended;
+    the kernels issue ds_add_rtn_u32 themselves.  One claim site, no lane-scan loop in front of it."""
+    body, _ = kernel(asm, stem)
+    lines = body.splitlines()
+    sites = [i for i, ln in enumerate(lines) if re.match(r"\s+ds_add_rtn_u32\b", ln)]
+    assert len(sites) == 1, f"{stem}: {len(sites)} ds_add_rtn_u32 instructions, expected exactly the work-queue claim"
+    window = "\n".join(lines[max(0, sites[0] - 40):sites[0] + 8])
+    assert "s_ff1_i32_b64" not in window and "v_readlane_b32" not in window.split("ds_add_rtn_u32")[1], \
+        "a lane-scan (atomic optimizer) loop surrounds the work-queue claim"
+
+
+@pytest.mark.parametrize("stem,size_of", [("subleq16_search_kernel", None), ("subleq16_selfplay_kernel", None)])
+def test_argument_struct_sits_at_kernarg_offset_zero(asm, stem, size_of):
+    """sq_args() / qp_args() reinterpret the kernarg segment pointer as the argument struct: the struct must be the only explicit parameter."""
+    _, meta = kernel(asm, stem)
+    assert len(meta["explicit_args"]) == 1, meta["explicit_args"]
+    off, size, kind = meta["explicit_args"][0]
+    assert off == 0 and kind == "by_value" and size > 256
+
+
+def test_fc16p_body_barrier_count_matches_kfpbarriers(asm):
+    """search_subleq.hpp's idle head group issues kFpBarriers barriers while the other runs fc16p_body: the two must agree or the workgroup
+    deadlocks.  fc16p_forward_kernel is fc16p_body and nothing else."""
+    src = open(os.path.join(CSRC, "net_fc_pipe.hpp")).read()
+    k = int(re.search(r"constexpr int kFpBarriers = (\d+);", src).group(1))
+    body, _ = kernel(asm, "fc16p_forward_kernel")
+    assert count(body, "s_barrier") == k
+    for f in ("search_subleq.hpp",):
+        txt = open(os.path.join(CSRC, f)).read()
+        assert "__syncthreads(); __syncthreads(); __syncthreads();" not in txt, f"{f} hard-codes a barrier count: use kFpBarriers"
+        assert "k < kFpBarriers" in txt
+
+
+def test_selfplay_kernel_roles_issue_the_same_number_of_barriers():
+    """subleq16_selfplay_kernel: inside the forward phase waves 0-3 (MFMA) and 4-7 (helpers) run different code between the same barriers:
+    one per head (H1 tile) in both branches, counted in the source (a mismatch is a deadlock on the GPU)."""
+    txt = open(os.path.join(CSRC, "search_subleq_persist.hpp")).read()
+    f0 = txt.index("// ================= waves 0-3")
+    f1 = txt.index("// ================= waves 4-7")
+    f2 = txt.index("EAZ_QPSTAMP(7);")
+    mfma, helper = txt[f0:f1], txt[f1:f2]
+    # the MFMA branch's barrier sits inside `for (int h = 0; h < 3; ++h)`
+    assert mfma.count("__syncthreads();") == 1 and "for (int h = 0; h < 3; ++h)" in mfma
+    assert helper.count("__syncthreads();") == 3
