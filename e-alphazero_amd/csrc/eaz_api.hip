@@ -1768,6 +1768,11 @@ extern "C" __attribute__((visibility("default"))) int eaz_diag_persist_stamps(ea
     HIP_OK(hipMemcpy(h_out, s->d_stamps, sizeof(unsigned long long) * 256 * 32, hipMemcpyDeviceToHost));
     return 0;
 }
+extern "C" __attribute__((visibility("default"))) int eaz_diag_qp_dhist(unsigned long long* h_out /* [72] */) {
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_qp_dhist), sizeof(unsigned long long) * 72));
+    return 0;
+}
 extern "C" __attribute__((visibility("default"))) int eaz_diag_sq_stamps(unsigned long long* h_out /* [16] */) {
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_sq_stamps), sizeof(unsigned long long) * 16));

@@ -37,6 +37,10 @@ namespace eaz {
 constexpr int kQpTrees = 16;
 constexpr int kQpThreads = 512;
 constexpr int kQpA = 16;
+#ifndef EAZ_QP_EWAVES
+#define EAZ_QP_EWAVES 8
+#endif
+constexpr int kQpEWaves = EAZ_QP_EWAVES;  // wavefronts that run the interpreters: the last kQpEWaves of the 8
 
 // node record in LDS (32-bit words)
 enum : int {
@@ -69,7 +73,8 @@ struct QpMisc {
     float o_value[kQpTrees], o_ube[kQpTrees];
     float b3[20];                       // output biases: value, ube, the 16 policy logits
     float b12[3][2][kFcH];              // hidden-layer biases of the three heads (layer 1, layer 2)
-    unsigned long long xbits[kQpTrees][4];  // observation bits of the 16 rows: [row][kq] bit ks = input 4 ks + kq (the MFMA A operands of layer 1)
+    unsigned long long xbits[kQpTrees][4];  // the 16 observations as bits: [row][p] bit i = input 64 p + i (subleq.py:88-98); the A operand of lane
+                                            // (row, kq) at k-step 16 p + i is bit 4 i + kq of word p
     uint8_t words[kQpTrees][48];        // row-words of the 16 observations in flight, 5 observation bits each (subleq.py:88-98)
 };
 constexpr int kQpPartLd = 20;  // quarter sums [4 waves][16 rows][kQpPartLd]: slot 0 value, 1 ube, 2..17 policy logits
@@ -116,6 +121,7 @@ struct Sq16SelfplayArgs {
         }                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                             \
     } while (0)
+__device__ unsigned long long g_qp_dhist[72];  // diagnostic build: histogram of the select depth D over all trees and simulations (+ [64..71]: by simulation octile, sum of D)
 #else
 #define EAZ_QPSTAMP(i)
 #endif
@@ -149,39 +155,37 @@ __device__ __forceinline__ uint32_t qp_hdr(int step, int task, int term, int tru
 // observation code of a row-word: bits 0..3 = v mod 16, bit 4 = (v == 16)  (subleq.py:88-98)
 __device__ __forceinline__ uint8_t qp_code(uint32_t v) { return static_cast<uint8_t>((v & 15u) | (v == 16u ? 16u : 0u)); }
 
-// The 48 row-words of a state (memory | example_input | input_after | example_output | output_after, subleq.py:679-707): lane w < 48 stores
-// the code of row-word w.
-__device__ __forceinline__ void qp_emit_words(uint8_t* words, unsigned long long mem, unsigned long long exin, unsigned long long inaf,
-                                              unsigned long long exout, unsigned long long outaf, int lane) {
+// The observation of a state, twice: the 48 row-words (memory | example_input | input_after | example_output | output_after,
+// subleq.py:679-707) as 5-bit codes for the novelty hash, and the 240 observation bits themselves (bit 5 w + j = bit j of row-word w's
+// code, subleq.py:88-98; inputs 240..255 zero) as four 64-bit words for layer 1.  Lane w < 48 computes the code of row-word w; bit k of
+// the observation is fetched from the lane that holds its word (ds_bpermute) and the 64 lanes' bits become a word by one ballot.
+__device__ __forceinline__ void qp_emit_obs(uint8_t* words, unsigned long long* xb, unsigned long long mem, unsigned long long exin, unsigned long long inaf,
+                                            unsigned long long exout, unsigned long long outaf, int lane) {
+    uint32_t code = 0u;
     if (lane < 16) {
-        words[lane] = static_cast<uint8_t>((mem >> (4 * lane)) & 15ull);
+        code = static_cast<uint32_t>(mem >> (4 * lane)) & 15u;
     } else if (lane < 48) {
         const int row = (lane - 16) >> 3, sh = 8 * (lane & 7);
         const unsigned long long src = row == 0 ? exin : (row == 1 ? inaf : (row == 2 ? exout : outaf));
-        words[lane] = qp_code(static_cast<uint32_t>(src >> sh) & 0xFFu);
+        code = qp_code(static_cast<uint32_t>(src >> sh) & 0xFFu);
     }
-}
-
-// The same observation as the A operands of layer 1: xb[kq] bit ks = observation input 4 ks + kq = bit (4 ks + kq) % 5 of row-word
-// (4 ks + kq) / 5 (subleq.py:88-98; inputs 240..255 are zero).  One ballot per mask; `words` was written by this wavefront.
-__device__ __forceinline__ void qp_emit_bits(unsigned long long* xb, const uint8_t* words, int lane) {
-    ps_wave_sync();
+    if (lane < 48) words[lane] = static_cast<uint8_t>(code);
 #pragma unroll
-    for (int kq = 0; kq < 4; ++kq) {
-        const int k = 4 * lane + kq;
-        const int w = k / 5, j = k - 5 * w;
-        const bool bit = k < 240 && ((words[k < 240 ? w : 0] >> j) & 1u) != 0;
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(bit);
-        if (lane == 0) xb[kq] = m;
+    for (int p = 0; p < 4; ++p) {
+        const int k = 64 * p + lane;
+        const int w = (k * 52429) >> 18, j = k - 5 * w;  // k / 5 for k < 2^14
+        const uint32_t c = static_cast<uint32_t>(__shfl(static_cast<int>(code), w < 48 ? w : 0));
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(w < 48 && ((c >> j) & 1u) != 0);
+        if (lane == 0) xb[p] = m;
     }
 }
 
 // One round of the forward's weight stream (search_persist.hpp ps_round): 16 k-steps of four MFMAs each on the prefetched weights Bq,
-// every k-step followed by the refill of its registers.  ABITS: layer 1, A operand = bit i of `abits` as a float; otherwise layer 2,
+// every k-step followed by the refill of its registers.  ABITS: layer 1, A operand = a bit of `abits` as a float; otherwise layer 2,
 // A operands from the H1 tile kPsARing k-steps ahead.  CHAIN: the round also carries the 16 dependent MFMAs of the previous head's
 // layer-3 quarter chain (A from the H2 columns this wave wrote, B = `w3` in registers).
 template <bool CHAIN, bool ABITS>
-__device__ __forceinline__ void qp_round(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDepth], float (&av)[kPsARing], const float* apn, const uint32_t abits,
+__device__ __forceinline__ void qp_round(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDepth], float (&av)[kPsARing], const float* apn, const unsigned long long abits,
                                          __amdgpu_buffer_rsrc_t rs, int voff, int sbase, floatx4& a3, const float* hpA, const float (&w3)[16]) {
     static_assert(kPsDepth == 16, "a round is 16 k-steps");
     float cha[kChRing];
@@ -191,7 +195,8 @@ __device__ __forceinline__ void qp_round(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDep
     }
 #pragma unroll
     for (int i = 0; i < kPsDepth; ++i) {
-        const float aop = ABITS ? static_cast<float>((abits >> i) & 1u) : av[i % kPsARing];
+        // layer 1: `abits` = the round's observation word >> kq, the A operand of k-step i is its bit 4 i
+        const float aop = ABITS ? static_cast<float>(((i < 8 ? static_cast<uint32_t>(abits) : static_cast<uint32_t>(abits >> 32)) >> (4 * (i & 7))) & 1u) : av[i % kPsARing];
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, Bq[i][c], acc[c], 0, 0, 0);
         if constexpr (CHAIN) {
@@ -210,6 +215,8 @@ __device__ __forceinline__ void qp_round(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDep
 __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src, uint32_t* dst, const uint32_t* root_ex, uint8_t* words,
                                             unsigned long long* xb, const int action, const int mode, const Key envkey, const int b, const int lane, char* blob0,
                                             char* blob1, float& reward_out, int& term_out) {
+    EAZ_WSTAMP_DECL;
+    EAZ_WSTAMP(0);
     uint32_t s[QS_WORDS];
 #pragma unroll
     for (int i = 0; i < QS_WORDS; ++i) s[i] = __builtin_amdgcn_readfirstlane(src[i]);
@@ -238,16 +245,22 @@ __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src
         else run = true;
     }
     const int branch = task - 1 < 0 ? 0 : (task - 1 > 5 ? 5 : task - 1);  // get_test_cases: lax.switch clamps the branch index
-    const unsigned long long t_in = kSq16Cases.v[branch][0][0], t_out = kSq16Cases.v[branch][0][1];
+    // the packed test vectors of the three cases, requested together (one scalar-cache round trip instead of one per case)
+    unsigned long long tv[3][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { tv[c][0] = kSq16Cases.v[branch][c][0]; tv[c][1] = kSq16Cases.v[branch][c][1]; }
+    const unsigned long long t_in = tv[0][0], t_out = tv[0][1];
     unsigned long long exin = exroot ? qp_u64(root_ex[0], root_ex[1]) : t_in, exout = exroot ? qp_u64(root_ex[2], root_ex[3]) : t_out;
     bool all_correct = false;
     int bytes_used = 0;
+    EAZ_WSTAMP(1);
     if (run) {
         const int idx = step_count - 1;  // the action is word step_count - 1 (subleq.py:654)
         if (!do_init && idx >= 0 && idx < 16) mem = (mem & ~(15ull << (4 * idx))) | (static_cast<unsigned long long>(action & 15) << (4 * idx));
         all_correct = true;
+#pragma unroll 1
         for (int c = 0; c < 3 && all_correct; ++c) {  // subleq.py:511 vmap; `solved` is the AND (:525), only case 0 feeds the state
-            const unsigned long long sin = kSq16Cases.v[branch][c][0], stout = kSq16Cases.v[branch][c][1];
+            const unsigned long long sin = c == 0 ? tv[0][0] : (c == 1 ? tv[1][0] : tv[2][0]), stout = c == 0 ? tv[0][1] : (c == 1 ? tv[1][1] : tv[2][1]);
             unsigned long long s_after, s_out;
             int bytes_c;
             const bool correct = subleq16_wave_run(mem, sin, stout, s_after, s_out, bytes_c);
@@ -257,6 +270,7 @@ __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src
         }
         exin = t_in; exout = t_out; exroot = 0;
     }
+    EAZ_WSTAMP(2);
     float reward;
     int terminated, solved;
     if (run) {
@@ -275,8 +289,10 @@ __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src
         d4[1] = make_uint4(static_cast<uint32_t>(outaf), static_cast<uint32_t>(outaf >> 32), qp_hdr(step_count, task, terminated, truncated, solved, exroot),
                            __builtin_bit_cast(uint32_t, reward));
     }
-    qp_emit_words(words, mem, exin, inaf, exout, outaf, lane);
-    qp_emit_bits(xb, words, lane);
+    EAZ_WSTAMP(3);
+    qp_emit_obs(words, xb, mem, exin, inaf, exout, outaf, lane);
+    EAZ_WSTAMP(4);
+    EAZ_WSTAMP(5);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         char* blob = k == 0 ? blob0 : blob1;
@@ -306,6 +322,7 @@ __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src
     }
     reward_out = reward;
     term_out = terminated;
+    EAZ_WSTAMP(6);
 }
 
 // novelty of the 16 observations whose row-words are in M.words (XXHash variant, hashes.py:162-229: lane = (environment, stripe), stripe i =
@@ -445,8 +462,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             M.root_ex[j][0] = static_cast<uint32_t>(exin); M.root_ex[j][1] = static_cast<uint32_t>(exin >> 32);
             M.root_ex[j][2] = static_cast<uint32_t>(exout); M.root_ex[j][3] = static_cast<uint32_t>(exout >> 32);
         }
-        qp_emit_words(M.words[j], mem, exin, inaf, exout, outaf, lane);
-        qp_emit_bits(M.xbits[j], M.words[j], lane);
+        qp_emit_obs(M.words[j], M.xbits[j], mem, exin, inaf, exout, outaf, lane);
     }
     __syncthreads();
 
@@ -694,6 +710,9 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                     node = nx;
                 }
                 M.parent[ti] = node; M.action[ti] = act; M.dst[ti] = nx == 0xFF ? s : nx; M.D[ti] = depth;  // simulation s - 1 expands node s
+#ifdef EAZ_FC_STAMPS
+                if (step == 0 && blockIdx.x < 64) { atomicAdd(&g_qp_dhist[depth < 63 ? depth : 63], 1ull); atomicAdd(&g_qp_dhist[64 + ((s - 1) * 8) / S], static_cast<unsigned long long>(depth)); }
+#endif
             }
             EAZ_QPSTAMP(3);
         }
@@ -704,7 +723,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             EAZ_QPSTAMP(4);
             {
                 EAZ_QP_ARGS;
-                int j = wave;
+                int j = wave >= 8 - kQpEWaves ? wave - (8 - kQpEWaves) : kQpTrees;
                 const uint32_t env_next_off = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) int*)(&M.env_next)));
 #pragma unroll 1
                 while (j < kQpTrees) {
@@ -730,7 +749,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                     }
                     int got;
                     asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(env_next_off), "v"(1) : "memory");
-                    j = 8 + (__builtin_amdgcn_readfirstlane(got) >> 6);
+                    j = kQpEWaves + (__builtin_amdgcn_readfirstlane(got) >> 6);
                 }
             }
             EAZ_QPSTAMP(5);
@@ -756,7 +775,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 W1r[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.net.w[a.heads.id[h] * 3]), 0, fp_kpad(240) * kFcH * 4, 0x00020000);
                 W2r[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.net.w[a.heads.id[h] * 3 + 1]), 0, kFcH * kFcH * 4, 0x00020000);
             }
-            const unsigned long long xb = M.xbits[fr][fkq];  // this lane's layer-1 A operands: bit ks = observation input 4 ks + kq of row r
+            const unsigned long long* xrow = M.xbits[fr];  // this lane's layer-1 A operands: bit 4 i + kq of word p = input 64 p + 4 i + kq of row r
             const float* hpA = H2 + h16_off(fn0 + fkq, fr);  // quarter chain: H2[h16_off(n0 + 4 q + kq, r)] = hpA[68 q]
             float av[kPsARing];
 #pragma unroll
@@ -767,8 +786,8 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 floatx4 a3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
                 // ---- layer 1: [16 x 256] x [256 x 256], inputs 240..255 zero on both sides (exact); the first round carries the quarter chain
                 // of the head before ----
-                if (h > 0) qp_round<true, true>(acc, Bq, av, nullptr, static_cast<uint32_t>(xb) & 0xFFFFu, W1r[h], fvoff, 4096 * kPsDepth, a3, hpA, w3v[0]);
-                else qp_round<false, true>(acc, Bq, av, nullptr, static_cast<uint32_t>(xb) & 0xFFFFu, W1r[h], fvoff, 4096 * kPsDepth, a3, hpA, w3v[0]);
+                if (h > 0) qp_round<true, true>(acc, Bq, av, nullptr, xrow[0] >> fkq, W1r[h], fvoff, 4096 * kPsDepth, a3, hpA, w3v[0]);
+                else qp_round<false, true>(acc, Bq, av, nullptr, xrow[0] >> fkq, W1r[h], fvoff, 4096 * kPsDepth, a3, hpA, w3v[0]);
                 if (h > 0 && fr == h - 1) {  // head 0 = value: output column 0, head 1 = ube: column 1 (shared W3 registers)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) part[(fw * 16 + 4 * fkq + reg) * kQpPartLd + fr] = a3[reg];
@@ -776,7 +795,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
 #pragma unroll 1
                 for (int rd = 1; rd < 4; ++rd) {
                     const bool same = rd < 3;  // the refills of the last round are the first k-steps of layer 2
-                    qp_round<false, true>(acc, Bq, av, nullptr, static_cast<uint32_t>(xb >> (16 * rd)) & 0xFFFFu, same ? W1r[h] : W2r[h], fvoff,
+                    qp_round<false, true>(acc, Bq, av, nullptr, xrow[rd] >> fkq, same ? W1r[h] : W2r[h], fvoff,
                                           same ? 4096 * kPsDepth * (rd + 1) : 0, a3, hpA, w3v[0]);
                 }
                 {

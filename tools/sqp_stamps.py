@@ -68,3 +68,23 @@ t0 = st[:, :, 0].min(axis=1)
 seg("T (first wave in -> last wave at the T/E barrier)", st[:, :, 4].max(axis=1) - t0)
 seg("E (barrier to barrier)", st[:, :, 6].max(axis=1) - st[:, :, 4].max(axis=1))
 seg("one simulation (T start -> F end, wave 0)", st[:, 0, 7] - st[:, 0, 0])
+
+lib.eaz_diag_sq_stamps.argtypes = [C.c_void_p]
+q = np.zeros(16, np.uint64)
+lib.eaz_diag_sq_stamps(q.ctypes.data)
+q = q.astype(np.int64)
+n = max(int(q[15]), 1)
+print(f"inside qp_env_step, mean over the {n} calls of workgroup 0's first wave (all launches of this process):")
+for name, i in (("compact state from LDS, decision", 0), ("test cases + interpreter", 1), ("reward / flags", 2), ("new state + row-words to LDS", 3),
+                ("observation bit masks (4 ballots)", 4), ("state blob (real steps only)", 5)):
+    print(f"   {name:40s} {q[i] / n:8.0f} cycles")
+print(f"   interpreter runs per call {q[9] / n:.2f}, executed cycles per run {q[8] / max(int(q[9]), 1):.1f} (longest run seen: {q[10]})")
+
+lib.eaz_diag_qp_dhist.argtypes = [C.c_void_p]
+dh = np.zeros(72, np.uint64)
+lib.eaz_diag_qp_dhist(dh.ctypes.data)
+dh = dh.astype(np.int64)
+tot = max(int(dh[:64].sum()), 1)
+print("select depth D over the first real steps of 64 workgroups (share of tree-simulations): " +
+      "  ".join(f"D={d}: {100 * dh[d] / tot:.1f}%" for d in range(1, 16) if dh[d]))
+print("mean D by eighth of the search: " + "  ".join(f"{8 * dh[64 + i] / tot:.2f}" for i in range(8)))
