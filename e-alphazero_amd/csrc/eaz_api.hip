@@ -989,8 +989,8 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
             }
         }
 #ifdef EAZ_FC_STAMPS
-        DALLOC(s->d_stamps, 2 * 256 * 32);  // [256][32] phase stamps + [256][8 waves][4] interpreter-phase stamps (search_subleq.hpp)
-        HIP_OK(hipMemset(s->d_stamps, 0, 2 * 256 * 32 * sizeof(unsigned long long)));
+        DALLOC(s->d_stamps, 4 * 256 * 32);  // search_subleq.hpp: [256][32] phase stamps + [256][8 waves][4]; search_subleq_persist.hpp: [256][8 waves][16]
+        HIP_OK(hipMemset(s->d_stamps, 0, 4 * 256 * 32 * sizeof(unsigned long long)));
 #endif
     }
     *out = s;
@@ -1766,6 +1766,11 @@ extern "C" __attribute__((visibility("default"))) int eaz_diag_persist_stamps2(e
 extern "C" __attribute__((visibility("default"))) int eaz_diag_persist_stamps(eaz_search* s, unsigned long long* h_out /* [256*32] */) {
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpy(h_out, s->d_stamps, sizeof(unsigned long long) * 256 * 32, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int eaz_diag_qp_stamps(eaz_search* s, unsigned long long* h_out /* [256*8*16] */) {
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(h_out, s->d_stamps, sizeof(unsigned long long) * 256 * 8 * 16, hipMemcpyDeviceToHost));
     return 0;
 }
 extern "C" __attribute__((visibility("default"))) int eaz_diag_qp_dhist(unsigned long long* h_out /* [72] */) {

@@ -24,7 +24,7 @@
 //      observation never becomes a tile: a Subleq observation is 240 bits, the interpreter's wave leaves them as four 64-bit masks per
 //      row (mask kq, bit ks = input 4 ks + kq: exactly the A operands lane (row, kq) feeds to k-step ks), and layer 1's A operand is
 //      `(float)((mask >> ks) & 1)` -- no LDS traffic in layer 1 at all.  Layer 3 = quarter chains whose operands W3 stay in registers
-//      for the whole launch; a head's chain rides in the first round of the next head (ps_round).  The heads' outputs are never
+//      for the whole launch; a head's chain rides in a round of the next head (ps_round).  The heads' outputs are never
 //      materialised: expand / root preparation read the four quarter sums and apply ((c0 + c1) + (c2 + c3)) + b themselves.
 // Same float operations in the same order as tree_step_kernel<16,1> / fc16p_forward_kernel (the 16-slot butterfly sum is
 // lsum<4> + two quad exchanges), so results are bit-identical to the per-simulation path and to the oracle (tests/conftest.py variants).
@@ -37,10 +37,6 @@ namespace eaz {
 constexpr int kQpTrees = 16;
 constexpr int kQpThreads = 512;
 constexpr int kQpA = 16;
-#ifndef EAZ_QP_EWAVES
-#define EAZ_QP_EWAVES 8
-#endif
-constexpr int kQpEWaves = EAZ_QP_EWAVES;  // wavefronts that run the interpreters: the last kQpEWaves of the 8
 
 // node record in LDS (32-bit words)
 enum : int {
@@ -110,20 +106,33 @@ struct Sq16SelfplayArgs {
 };
 
 #ifdef EAZ_FC_STAMPS
-// diagnostic build: shader-clock stamps of simulation S / 2 of the first real step, lane 0 of every wave: [256 workgroups][8 waves][8]
+// diagnostic build: shader-clock stamps of simulation S / 2 of the first real step, lane 0 of every wave: [256 workgroups][8 waves][16]
+// (slots 8..15: inside the first interpreter step of the wave, EAZ_QESTAMP)
 #define EAZ_QPSTAMP(i)                                                                                 \
     do {                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                             \
         if (step == 0 && s == 1 + S / 2 && (tid & 63) == 0 && blockIdx.x < 256 && qp_args()->stamps) { \
             unsigned long long t_;                                                                     \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
-            qp_args()->stamps[(blockIdx.x * 8 + (tid >> 6)) * 8 + (i)] = t_;                           \
+            qp_args()->stamps[(blockIdx.x * 8 + (tid >> 6)) * 16 + (i)] = t_;                          \
+        }                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    } while (0)
+// raw stamp `i` of the wave's FIRST interpreter step of the stamped simulation (sp = the wave's stamp row or null)
+#define EAZ_QESTAMP(sp, i)                                                                             \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        if ((sp) != nullptr && lane == 0) {                                                            \
+            unsigned long long t_;                                                                     \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+            (sp)[(i)] = t_;                                                                            \
         }                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                             \
     } while (0)
 __device__ unsigned long long g_qp_dhist[72];  // diagnostic build: histogram of the select depth D over all trees and simulations (+ [64..71]: by simulation octile, sum of D)
 #else
 #define EAZ_QPSTAMP(i)
+#define EAZ_QESTAMP(sp, i)
 #endif
 
 __device__ __forceinline__ unsigned long long qp_u64(uint32_t lo, uint32_t hi) { return static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32); }
@@ -214,9 +223,8 @@ __device__ __forceinline__ void qp_round(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDep
 // blob: also the 336-byte state of include/eaz.h (real steps); words: the observation's row-words.  Returns the reward / terminated flag.
 __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src, uint32_t* dst, const uint32_t* root_ex, uint8_t* words,
                                             unsigned long long* xb, const int action, const int mode, const Key envkey, const int b, const int lane, char* blob0,
-                                            char* blob1, float& reward_out, int& term_out) {
-    EAZ_WSTAMP_DECL;
-    EAZ_WSTAMP(0);
+                                            char* blob1, float& reward_out, int& term_out, unsigned long long* dstamp = nullptr) {
+    EAZ_QESTAMP(dstamp, 8);
     uint32_t s[QS_WORDS];
 #pragma unroll
     for (int i = 0; i < QS_WORDS; ++i) s[i] = __builtin_amdgcn_readfirstlane(src[i]);
@@ -253,7 +261,7 @@ __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src
     unsigned long long exin = exroot ? qp_u64(root_ex[0], root_ex[1]) : t_in, exout = exroot ? qp_u64(root_ex[2], root_ex[3]) : t_out;
     bool all_correct = false;
     int bytes_used = 0;
-    EAZ_WSTAMP(1);
+    EAZ_QESTAMP(dstamp, 9);
     if (run) {
         const int idx = step_count - 1;  // the action is word step_count - 1 (subleq.py:654)
         if (!do_init && idx >= 0 && idx < 16) mem = (mem & ~(15ull << (4 * idx))) | (static_cast<unsigned long long>(action & 15) << (4 * idx));
@@ -270,7 +278,7 @@ __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src
         }
         exin = t_in; exout = t_out; exroot = 0;
     }
-    EAZ_WSTAMP(2);
+    EAZ_QESTAMP(dstamp, 10);
     float reward;
     int terminated, solved;
     if (run) {
@@ -289,10 +297,9 @@ __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src
         d4[1] = make_uint4(static_cast<uint32_t>(outaf), static_cast<uint32_t>(outaf >> 32), qp_hdr(step_count, task, terminated, truncated, solved, exroot),
                            __builtin_bit_cast(uint32_t, reward));
     }
-    EAZ_WSTAMP(3);
+    EAZ_QESTAMP(dstamp, 11);
     qp_emit_obs(words, xb, mem, exin, inaf, exout, outaf, lane);
-    EAZ_WSTAMP(4);
-    EAZ_WSTAMP(5);
+    EAZ_QESTAMP(dstamp, 12);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         char* blob = k == 0 ? blob0 : blob1;
@@ -322,7 +329,7 @@ __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src
     }
     reward_out = reward;
     term_out = terminated;
-    EAZ_WSTAMP(6);
+    EAZ_QESTAMP(dstamp, 13);
 }
 
 // novelty of the 16 observations whose row-words are in M.words (XXHash variant, hashes.py:162-229: lane = (environment, stripe), stripe i =
@@ -394,40 +401,36 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int b0 = blockIdx.x * kQpTrees;
-    // tree lanes: 32 per tree; re-score: slot = node of the path, q = quarter of the actions
-    const int ti = tid >> 5, tl = tid & 31, slot = tl >> 2, q = tl & 3;
-    uint32_t* T = trees + ti * L.tstride;
-    uint32_t* ST = states + ti * N * QS_WORDS;
-    uint16_t* P = path + ti * S;
-    const bool tree_live = b0 + ti < B;
-    const int gb = tree_live ? b0 + ti : B - 1;  // trees beyond the batch mirror the last environment; they never store outside LDS / their scratch rows
-    float* LG = logits_base + static_cast<long>(b0 + ti) * N * kQpA;
-    const Group<4, 4> g = make_group<4, 4>(gb, q, kQpA);
-    const float beta = sbeta * (B > 1 ? static_cast<float>(gb) / static_cast<float>(B - 1) : 0.0f);  // selfplay.py:105
-    const bool need_var = beta != 0.0f;
+    // Every phase derives its lane roles from a thread id the compiler cannot trace to threadIdx (an empty asm): otherwise the ~40 registers
+    // of lane-derived pointers / indices of ALL phases are computed once at the kernel entry and held (or spilled) across the whole loop.
+    auto phase_tid = [&]() { int t_ = tid; asm volatile("" : "+v"(t_)); return t_; };
+    // tree lanes: 32 per tree (a tree never leaves its wavefront); re-score: slot = node of the path, q = quarter of the actions.  Trees
+    // beyond the batch mirror the last environment; they never store outside LDS / their own scratch rows.
+#define EAZ_QP_TREE_LANES                                                                                            \
+    const int pt_ = phase_tid();                                                                                     \
+    const int ti = pt_ >> 5, tl = pt_ & 31, slot = tl >> 2, q = tl & 3;                                              \
+    uint32_t* T = trees + ti * L.tstride;                                                                            \
+    uint32_t* ST = states + ti * N * QS_WORDS;                                                                       \
+    uint16_t* P = path + ti * S;                                                                                     \
+    const bool tree_live = b0 + ti < B;                                                                              \
+    const int gb = tree_live ? b0 + ti : B - 1;                                                                      \
+    float* LG = logits_base + static_cast<long>(b0 + ti) * N * kQpA;                                                 \
+    const Group<4, 4> g = make_group<4, 4>(gb, q, kQpA);                                                             \
+    const float beta = sbeta * (B > 1 ? static_cast<float>(gb) / static_cast<float>(B - 1) : 0.0f); /* selfplay.py:105 */ \
+    const bool need_var = beta != 0.0f;                                                                              \
+    (void)ST; (void)P; (void)LG; (void)slot; (void)need_var; (void)tree_live
+    // forward lanes: lane (r, kq) of wave w owns hidden columns 64 w + 4 r .. + 3
+#define EAZ_QP_FWD_LANES                                                           \
+    const int pf_ = phase_tid() & 63;                                              \
+    const int fr = pf_ & 15, fkq = pf_ >> 4, fw = wave & 3;                        \
+    const int fn0 = fw * 64, fcol = fn0 + 4 * fr, fvoff = (fkq * kFcH + fcol) * 4; \
+    (void)fcol
 
     // ---------------------------------------------------------------- prologue ----------------------------------------------------
-    // ---- the forward's per-lane constants, resident for the whole launch: lane (r, kq) of wave w owns hidden columns 64 w + 4 r .. + 3;
-    // biases of those columns, and the layer-3 weights of the wave's quarter of k as MFMA B operands (W3[64 w + 4 q + kq][r], zero beyond
-    // the head's outputs) ----
-    const int fr = lane & 15, fkq = lane >> 4, fw = wave & 3;
-    const int fn0 = fw * 64, fcol = fn0 + 4 * fr, fvoff = (fkq * kFcH + fcol) * 4;
-    // The two one-output heads share a register set: B column 0 = W3 of the value head, column 1 = W3 of the ube head (a chain then also
-    // produces the other head's column from the wrong hidden tile, which nobody reads).
-    float w3v[2][16];  // [0]: value | ube, [1]: policy
     floatx4 Bq[kPsDepth];  // the weight stream, 16 k-steps ahead
     {
         EAZ_QP_ARGS;
-        {
-            const float* pwv = a.net.w[a.heads.id[fr == 1 ? 1 : 0] * 3 + 2] + (fn0 + fkq);
-            const float* pwp = a.net.w[a.heads.id[2] * 3 + 2] + (fn0 + fkq) * kQpA + fr;
-#pragma unroll
-            for (int qq = 0; qq < 16; ++qq) {
-                const float wv = pwv[4 * qq], wp = pwp[4 * qq * kQpA];
-                w3v[0][qq] = fr < 2 ? wv : 0.0f;
-                w3v[1][qq] = wp;
-            }
-        }
+        EAZ_QP_FWD_LANES;
         for (int i = tid; i < 3 * 2 * kFcH; i += kQpThreads) {
             const int h = i / (2 * kFcH), l = (i / kFcH) & 1, c = i & (kFcH - 1);
             M.b12[h][l][c] = a.net.b[a.heads.id[h] * 3 + l][c];
@@ -481,6 +484,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
         if (s >= 2 || (s == 0 && it > 0)) {
             // ---- expand + backward of the simulation evaluated last (simulation s - 2; at s == 0: simulation S - 1 of the step before) ----
             EAZ_QP_ARGS;
+            EAZ_QP_TREE_LANES;
             EAZ_QPSTAMP(0);
             const int D = M.D[ti], dst = M.dst[ti], parent = M.parent[ti], action = M.action[ti];
             {
@@ -556,6 +560,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             // ---- the search of real step `step - 1` is complete: gumbel_muzero_policy tail (A.2, tree_finish_kernel), epistemic_summary
             // (A.7, tree_summary_kernel), action choice (selfplay.py:118-134), SelfplayOutput[t] except the state ----
             EAZ_QP_ARGS;
+            EAZ_QP_TREE_LANES;
             const int pstep = step - 1;
             const Key kt = fold(a.sp.key, kTagStep + static_cast<uint32_t>(pstep));
             if (slot == 0) {
@@ -635,6 +640,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
         } else if (s >= 1) {
             // ---- re-score the nodes whose selection inputs changed: the path's levels 0 .. D-1 and the (re-)expanded node (s == 1: the root) ----
             EAZ_QP_ARGS;
+            EAZ_QP_TREE_LANES;
             const int D = s >= 2 ? M.D[ti] : 0, dst = s >= 2 ? M.dst[ti] : 0;
             const int nl = D + 1;
             for (int l = slot; l < nl; l += 8) {
@@ -723,8 +729,19 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             EAZ_QPSTAMP(4);
             {
                 EAZ_QP_ARGS;
-                int j = wave >= 8 - kQpEWaves ? wave - (8 - kQpEWaves) : kQpTrees;
                 const uint32_t env_next_off = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) int*)(&M.env_next)));
+                // every wave starts on its own environment, then takes what is left, one at a time: the runs are heavy-tailed
+                const int n_static = 8;
+                auto claim = [&]() {
+                    // one ds_add_rtn by all 64 lanes (lane 0 reads the counter before this wave's 64 increments: the counter runs in units of 64),
+                    // written as the instruction itself: `atomicAdd` goes through the compiler's atomic optimizer (a lane scan behind vmcnt(0))
+                    int got;
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(env_next_off), "v"(1) : "memory");
+                    return n_static + (__builtin_amdgcn_readfirstlane(got) >> 6);
+                };
+                int j = wave;
+                int n_done = 0;
+                (void)n_done;
 #pragma unroll 1
                 while (j < kQpTrees) {
                     const int bj = b0 + j < B ? b0 + j : B - 1;
@@ -735,8 +752,15 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                     if (env_mode == 0) {
                         const int node = __builtin_amdgcn_readfirstlane(M.parent[j]), action = __builtin_amdgcn_readfirstlane(M.action[j]);
                         const int dstn = __builtin_amdgcn_readfirstlane(M.dst[j]);
+#ifdef EAZ_FC_STAMPS
+                        unsigned long long* dsp = (a.stamps && step == 0 && s == 1 + S / 2 && blockIdx.x < 256 && n_done == 0) ? a.stamps + (blockIdx.x * 8 + wave) * 16 : nullptr;
+                        n_done += 1;
+#else
+                        unsigned long long* dsp = nullptr;
+#endif
                         qp_env_step(a.e, SJ + node * QS_WORDS, SJ + dstn * QS_WORDS, M.root_ex[j], M.words[j], M.xbits[j], action, 0, env_key, bj, lane,
-                                    nullptr, nullptr, rew, term);
+                                    nullptr, nullptr, rew, term, dsp);
+                        EAZ_QESTAMP(dsp, 14);
                         if (lane == 0) { M.o_reward[j] = rew; M.o_term[j] = term; }  // rewards[b, current_player], single player
                     } else {
                         // vmap(auto_reset(env.step, env.init)) (selfplay.py:26-75,135) on the environment's current state
@@ -747,9 +771,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                         qp_env_step(a.e, M.root_state[j], M.root_state[j], M.root_ex[j], M.words[j], M.xbits[j], action, 1, env_key, bj, lane, blob0, blob1,
                                     rew, term);
                     }
-                    int got;
-                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(env_next_off), "v"(1) : "memory");
-                    j = kQpEWaves + (__builtin_amdgcn_readfirstlane(got) >> 6);
+                    j = claim();
                 }
             }
             EAZ_QPSTAMP(5);
@@ -758,6 +780,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
         }
         if (s == 0) {
             // ---- a new real step: empty tree (mctx instantiate_tree_from_root, A.3) ----
+            EAZ_QP_TREE_LANES;
             for (int n = tl; n < N; n += 32) {
                 uint32_t* R = T + n * QN_WORDS;
 #pragma unroll
@@ -769,11 +792,26 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
         if (wave < 4) {
             // ================= waves 0-3: layers 1-3 of the three heads for the 16 rows; barriers: H1 of head 0, 1, 2 | quarter sums =================
             EAZ_QP_ARGS;
+            EAZ_QP_FWD_LANES;
             __amdgpu_buffer_rsrc_t W1r[3], W2r[3];
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
                 W1r[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.net.w[a.heads.id[h] * 3]), 0, fp_kpad(240) * kFcH * 4, 0x00020000);
                 W2r[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.net.w[a.heads.id[h] * 3 + 1]), 0, kFcH * kFcH * 4, 0x00020000);
+            }
+            // layer-3 weights of this wave's quarter of k as MFMA B operands (W3[64 w + 4 q + kq][r]), requested here and consumed by the
+            // chains ~10 k cycles later.  The two one-output heads share a register set: B column 0 = W3 of the value head, column 1 = W3
+            // of the ube head (a chain then also produces the other head's column from the wrong hidden tile, which nobody reads).
+            float w3v[2][16];  // [0]: value | ube, [1]: policy
+            {
+                const float* pwv = a.net.w[a.heads.id[fr == 1 ? 1 : 0] * 3 + 2] + (fn0 + fkq);
+                const float* pwp = a.net.w[a.heads.id[2] * 3 + 2] + (fn0 + fkq) * kQpA + fr;
+#pragma unroll
+                for (int qq = 0; qq < 16; ++qq) {
+                    const float wv = pwv[4 * qq], wp = pwp[4 * qq * kQpA];
+                    w3v[0][qq] = fr < 2 ? wv : 0.0f;
+                    w3v[1][qq] = wp;
+                }
             }
             const unsigned long long* xrow = M.xbits[fr];  // this lane's layer-1 A operands: bit 4 i + kq of word p = input 64 p + 4 i + kq of row r
             const float* hpA = H2 + h16_off(fn0 + fkq, fr);  // quarter chain: H2[h16_off(n0 + 4 q + kq, r)] = hpA[68 q]
@@ -814,8 +852,9 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 }
                 __syncthreads();  // H1 of head h
                 // ---- layer 2: [16 x 256] x [256 x 256]; the refills of the last round are the first k-steps of the next head (next simulation) ----
+                floatx4 acc2[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+                for (int c = 0; c < 4; ++c) acc2[c] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
                 const float* Ap = H1 + (h & 1) * kF16HFloats + fkq * 16 + fr;  // h16_off(4 ks + kq, r) = 68 ks + 16 kq + r
 #pragma unroll
                 for (int i = 0; i < kPsARing; ++i) av[i] = Ap[i * 68];
@@ -823,7 +862,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 for (int rd = 0; rd < 4; ++rd) {
                     const bool same = rd < 3;
                     // reads past k-step 63 land in the next tile and are never used
-                    qp_round<false, false>(acc, Bq, av, Ap + (rd * kPsDepth + kPsARing) * 68, 0u, same ? W2r[h] : W1r[h == 2 ? 0 : h + 1], fvoff,
+                    qp_round<false, false>(acc2, Bq, av, Ap + (rd * kPsDepth + kPsARing) * 68, 0ull, same ? W2r[h] : W1r[h == 2 ? 0 : h + 1], fvoff,
                                            same ? 4096 * kPsDepth * (rd + 1) : 0, a3, hpA, w3v[0]);
                 }
                 const floatx4 bb2 = *reinterpret_cast<const floatx4*>(&M.b12[h][1][fcol]);
@@ -832,7 +871,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                     floatx4 o;
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        const float v = acc[c][reg] + bb2[c];
+                        const float v = acc2[c][reg] + bb2[c];
                         o[reg] = v > 0.0f ? v : 0.0f;
                     }
                     *reinterpret_cast<floatx4*>(H2 + h16_off(fcol + c, 4 * fkq)) = o;
@@ -858,6 +897,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
         if (s == 0) {
             // ---- root of real step `step`: selfplay.py:92-106,113 (root_prep_kernel) + mctx instantiate_tree_from_root (tree_root_kernel) ----
             EAZ_QP_ARGS;
+            EAZ_QP_TREE_LANES;
             const Key kt = fold(a.sp.key, kTagStep + static_cast<uint32_t>(step));
             const Key gkey = fold(kt, kTagGumbel);
             const float z = tl < 18 ? head_out(ti, tl < 16 ? 2 + tl : tl - 16) : 0.0f;

@@ -35,11 +35,10 @@ for rep in range(2):
     dt = time.perf_counter() - t0
 print(f"selfplay(T={T}): {1e3 * dt:.3f} ms = {1e6 * dt / (T * (S + 1)):.2f} us per forward (host-timed, one launch), {B * T / dt:.0f} env-steps/s")
 lib = eaz.load_library()
-buf = np.zeros(2 * 256 * 32, np.uint64)
-for fn, off in ((lib.eaz_diag_persist_stamps, 0), (lib.eaz_diag_persist_stamps2, 256 * 32)):
-    fn.argtypes = [C.c_void_p, C.c_void_p]
-    fn(search.h, buf[off:].ctypes.data)
-st = buf.reshape(256, 8, 8).astype(np.int64)
+buf = np.zeros(256 * 8 * 16, np.uint64)
+lib.eaz_diag_qp_stamps.argtypes = [C.c_void_p, C.c_void_p]
+lib.eaz_diag_qp_stamps(search.h, buf.ctypes.data)
+st = buf.reshape(256, 8, 16).astype(np.int64)
 st = st[(st[:, :, 4] > 0).all(axis=1)]
 
 
@@ -69,16 +68,14 @@ seg("T (first wave in -> last wave at the T/E barrier)", st[:, :, 4].max(axis=1)
 seg("E (barrier to barrier)", st[:, :, 6].max(axis=1) - st[:, :, 4].max(axis=1))
 seg("one simulation (T start -> F end, wave 0)", st[:, 0, 7] - st[:, 0, 0])
 
-lib.eaz_diag_sq_stamps.argtypes = [C.c_void_p]
-q = np.zeros(16, np.uint64)
-lib.eaz_diag_sq_stamps(q.ctypes.data)
-q = q.astype(np.int64)
-n = max(int(q[15]), 1)
-print(f"inside qp_env_step, mean over the {n} calls of workgroup 0's first wave (all launches of this process):")
-for name, i in (("compact state from LDS, decision", 0), ("test cases + interpreter", 1), ("reward / flags", 2), ("new state + row-words to LDS", 3),
-                ("observation bit masks (4 ballots)", 4), ("state blob (real steps only)", 5)):
-    print(f"   {name:40s} {q[i] / n:8.0f} cycles")
-print(f"   interpreter runs per call {q[9] / n:.2f}, executed cycles per run {q[8] / max(int(q[9]), 1):.1f} (longest run seen: {q[10]})")
+print("inside the FIRST interpreter step of every wave (qp_env_step, raw stamps):")
+seg("   compact state from LDS, decision, test vectors requested", diff(8, 9))
+seg("   program patch + test cases + interpreter", diff(9, 10))
+seg("   reward / flags", diff(10, 11))
+seg("   new state to LDS + observation words / bit masks", diff(11, 12))
+seg("   (state blob: real steps only)", diff(12, 13))
+seg("   outputs + stamp", diff(13, 14))
+seg("   the whole step", diff(8, 14))
 
 lib.eaz_diag_qp_dhist.argtypes = [C.c_void_p]
 dh = np.zeros(72, np.uint64)
