@@ -185,16 +185,25 @@ def dry_run(args, world, rank):
     state_bytes, A = {"c2": (16, 2), "c3": (336, 16), "c4": (80, 7)}[args.workload]
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    g = _torch.Generator().manual_seed(rank)
-    block = _torch.randint(0, 256, (T, B, _pool.record_bytes(state_bytes, A)), dtype=_torch.uint8, generator=g)
-    gathered = None
+    def fake_output(r, step):
+        """a SelfplayOutput-shaped dict of rank r at step `step` (different data every step: ordering / buffer-reuse bugs would show)"""
+        g = _torch.Generator().manual_seed(1000 * step + r)
+        f = lambda *sh: _torch.randn(*sh, generator=g)
+        return dict(state=_torch.randint(0, 256, (T, B, state_bytes), dtype=_torch.uint8, generator=g), root_value=f(T, B),
+                    root_epistemic_std=f(T, B), value_prediction=f(T, B), ube_prediction=f(T, B), q_values_epistemic_variance=f(T, B, A),
+                    action=_torch.randint(0, A, (T, B), dtype=_torch.int32, generator=g))
+
+    pooler = _pool.TrajectoryPooler() if world > 1 else None
+    R = _pool.record_bytes(state_bytes, A)
+    pend = []
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for step in range(args.steps):
         if world > 1:
-            gathered = _pool.all_gather_trajectories(block, out=gathered)
+            pend.append(pooler.submit(fake_output(rank, step)))   # the bench's one_step() without the device work
     if world > 1:
+        pooler.flush()
         dist.barrier()
     dt = time.perf_counter() - t0
     ok = True
@@ -202,8 +211,12 @@ def dry_run(args, world, rank):
         tmax = _torch.tensor([dt], dtype=_torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        pooled = _pool.pooled_batch_major(gathered)           # [world * B, T, R], src/main.py:383-385
-        ok = tuple(pooled.shape) == (world * B, T, block.shape[2]) and bool(_torch.equal(pooled[rank * B:(rank + 1) * B], block.permute(1, 0, 2)))
+        # the two most recent steps are still in their landing buffers: every rank's block must be where main.py:383-385 puts it
+        for step in range(max(0, args.steps - 2), args.steps):
+            pooled = _pool.pooled_batch_major(pend[step].wait())           # [world * B, T, R]
+            ok = ok and tuple(pooled.shape) == (world * B, T, R)
+            for r in range(world):
+                ok = ok and bool(_torch.equal(pooled[r * B:(r + 1) * B], _pool.pack(fake_output(r, step)).permute(1, 0, 2)))
     if rank == 0:
         print(json.dumps({"metric": w["metric"], "value": None, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True,
@@ -441,20 +454,20 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
     env, search, B, S, T, name = wl["env"], wl["search"], wl["B"], wl["S"], wl["T"], wl["name"]
     states = env.init(B, key=rank)
     outputs = None
-    gathered = None
+    pooler = pool.TrajectoryPooler(to_host=rehearsal) if dist is not None else None
 
     def one_step(i):
-        nonlocal outputs, gathered
+        nonlocal outputs
         outputs = search.selfplay(states, T, key=(1000 * rank + i), outputs=outputs, **wl["sp_kw"])
-        if dist is not None:
-            # pool the trajectories of all ranks (replay-buffer landing zone): ONE all-gather of the packed block
-            block = pool.pack(outputs)
-            if rehearsal:
-                gathered = pool.all_gather_trajectories(block.cpu(), out=gathered)
-            else:
-                gathered = pool.all_gather_trajectories(block, out=gathered)
+        if pooler is not None:
+            # pool the trajectories of all ranks (replay-buffer landing zone): ONE all-gather of the packed block per call, started
+            # asynchronously on a double-buffered block so that it overlaps the NEXT selfplay() launch; the timed region
+            # ends with every collective complete (sync() below)
+            pooler.submit(outputs)
 
     def sync():
+        if pooler is not None:
+            pooler.flush()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -465,9 +478,8 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
         # graph capture, kernel module loading and (N > 1) the all-gather's buffers are one-time set-up: with --warmup 0 run one
         # single real step through the same path before the clock starts (not a step of the workload: T = 1)
         search.selfplay(states, 1, key=(1000 * rank + 999), **wl["sp_kw"])
-        if dist is not None:
-            blk = pool.pack(search.selfplay(states, 1, key=(1000 * rank + 998), **wl["sp_kw"]))
-            pool.all_gather_trajectories(blk.cpu() if rehearsal else blk)
+        if pooler is not None:
+            pool.TrajectoryPooler(to_host=rehearsal).submit(search.selfplay(states, 1, key=(1000 * rank + 998), **wl["sp_kw"])).wait()
     # ---- timed region: EXACTLY K steps in the production configuration (one captured hipGraph per real step) ----
     sync()
     t0 = time.perf_counter()

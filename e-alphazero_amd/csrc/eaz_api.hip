@@ -142,7 +142,7 @@ struct eaz_search {
     char* d_replay_states;     // scratch states for that replay
     // Subleq-16 fused self-play (search_subleq_persist.hpp): one launch per selfplay() call, trees and states in LDS
     int sqp_lds;               // dynamic LDS bytes of that launch (0: the trees of a workgroup do not fit)
-    float* d_sq_logits;        // [ceil16(B), N, 16] prior-logit scratch rows
+    float* d_sq_logits;        // [ceil16(B), N, 32] scratch rows: prior logits | their softmax
 };
 
 extern "C" int eaz_ctx_create(int device, eaz_ctx** out) {
@@ -196,7 +196,6 @@ extern "C" int eaz_env_create_deepsea(eaz_ctx* ctx, int G, const uint8_t* h_acti
 extern "C" int eaz_env_create_subleq(eaz_ctx* ctx, int W, const int32_t* h_tasks, int n_tasks, int binary, eaz_env** out) {
     ARG_OK(ctx && out && h_tasks);
     if (W < 16 || W > 256) return fail("word_size must be in [16, 256] (subleq.py:606), got %d", W);
-    if (W % 4 != 0) return fail("the gfx950 Subleq kernel requires word_size %% 4 == 0, got %d", W);
     ARG_OK(n_tasks >= 1 && n_tasks <= 16);
     eaz_env* e = new eaz_env();
     e->ctx = ctx;
@@ -281,7 +280,7 @@ static int subleq_envs_per_wg(int B) {
     while (epw > 8 && cdiv(B, epw) < 256) epw /= 2;
     return epw;
 }
-static int subleq_lds_bytes(int W) { return 2 * 64 * W; }
+static int subleq_lds_bytes(int W) { return 2 * 64 * ((W + 3) & ~3); }  // program + snapshot per lane, rows padded to whole 32-bit words
 
 static int env_step_launch(eaz_env* env, int B, const void* in, const int32_t* action, Key key, int mode, void* out,
                            void* out_copy, hipStream_t st, const Key* d_key = nullptr, float* mover_reward = nullptr) {
@@ -850,9 +849,14 @@ static int make_shard(eaz_search* p, int b0, int Bs, eaz_search** out) {
     c->B = Bs;
     c->side = c->main = nullptr;
     c->ev_fork = c->ev_join = c->ev_in = c->ev_out = c->ev_shard_fork = c->ev_shard_join = nullptr;
-    // no side stream of its own: the novelty lookup runs in line with the half-batch (the two halves overlap each other instead; a second
-    // level of fork / join inside the captured step crashed hipGraph instantiation on ROCm 7.2)
+    // its own stream, and its own side stream + events for the novelty lookup beside the forward (infer_launch): a second level of fork / join
+    // inside the captured step.  Round 2 ran the lookup in line after a host crash in hipGraphInstantiate during development; the sequence
+    // itself is legal and works on ROCm 7.2 (tools/graph_nested_fork.hip: every forked stream joined before hipStreamEndCapture, no captured
+    // event waited on outside the capture), so the crash belonged to that uncommitted state of the code, not to the runtime.
     HIP_OK(hipStreamCreateWithFlags(&c->main, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     const long N = p->N, A = p->A, SB = p->tree.state_bytes, Sn = p->S, OD = p->env->dev.obs_dim;
     TreeDev& t = c->tree;
     t.B = Bs;
@@ -968,7 +972,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
             if (net->dev.in_dim == 240 && A == kQpA && s->N <= 250 && QL.total <= 160 * 1024) {
                 s->sqp_lds = QL.total;
                 HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(subleq16_selfplay_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, QL.total));
-                DALLOC(s->d_sq_logits, static_cast<size_t>(cdiv(B, kQpTrees)) * kQpTrees * s->N * kQpA);
+                DALLOC(s->d_sq_logits, static_cast<size_t>(cdiv(B, kQpTrees)) * kQpTrees * s->N * (2 * kQpA));
                 DALLOC(s->d_replay_states, static_cast<size_t>(B) * env->dev.state_bytes);
             }
         }

@@ -112,8 +112,10 @@ __global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src,
                                                          float* next_reward, uint8_t* next_term, uint8_t* next_legal,
                                                          int envs_per_wg, int mem_copy) {
     const Key key = key_ptr ? *key_ptr : key_arg;  // device-resident key: lets a captured hipGraph serve every real step
-    extern __shared__ __attribute__((aligned(16))) uint8_t lmem[];  // 2 * 64 * W (working memory + snapshot)
+    extern __shared__ __attribute__((aligned(16))) uint8_t lmem[];  // 2 * 64 * Wp (working memory + snapshot)
     const int W = e.W;
+    const int Wp = (W + 3) & ~3;  // any word_size in 16..256 (subleq.py:606): the LDS rows are whole 32-bit words, the bytes W..Wp-1 stay zero
+                                  // (state bytes beyond W are zero) and no Subleq address reaches them
     const int el = threadIdx.x;
     const int b = blockIdx.x * envs_per_wg + el;
     const bool live = el < envs_per_wg && b < B;
@@ -157,10 +159,10 @@ __global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src,
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { ex_in[i] = tin[i]; ex_out[i] = tout[i]; }
             }
-            MemLds mem{lmem + static_cast<long>(el) * W, lmem + static_cast<long>(64 + el) * W, W};
-            if (do_init) { for (int i = 0; i < W; i += 4) *reinterpret_cast<uint32_t*>(mem.m + i) = 0u; }
+            MemLds mem{lmem + static_cast<long>(el) * Wp, lmem + static_cast<long>(64 + el) * Wp, Wp};
+            if (do_init) { for (int i = 0; i < Wp; i += 4) *reinterpret_cast<uint32_t*>(mem.m + i) = 0u; }
             else {
-                for (int i = 0; i < W; i += 4) *reinterpret_cast<uint32_t*>(mem.m + i) = *reinterpret_cast<const uint32_t*>(sp->memory + i);
+                for (int i = 0; i < Wp; i += 4) *reinterpret_cast<uint32_t*>(mem.m + i) = *reinterpret_cast<const uint32_t*>(sp->memory + i);
                 if (idx >= 0 && idx < W) mem.m[idx] = static_cast<uint8_t>(act);
             }
             int bytes_c = 0;

@@ -5,7 +5,9 @@
 // (env.step of src/envs/subleq.py:648-677 + forward of src/network/fully_connected.py:41-101 + XXHash novelty of hashes.py:162-229).
 //
 // One workgroup of 512 threads (8 waves) owns 16 environments / trees for all T real steps.  Nothing of a tree lives in global memory
-// except the prior logits of its nodes (a [N,16] f32 scratch row set per tree, read back only for the nodes of the backed-up path):
+// except the prior logits of its nodes and their softmax (a [N,32] f32 scratch row set per tree: both are functions of the node alone,
+// written once at expansion; read back only for the nodes of the backed-up path, requested when the select ends, i.e. a whole
+// interpreter + forward phase before the re-score uses them):
 //   trees   LDS node records (QN_WORDS words).  A tree of N nodes has at most N - 1 edges whatever A is, so the [N,A] child arrays of
 //           mctx collapse into per-NODE fields: children_values / _visits / _variance[p, a] are always the node value / visit count /
 //           variance of the child itself (the backward pass copies them on every visit, A.6), the edge's reward and "discount is zero"
@@ -58,7 +60,9 @@ struct QpMisc {
     int o_term[kQpTrees];
     float gumbel[kQpTrees][kQpA];
     float root_logits[kQpTrees][kQpA];  // masked prior logits of node 0
+    float root_probs[kQpTrees][kQpA];   // their softmax (qtransform's prior probabilities of the node)
     float new_logits[kQpTrees][kQpA];   // masked prior logits of the node expanded by this simulation
+    float new_probs[kQpTrees][kQpA];
     float edge[kQpTrees][16][2];        // backward: (reward, discount) of the 16 path levels of the chunk being folded
     float root_v[kQpTrees], root_u[kQpTrees];
     uint32_t root_state[kQpTrees][QS_WORDS];
@@ -101,7 +105,7 @@ struct Sq16SelfplayArgs {
     EnvDev e;
     NetDev net;
     HeadList heads;      // value, ube, the policy head the search reads (context.py:132)
-    float* logits;       // [ceil16(B), N, 16] prior-logit scratch rows of the trees
+    float* logits;       // [ceil16(B), N, 32] scratch rows of the trees: masked prior logits [16] | their softmax [16]
     unsigned long long* stamps;
 };
 
@@ -414,7 +418,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
     uint16_t* P = path + ti * S;                                                                                     \
     const bool tree_live = b0 + ti < B;                                                                              \
     const int gb = tree_live ? b0 + ti : B - 1;                                                                      \
-    float* LG = logits_base + static_cast<long>(b0 + ti) * N * kQpA;                                                 \
+    float* LG = logits_base + static_cast<long>(b0 + ti) * N * (2 * kQpA);                                           \
     const Group<4, 4> g = make_group<4, 4>(gb, q, kQpA);                                                             \
     const float beta = sbeta * (B > 1 ? static_cast<float>(gb) / static_cast<float>(B - 1) : 0.0f); /* selfplay.py:105 */ \
     const bool need_var = beta != 0.0f;                                                                              \
@@ -476,6 +480,8 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
         return ((c0 + c1) + (c2 + c3)) + M.b3[slot];
     };
     const int n_iter = n_steps * (S + 1);
+    floatx4 pre_lg = floatx4{0.0f, 0.0f, 0.0f, 0.0f}, pre_pr = floatx4{0.0f, 0.0f, 0.0f, 0.0f};  // prefetched logits / probabilities of path level `slot`
+    int pre_node = -1;
 #pragma unroll 1
     for (int it = 0; it <= n_iter; ++it) {
         const int step = it / (S + 1), s = it - step * (S + 1);  // s = 0: root of real step `step`; s >= 1: simulation s - 1
@@ -496,7 +502,16 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 const float m = gmax<16>(lgv);                                                    // :135
                 ps_wave_sync();
                 lgv = lgv - m;                                                                     // :137 (every action legal, subleq.py:626)
-                if (tl < 16) { M.new_logits[ti][tl] = lgv; LG[dst * kQpA + tl] = lgv; }
+                // jax.nn.softmax of the node's prior logits, once per node (qtransform_p): Group::softmax on 16 lanes x 1 action -- the butterfly
+                // sum over masks 1, 2, 4, 8 is the pairwise tree of lsum<4> + masks 1, 2 of the 4 x 4 form, so the bits are the same
+                const float pm = gmax<16>(lgv);
+                const float pe = tl < 16 ? det_exp(lgv - pm) : 0.0f;
+                const float ps = gsum<16>(pe);
+                const float pp = pe / ps;
+                if (tl < 16) {
+                    M.new_logits[ti][tl] = lgv; M.new_probs[ti][tl] = pp;
+                    LG[dst * (2 * kQpA) + tl] = lgv; LG[dst * (2 * kQpA) + kQpA + tl] = pp;
+                }
                 if (tl == 0) {
                     const bool term = M.o_term[ti] != 0;
                     const float value = term ? 0.0f : M.o_value[ti];                               // :140
@@ -585,7 +600,11 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                     gum[j] = M.gumbel[ti][4 * q + j];
                 }
                 float cq[4];
-                qtransform<4, 4>(t, g, rw, u2f(T[QN_RAW_VALUE]), u2f(T[QN_RAW_VAR]), beta, cq);
+                {
+                    const floatx4 pr4 = *reinterpret_cast<const floatx4*>(&M.root_probs[ti][4 * q]);
+                    const float pr[4] = {pr4[0], pr4[1], pr4[2], pr4[3]};
+                    qtransform_p<4, 4>(t, g, rw, pr, u2f(T[QN_RAW_VALUE]), u2f(T[QN_RAW_VAR]), beta, cq);
+                }
                 int lmax = 0, lsumN = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { lmax = rw.visits[j] > lmax ? rw.visits[j] : lmax; lsumN += rw.visits[j]; }
@@ -648,10 +667,14 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 uint32_t* R = T + node * QN_WORDS;
                 NodeRows<4> rw;
                 const uint32_t cw = R[QN_CHILD + q];
-                floatx4 lg4;
-                if (node == 0) lg4 = *reinterpret_cast<const floatx4*>(&M.root_logits[ti][4 * q]);
-                else if (l == D) lg4 = *reinterpret_cast<const floatx4*>(&M.new_logits[ti][4 * q]);
-                else lg4 = *reinterpret_cast<const floatx4*>(LG + node * kQpA + 4 * q);
+                floatx4 lg4, pr4;
+                if (node == 0) { lg4 = *reinterpret_cast<const floatx4*>(&M.root_logits[ti][4 * q]); pr4 = *reinterpret_cast<const floatx4*>(&M.root_probs[ti][4 * q]); }
+                else if (l == D) { lg4 = *reinterpret_cast<const floatx4*>(&M.new_logits[ti][4 * q]); pr4 = *reinterpret_cast<const floatx4*>(&M.new_probs[ti][4 * q]); }
+                else if (node == pre_node) { lg4 = pre_lg; pr4 = pre_pr; }  // requested when the select that recorded this path ended
+                else {
+                    lg4 = *reinterpret_cast<const floatx4*>(LG + node * (2 * kQpA) + 4 * q);
+                    pr4 = *reinterpret_cast<const floatx4*>(LG + node * (2 * kQpA) + kQpA + 4 * q);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int c = (cw >> (8 * j)) & 0xFFu;
@@ -668,7 +691,10 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                     rw.rvar[j] = 0.0f;
                 }
                 float cq[4];
-                qtransform<4, 4>(t, g, rw, u2f(R[QN_RAW_VALUE]), need_var ? u2f(R[QN_RAW_VAR]) : 0.0f, beta, cq);
+                {
+                    const float pr[4] = {pr4[0], pr4[1], pr4[2], pr4[3]};
+                    qtransform_p<4, 4>(t, g, rw, pr, u2f(R[QN_RAW_VALUE]), need_var ? u2f(R[QN_RAW_VAR]) : 0.0f, beta, cq);
+                }
                 int lsumN = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) lsumN += rw.visits[j];
@@ -719,6 +745,14 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
 #ifdef EAZ_FC_STAMPS
                 if (step == 0 && blockIdx.x < 64) { atomicAdd(&g_qp_dhist[depth < 63 ? depth : 63], 1ull); atomicAdd(&g_qp_dhist[64 + ((s - 1) * 8) / S], static_cast<unsigned long long>(depth)); }
 #endif
+            }
+            // the next re-score reads the prior logits / probabilities of this path's nodes: level `slot` of it, requested now
+            ps_wave_sync();
+            pre_node = -1;
+            if (slot >= 1 && slot < M.D[ti]) {
+                pre_node = P[slot] & 0xFF;
+                pre_lg = *reinterpret_cast<const floatx4*>(LG + pre_node * (2 * kQpA) + 4 * q);
+                pre_pr = *reinterpret_cast<const floatx4*>(LG + pre_node * (2 * kQpA) + kQpA + 4 * q);
             }
             EAZ_QPSTAMP(3);
         }
@@ -912,7 +946,13 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 M.gumbel[ti][tl] = a.sp.gumbel_scale * gn;
             }
             const float m = gmax<16>(lgv);  // mask_invalid_actions (A.2): every action legal (subleq.py:626)
-            if (tl < 16) M.root_logits[ti][tl] = lgv - m;
+            {
+                const float ml = lgv - m;
+                const float pm = gmax<16>(ml);
+                const float pe = tl < 16 ? det_exp(ml - pm) : 0.0f;
+                const float ps = gsum<16>(pe);
+                if (tl < 16) { M.root_logits[ti][tl] = ml; M.root_probs[ti][tl] = pe / ps; }
+            }
             if (tl == 0) {
                 const float root_v = M.o_value[ti];
                 const float root_u = ube_combine(M.o_ube[ti], M.o_nov[ti], t.max_u);  // fully_connected.py:92-96

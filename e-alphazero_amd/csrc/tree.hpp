@@ -243,13 +243,14 @@ __device__ __forceinline__ void load_rows(const TreeDev& t, const Group<LPT, APL
 }
 
 // emctx epistemic_qtransform_completed_by_mix_value [EXT] (selfplay.py:114-116; A.5).  beta == 0 -> plain mctx.
+// `probs` = jax.nn.softmax(prior_logits) of the node: a function of the node's logits alone, so a caller may compute it once per node
+// (search_subleq_persist.hpp keeps it beside the logits) instead of once per visit -- same operations, same bits.
 template <int LPT, int APL>
-__device__ __forceinline__ void qtransform(const TreeDev& t, const Group<LPT, APL>& g, const NodeRows<APL>& r,
-                                           float raw_value, float raw_var, float beta, float (&out)[APL]) {
-    float q[APL], probs[APL];
+__device__ __forceinline__ void qtransform_p(const TreeDev& t, const Group<LPT, APL>& g, const NodeRows<APL>& r, const float (&probs)[APL],
+                                             float raw_value, float raw_var, float beta, float (&out)[APL]) {
+    float q[APL];
 #pragma unroll
     for (int j = 0; j < APL; ++j) q[j] = r.rewards[j] + r.discounts[j] * r.values[j];
-    g.softmax(r.logits, probs);
     int ln = 0, lmax = 0;
 #pragma unroll
     for (int j = 0; j < APL; ++j) { ln += r.visits[j]; lmax = r.visits[j] > lmax ? r.visits[j] : lmax; }
@@ -289,6 +290,13 @@ __device__ __forceinline__ void qtransform(const TreeDev& t, const Group<LPT, AP
     const float scale = (t.maxvisit_init + static_cast<float>(maxN)) * t.value_scale;
 #pragma unroll
     for (int j = 0; j < APL; ++j) out[j] = scale * out[j];
+}
+template <int LPT, int APL>
+__device__ __forceinline__ void qtransform(const TreeDev& t, const Group<LPT, APL>& g, const NodeRows<APL>& r,
+                                           float raw_value, float raw_var, float beta, float (&out)[APL]) {
+    float probs[APL];
+    g.softmax(r.logits, probs);
+    qtransform_p<LPT, APL>(t, g, r, probs, raw_value, raw_var, beta, out);
 }
 
 // mctx seq_halving.score_considered + masked_argmax [EXT] (A.2)

@@ -79,20 +79,34 @@ def fc_weight_list(params):
 
 
 def save_npz(path: str, params, state) -> None:
-    """Checkpoint interop: flat .npz with 'module/name' keys."""
+    """Checkpoint interop (main.py:325-340): one flat .npz, keys "params/<haiku module>/<leaf>" and
+    "state/<haiku module>/<leaf>" -- exactly what the reference-side export of INTEGRATION.md ("Checkpoints") writes from
+    dic["model"] = (params, state).  Every leaf is kept (BatchNorm EMAs carry `hidden` / `counter` beside `average`)."""
     flat = {}
-    for mod, d in list(params.items()) + list(state.items()):
-        for k, v in d.items():
-            flat[f"{mod}/{k}"] = np.asarray(v)
+    for prefix, tree in (("params", params), ("state", state or {})):
+        for mod, d in tree.items():
+            for k, v in d.items():
+                flat[f"{prefix}/{mod}/{k}"] = np.asarray(v)
     np.savez(path, **flat)
 
 
+_STATE_LEAVES = ("binary_set", "random_matrix")
+
+
 def load_npz(path: str):
+    """-> (params, state) haiku-style dicts.  Loaded with allow_pickle=False: nothing in the file is executed.  Files without the
+    "params/" / "state/" prefixes (round-1/2 layout) are split by leaf name: hash-module leaves and "/~/" (EMA) modules are state."""
     z = np.load(path, allow_pickle=False)
     params, state = {}, {}
     for key in z.files:
-        mod, name = key.rsplit("/", 1)
-        (state if name == "binary_set" else params).setdefault(mod, {})[name] = z[key]
+        head, _, rest = key.partition("/")
+        if head in ("params", "state") and "/" in rest:
+            mod, name = rest.rsplit("/", 1)
+            (params if head == "params" else state).setdefault(mod, {})[name] = z[key]
+        else:
+            mod, name = key.rsplit("/", 1)
+            is_state = name in _STATE_LEAVES or "/~/" in mod
+            (state if is_state else params).setdefault(mod, {})[name] = z[key]
     return params, state
 
 

@@ -62,6 +62,58 @@ def all_gather_trajectories(block: torch.Tensor, out: torch.Tensor | None = None
     return out
 
 
+class TrajectoryPooler:
+    """The all-gather of step k off the critical path of step k + 1 ("off the critical path (overlap with next call)").
+
+    `submit(out)` packs the SelfplayOutput of the call that has just been enqueued into one of TWO packed blocks and starts the all-gather
+    with async_op=True: on RCCL the collective runs on the communicator's own stream behind the work already enqueued on the current
+    stream (the pack), so the next selfplay() launch does not wait for it; the block / landing buffer of a slot is reused only after its
+    previous collective has been waited for.  `Pending.wait()` makes the current stream (gloo: the host) wait for that step's collective
+    and returns its [world, T, B, R] landing buffer, valid until two more submits.  `flush()` waits for everything in flight."""
+
+    class Pending:
+        def __init__(self, work, gathered):
+            self.work, self.gathered = work, gathered
+
+        def wait(self) -> torch.Tensor:
+            if self.work is not None:
+                self.work.wait()
+                self.work = None
+            return self.gathered
+
+    def __init__(self, group=None, to_host: bool = False):
+        self.group, self.to_host = group, to_host
+        self.blocks = [None, None]
+        self.landing = [None, None]
+        self.pending = [None, None]
+        self.n = 0
+
+    def submit(self, out: dict) -> "TrajectoryPooler.Pending":
+        import torch.distributed as dist
+
+        slot = self.n & 1
+        self.n += 1
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()  # the collective that read this slot's block two steps ago
+        block = pack(out)
+        if self.to_host:               # rehearsal on fewer GPUs than ranks: gloo through host memory
+            block = block.cpu()
+        if self.blocks[slot] is None or self.blocks[slot].shape != block.shape:
+            self.blocks[slot] = torch.empty_like(block)
+            world = dist.get_world_size(self.group)
+            self.landing[slot] = torch.empty((world,) + tuple(block.shape), dtype=torch.uint8, device=block.device)
+        self.blocks[slot].copy_(block)
+        T, B, R = block.shape
+        work = dist.all_gather_into_tensor(self.landing[slot].view(-1, B, R), self.blocks[slot], group=self.group, async_op=True)
+        self.pending[slot] = TrajectoryPooler.Pending(work, self.landing[slot])
+        return self.pending[slot]
+
+    def flush(self) -> None:
+        for p in self.pending:
+            if p is not None:
+                p.wait()
+
+
 def pooled_view(gathered: torch.Tensor) -> torch.Tensor:
     """[world, T, B, R] -> time-major [T, world*B, R]"""
     W, T, B, R = gathered.shape

@@ -36,6 +36,19 @@ def test_self_launch_reports_n_gpus(n):
     assert res["config"]["global_batch"] == 8 * n and res["scaling"] == "weak"
 
 
+@pytest.mark.timeout(300)
+def test_eight_rank_dry_run_with_the_c5_record_layout():
+    """BASELINE.json configs[4] (DeepSea-32, 8 x B, RCCL all-gather) rehearsed on the CPU at a reduced per-rank batch: eight ranks started
+    by bench.py itself, C2/C5 record layout (16-byte states, 2 actions, T = 32), three steps through the asynchronous double-buffered
+    pooler, every rank's block checked at its place in the [8 * B, T, R] replay block (src/main.py:383-385)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "3", "--warmup", "0", "--dry-run", "--batch", "16", "--workload", "c2"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = _json_line(r.stdout)
+    assert res["n_gpus"] == 8 and res["pooled_block_ok"] is True and res["config"]["global_batch"] == 128
+    assert "x8" in res["config"]["parallelism"]
+
+
 @pytest.mark.timeout(180)
 def test_torchrun_environment_is_honoured():
     """Under torchrun (WORLD_SIZE set) bench.py must not fan out again, and --gpus must agree with the world size."""

@@ -188,8 +188,14 @@ def test_subleq16_selfplay_crosses_episode_boundaries(oracle, eaz, torch, flags,
     st = env.init(B, key=13)
     ost = oenv.init(B, key=(13, 0))
     assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost)
+    import time as _t
+    _t0 = _t.perf_counter()
     out = search.selfplay(st, T, key=57, **flags)
+    torch.cuda.synchronize()
+    _t1 = _t.perf_counter()
     ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(57, 0), discount=0.97, **flags)
+    _t2 = _t.perf_counter()
+    print(f"TIMING {kernel_variant} {flags}: device {_t1 - _t0:.2f} s, oracle {_t2 - _t1:.2f} s", flush=True)
     assert np.array_equal(out["action"].cpu().numpy(), ref["action"])
     assert np.array_equal(subleq_device_to_oracle(out["state"].cpu().numpy(), W), ref["state"])
     assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost)
@@ -197,6 +203,40 @@ def test_subleq16_selfplay_crosses_episode_boundaries(oracle, eaz, torch, flags,
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
     sc = ref["state"].view(np.uint8)[..., 0:4].copy().view(np.int32)[..., 0]
     assert (np.diff(sc.astype(np.int64), axis=0) < 0).any(), "no episode ended inside the window: the test lost its point"
+
+
+@pytest.mark.parametrize("W,binary", [(17, True), (18, True), (30, False)])
+def test_subleq_word_sizes_that_are_not_multiples_of_four(oracle, eaz, torch, W, binary, kernel_variant):
+    """subleq.py:606 allows every word_size in 16..256; with subleq_hash_only_io (config.py:30) the hashed slice is 32 rows and always a
+    multiple of 4 (hashes.py:210).  Environment steps on random programs, then self-play across an auto-reset, against the oracle."""
+    from e_alphazero_amd import engine
+
+    if kernel_variant not in ("persist", "tile16-unfused"):
+        pytest.skip("one fused and one unfused variant cover the per-lane Subleq kernel")
+    B, S, T = 21, 10, 3
+    dims, params, state = subleq_setup(eaz, W, binary=binary, seed=W, fill=0.3)
+    assert dims["hash_len"] % 4 == 0 and W % 4 != 0
+    env = engine.EnvHandle.subleq(W, (1, 4), binary, device=0)
+    oenv = oracle.OracleEnv.subleq(W, (1, 4), binary)
+    rng = np.random.default_rng(W)
+    st = env.init(B, key=3)
+    ost = oenv.init(B, key=(3, 0))
+    for t in range(W + 2):  # past the end of an episode: finish, terminal no-op, auto-reset
+        a = rng.integers(0, W, B).astype(np.int32)
+        st = env.step(st, torch.from_numpy(a).cuda(), key=50 + t, autoreset=t % 3 == 2)
+        ost = oenv.step(ost, a, key=(50 + t, 0), autoreset=t % 3 == 2)
+        assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost), f"W={W} t={t}"
+        assert np.array_equal(env.observe(st).cpu().numpy(), oenv.observe(ost))
+    net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
+    onet = oracle.OracleNet(dims["in_dim"], 256, W, eaz.params.fc_weight_list(params), hash_off=dims["hash_off"],
+                            hash_len=dims["hash_len"], bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+    search = engine.Search(env, net, B, S, discount=0.97)
+    out = search.selfplay(st, T, key=61)
+    ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(61, 0), discount=0.97)
+    assert np.array_equal(out["action"].cpu().numpy(), ref["action"])
+    assert np.array_equal(subleq_device_to_oracle(out["state"].cpu().numpy(), W), ref["state"])
+    for k in ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction", "q_values_epistemic_variance"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
 
 
 def test_empty_batches_are_no_ops(eaz, torch):
@@ -585,16 +625,13 @@ def test_simhash_lookup_update_and_selfplay_match_oracle(oracle, eaz, torch, kin
 
 
 def test_unsupported_shapes_fail_loudly(eaz, torch):
-    """The device path is specialised for linear_layer_size = 256 (config.py:24, every reference configuration) and Subleq word sizes
-    that are multiples of 4 (the reference allows 16..256, subleq.py:606): anything else must be refused with a message, never computed
-    on some fallback."""
+    """The device path is specialised for linear_layer_size = 256 (config.py:24, every reference configuration); Subleq word sizes are
+    16..256 (subleq.py:606): anything else must be refused with a message, never computed on some fallback."""
     from e_alphazero_amd import engine
 
     env = engine.EnvHandle.deepsea(8, np.zeros((8, 8), np.uint8), device=0)
     with pytest.raises(eaz.EazError, match="linear_layer_size = 256"):
         engine.FCNet(env.ctx, 64, 128, 2, eaz.params.init_fc_params(64, 128, 2, seed=0))
-    with pytest.raises(eaz.EazError, match="word_size % 4"):
-        engine.EnvHandle.subleq(18, (1,), True, device=0)
     with pytest.raises(eaz.EazError, match=r"\[16, 256\]"):
         engine.EnvHandle.subleq(8, (1,), True, device=0)
     with pytest.raises(eaz.EazError, match="multiple of 4"):

@@ -11,8 +11,8 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _fake_output(rank, T, B, SB, A):
-    g = torch.Generator().manual_seed(100 + rank)
+def _fake_output(rank, T, B, SB, A, step=0):
+    g = torch.Generator().manual_seed(100 + rank + 1000 * step)
     return dict(
         state=torch.randint(0, 256, (T, B, SB), dtype=torch.uint8, generator=g),
         root_value=torch.randn(T, B, generator=g), root_epistemic_std=torch.rand(T, B, generator=g),
@@ -47,6 +47,24 @@ def _worker(rank, world, port, T, B, SB, A, q):
         for k, v in ref.items():
             ok &= bool(torch.equal(bm[k][r * B:(r + 1) * B], v.transpose(0, 1)))
     ok &= tuple(bm["state"].shape) == (world * B, T, SB) and tuple(bm["action"].shape) == (world * B, T)
+    # three consecutive selfplay() calls through the asynchronous, double-buffered pooler (what bench.py's timed loop does): different data
+    # every step, results read late (after the NEXT submit), buffers reused from the third step on
+    pooler = pool.TrajectoryPooler()
+    pend = []
+    for step in range(3):
+        pend.append(pooler.submit(_fake_output(rank, T, B, SB, A, step)))
+        if step >= 1:  # step - 1 is complete and still in its landing buffer while step's collective is in flight
+            got = pool.unpack_batch_major(pool.pooled_batch_major(pend[step - 1].wait()), SB, A)
+            for r in range(world):
+                ref = _fake_output(r, T, B, SB, A, step - 1)
+                for k, v in ref.items():
+                    ok &= bool(torch.equal(got[k][r * B:(r + 1) * B], v.transpose(0, 1)))
+    pooler.flush()
+    got = pool.unpack_batch_major(pool.pooled_batch_major(pend[2].wait()), SB, A)
+    for r in range(world):
+        for k, v in _fake_output(r, T, B, SB, A, 2).items():
+            ok &= bool(torch.equal(got[k][r * B:(r + 1) * B], v.transpose(0, 1)))
+    ok &= pend[0].gathered.data_ptr() == pend[2].gathered.data_ptr() != pend[1].gathered.data_ptr()  # two landing buffers, alternating
     q.put((rank, ok, tuple(pooled["state"].shape)))
     dist.barrier()
     dist.destroy_process_group()
