@@ -435,8 +435,10 @@ def parity_gate(wl, args):
     oenv, onet, okw, oname = wl["oracle"](O)
     ost = oenv.init(nb)
     ref = O.selfplay(oenv, onet, ost, T=nt, S=S, key=engine.key_pair(4242), **okw, **wl["sp_kw"])
-    ok_int = bool(np.array_equal(out["action"].cpu().numpy(), ref["action"]) and np.array_equal(out["state"].cpu().numpy(), ref["state"])
-                  and np.array_equal(st.cpu().numpy(), ost))
+    # Subleq: the oracle keeps words as int32, the device blob of include/eaz.h as bytes -- same fields, compared in the oracle's layout
+    conv = (lambda a: O.subleq_device_to_oracle(a, 16)) if wl["name"] == "c3" else (lambda a: a)
+    ok_int = bool(np.array_equal(out["action"].cpu().numpy(), ref["action"]) and np.array_equal(conv(out["state"].cpu().numpy()), ref["state"])
+                  and np.array_equal(conv(st.cpu().numpy()), ost))
     err = max(float(np.max(np.abs(out[k].cpu().numpy() - ref[k]))) for k in
               ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction", "q_values_epistemic_variance"))
     if not ok_int or not err <= 1e-5:

@@ -46,6 +46,7 @@ SIGNATURES = {
     "eaz_env_create_subleq": [_vp, _i, _vp, _i, _i, _pp],
     "eaz_env_set_subleq_reward": [_vp, _i],
     "eaz_subleq16_test_vectors": [_i, _i, _vp, _vp],
+    "eaz_subleq_test_vectors": [_i, _i, _i, _vp, _vp],
     "eaz_env_create_connect4": [_vp, _pp],
     "eaz_env_num_players": [_vp],
     "eaz_env_destroy": [_vp],

@@ -237,6 +237,12 @@ extern "C" int eaz_subleq16_test_vectors(int task, int c, uint16_t in[8], uint16
     return 0;
 }
 
+extern "C" int eaz_subleq_test_vectors(int word_size, int task, int c, uint16_t in[8], uint16_t expected_out[8]) {
+    ARG_OK(in && expected_out && c >= 0 && c < 3 && word_size >= 16 && word_size <= 256);
+    subleq_test_case(task, c, word_size, in, expected_out);  // the function the per-lane interpreter kernel calls (csrc/envs.hpp)
+    return 0;
+}
+
 extern "C" int eaz_env_create_connect4(eaz_ctx* ctx, eaz_env** out) {
     ARG_OK(ctx && out);
     eaz_env* e = new eaz_env();

@@ -96,14 +96,15 @@ __device__ __forceinline__ int ds_hot_index(const EnvDev& e, const eaz_deepsea_s
 // ---------------------------------------------------------------------------------------------------------------
 // Subleq
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int pymod(int x, int m) {
+__host__ __device__ __forceinline__ int pymod(int x, int m) {
     const int r = x % m;
     return r < 0 ? r + m : r;
 }
 
 // subleq.py:398-501 get_test_cases: test case `c` of `task`, already modulo'd and padded (:101-107,:402-404).
 // lax.switch clamps the branch index, so task ids >= 6 all select the multiplication table.
-__device__ __forceinline__ void subleq_test_case(int task, int c, int W, uint16_t tin[8], uint16_t tout[8]) {
+// (host + device: eaz_subleq_test_vectors hands the same function to the CPU test that holds it against the oracle's generator)
+__host__ __device__ __forceinline__ void subleq_test_case(int task, int c, int W, uint16_t tin[8], uint16_t tout[8]) {
     int branch = task - 1;
     branch = branch < 0 ? 0 : (branch > 5 ? 5 : branch);
     int in[8], out[8];

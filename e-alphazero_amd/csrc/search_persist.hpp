@@ -12,8 +12,9 @@
 // Workgroup = 320 threads:
 //   waves 0-3  tree phase: 16 lanes per tree (lane j = level j of the recorded root-to-leaf path); forward: each wave owns 64 output
 //              columns of the hidden layers (v_mfma_f32_16x16x4_f32, one accumulation chain per output = the oracle's fmaf chain)
-//   wave 4     helper: novelty lookup of the 16 leaves, the 256-deep layer-3 chains of head h (VALU fmaf chain, bit-identical to the
-//              MFMA chain) while waves 0-3 run layer 2 of head h+1, the head epilogues (tanh)
+//   wave 4     helper: W1 row gathers (layer 1) of heads 1 and 2 under layer 2 of the head before, novelty lookup of the 16 leaves, and at the
+//              end ((c0 + c1) + (c2 + c3)) + b and the head activations from the four quarter chains of layer 3, which waves 0-3 run as
+//              MFMA chains over their own hidden columns (a head's chain rides in the first round of the next head's layer 2)
 //
 // Per simulation (all in LDS / registers, nothing but the weight stream and 16 W1 rows per head comes from L2):
 //   expand + backward of the previous leaf   lane 0 writes the new node; the path's levels are folded leaf-to-root: every lane computes
@@ -39,9 +40,6 @@ namespace eaz {
 constexpr int kPsTrees = 16;     // trees per workgroup = rows of the forward tile
 constexpr int kPsThreads = 320;  // 4 tree / MFMA waves + 1 helper wave
 constexpr int kPsA = 2;          // actions (DeepSea)
-#ifndef EAZ_PS_EXPERIMENT
-#define EAZ_PS_EXPERIMENT 0
-#endif
 #ifndef EAZ_PS_DEPTH
 #define EAZ_PS_DEPTH 16
 #endif
@@ -214,21 +212,15 @@ __device__ __forceinline__ void ps_round(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDep
     }
 #pragma unroll
     for (int i = 0; i < kPsDepth; ++i) {
-#if EAZ_PS_EXPERIMENT == 2   /* timing experiments of the diagnostic build only (results are wrong): 1 = no weight refills, 2 = no MFMAs */
-        acc[0][0] += av[i % kPsARing] * Bq[i][0]; acc[1][0] += Bq[i][1]; acc[2][0] += Bq[i][2]; acc[3][0] += Bq[i][3];
-#else
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i % kPsARing], Bq[i][c], acc[c], 0, 0, 0);
-#endif
         if constexpr (CHAIN) {
             if (i < 16) {
                 a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(cha[i % kChRing], chb[i % kChRing], a3, 0, 0, 0);
                 if (i + kChRing < 16) { cha[i % kChRing] = hpA[68 * (i + kChRing)]; chb[i % kChRing] = wpB[4 * (i + kChRing)]; }
             }
         }
-#if EAZ_PS_EXPERIMENT != 1
         Bq[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sbase + i * 4096, 0));
-#endif
         av[i % kPsARing] = apn[i * 68];
         __builtin_amdgcn_sched_barrier(0);  // keep every refill right behind the k-step that freed its registers
     }

@@ -150,6 +150,7 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
                 asm volatile("" ::"v"(touch));
             }
             int j = wave, taken = 0;
+            (void)taken;  // read by the diagnostic build's stamps only
             const uint32_t env_next_off = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) int*)(&env_next)));
 #pragma unroll 1
             while (j < 16) {

@@ -833,19 +833,15 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 W1r[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.net.w[a.heads.id[h] * 3]), 0, fp_kpad(240) * kFcH * 4, 0x00020000);
                 W2r[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.net.w[a.heads.id[h] * 3 + 1]), 0, kFcH * kFcH * 4, 0x00020000);
             }
-            // layer-3 weights of this wave's quarter of k as MFMA B operands (W3[64 w + 4 q + kq][r]), requested here and consumed by the
-            // chains ~10 k cycles later.  The two one-output heads share a register set: B column 0 = W3 of the value head, column 1 = W3
-            // of the ube head (a chain then also produces the other head's column from the wrong hidden tile, which nobody reads).
-            float w3v[2][16];  // [0]: value | ube, [1]: policy
+            // layer-3 weights of this wave's quarter of k as MFMA B operands (W3[64 w + 4 q + kq][r]): ONE set of 16 registers, requested
+            // ~10 k cycles before the chain that consumes it.  First the two one-output heads together: B column 0 = W3 of the value head,
+            // column 1 = W3 of the ube head (a chain then also produces the other head's column from the wrong hidden tile, which nobody
+            // reads); once the ube head's chain has run (first round of the third head) the policy head's weights take their place.
+            float w3v[16];
             {
                 const float* pwv = a.net.w[a.heads.id[fr == 1 ? 1 : 0] * 3 + 2] + (fn0 + fkq);
-                const float* pwp = a.net.w[a.heads.id[2] * 3 + 2] + (fn0 + fkq) * kQpA + fr;
 #pragma unroll
-                for (int qq = 0; qq < 16; ++qq) {
-                    const float wv = pwv[4 * qq], wp = pwp[4 * qq * kQpA];
-                    w3v[0][qq] = fr < 2 ? wv : 0.0f;
-                    w3v[1][qq] = wp;
-                }
+                for (int qq = 0; qq < 16; ++qq) { const float wv = pwv[4 * qq]; w3v[qq] = fr < 2 ? wv : 0.0f; }
             }
             const unsigned long long* xrow = M.xbits[fr];  // this lane's layer-1 A operands: bit 4 i + kq of word p = input 64 p + 4 i + kq of row r
             const float* hpA = H2 + h16_off(fn0 + fkq, fr);  // quarter chain: H2[h16_off(n0 + 4 q + kq, r)] = hpA[68 q]
@@ -858,17 +854,22 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 floatx4 a3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
                 // ---- layer 1: [16 x 256] x [256 x 256], inputs 240..255 zero on both sides (exact); the first round carries the quarter chain
                 // of the head before ----
-                if (h > 0) qp_round<true, true>(acc, Bq, av, nullptr, xrow[0] >> fkq, W1r[h], fvoff, 4096 * kPsDepth, a3, hpA, w3v[0]);
-                else qp_round<false, true>(acc, Bq, av, nullptr, xrow[0] >> fkq, W1r[h], fvoff, 4096 * kPsDepth, a3, hpA, w3v[0]);
+                if (h > 0) qp_round<true, true>(acc, Bq, av, nullptr, xrow[0] >> fkq, W1r[h], fvoff, 4096 * kPsDepth, a3, hpA, w3v);
+                else qp_round<false, true>(acc, Bq, av, nullptr, xrow[0] >> fkq, W1r[h], fvoff, 4096 * kPsDepth, a3, hpA, w3v);
                 if (h > 0 && fr == h - 1) {  // head 0 = value: output column 0, head 1 = ube: column 1 (shared W3 registers)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) part[(fw * 16 + 4 * fkq + reg) * kQpPartLd + fr] = a3[reg];
+                }
+                if (h == 2) {
+                    const float* pwp = a.net.w[a.heads.id[2] * 3 + 2] + (fn0 + fkq) * kQpA + fr;
+#pragma unroll
+                    for (int qq = 0; qq < 16; ++qq) w3v[qq] = pwp[4 * qq * kQpA];
                 }
 #pragma unroll 1
                 for (int rd = 1; rd < 4; ++rd) {
                     const bool same = rd < 3;  // the refills of the last round are the first k-steps of layer 2
                     qp_round<false, true>(acc, Bq, av, nullptr, xrow[rd] >> fkq, same ? W1r[h] : W2r[h], fvoff,
-                                          same ? 4096 * kPsDepth * (rd + 1) : 0, a3, hpA, w3v[0]);
+                                          same ? 4096 * kPsDepth * (rd + 1) : 0, a3, hpA, w3v);
                 }
                 {
                     float* Ht = H1 + (h & 1) * kF16HFloats;
@@ -897,7 +898,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                     const bool same = rd < 3;
                     // reads past k-step 63 land in the next tile and are never used
                     qp_round<false, false>(acc2, Bq, av, Ap + (rd * kPsDepth + kPsARing) * 68, 0ull, same ? W2r[h] : W1r[h == 2 ? 0 : h + 1], fvoff,
-                                           same ? 4096 * kPsDepth * (rd + 1) : 0, a3, hpA, w3v[0]);
+                                           same ? 4096 * kPsDepth * (rd + 1) : 0, a3, hpA, w3v);
                 }
                 const floatx4 bb2 = *reinterpret_cast<const floatx4*>(&M.b12[h][1][fcol]);
 #pragma unroll
@@ -915,7 +916,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     floatx4 z3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                    for (int qq = 0; qq < 16; ++qq) z3 = __builtin_amdgcn_mfma_f32_16x16x4f32(hpA[68 * qq], w3v[1][qq], z3, 0, 0, 0);
+                    for (int qq = 0; qq < 16; ++qq) z3 = __builtin_amdgcn_mfma_f32_16x16x4f32(hpA[68 * qq], w3v[qq], z3, 0, 0, 0);
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) part[(fw * 16 + 4 * fkq + reg) * kQpPartLd + 2 + fr] = z3[reg];
                 }

@@ -96,6 +96,9 @@ EAZ_API int eaz_env_set_subleq_reward(eaz_env* env, int reward_fn);
  * compile-time table of csrc/envs.hpp, i.e. get_test_cases (subleq.py:398-501) with the branch index clamped like lax.switch; 8 values
  * each, W = 16 beyond the valid ones.  tests/test_abi_and_host.py holds it against the oracle's generator for every task. */
 EAZ_API int eaz_subleq16_test_vectors(int task, int c, uint16_t in[8], uint16_t expected_out[8]);
+/* The same for any word_size in 16..256: the run-time generator of csrc/envs.hpp that the per-lane interpreter (word sizes other than 16)
+ * evaluates on the device, compiled for the host as well. */
+EAZ_API int eaz_subleq_test_vectors(int word_size, int task, int c, uint16_t in[8], uint16_t expected_out[8]);
 /* pgx.make("connect_four") [EXT] main.py:190-194 */
 EAZ_API int eaz_env_create_connect4(eaz_ctx* ctx, eaz_env** out);
 EAZ_API int eaz_env_destroy(eaz_env* env);

@@ -404,3 +404,31 @@ def fold(key, tag):
     out = np.empty(2, np.uint32)
     lib().eazo_fold(key[0], key[1], tag, _p(out))
     return int(out[0]), int(out[1])
+
+
+# ---- Subleq state blobs: this oracle's layout (int32 memory[256], int32 io) <-> the device layout (include/eaz.h eaz_subleq_state): the
+# checker side of every Subleq state comparison (tests/, bench.py's parity gate) ----
+ORACLE_SUBLEQ = np.dtype([("step_count", "<i4"), ("task", "<i4"), ("reward", "<f4"), ("terminated", "u1"), ("truncated", "u1"),
+                          ("solved", "u1"), ("pad", "u1"), ("memory", "<i4", 256), ("ex_in", "<i4", 8), ("ex_in_after", "<i4", 8),
+                          ("ex_out", "<i4", 8), ("ex_out_after", "<i4", 8)])
+DEVICE_SUBLEQ = np.dtype([("step_count", "<i4"), ("task", "<i4"), ("reward", "<f4"), ("terminated", "u1"), ("truncated", "u1"),
+                          ("solved", "u1"), ("pad", "u1"), ("ex_in", "<u2", 8), ("ex_in_after", "<u2", 8), ("ex_out", "<u2", 8),
+                          ("ex_out_after", "<u2", 8), ("memory", "u1", 256)])
+assert ORACLE_SUBLEQ.itemsize == 1168 and DEVICE_SUBLEQ.itemsize == 336
+
+
+def subleq_oracle_to_device(blobs):
+    o = np.ascontiguousarray(blobs).view(ORACLE_SUBLEQ).reshape(blobs.shape[:-1])
+    d = np.zeros(o.shape, DEVICE_SUBLEQ)
+    for k in DEVICE_SUBLEQ.names:
+        d[k] = o[k]
+    return d.view(np.uint8).reshape(*o.shape, 336)
+
+
+def subleq_device_to_oracle(blobs, W):
+    d = np.ascontiguousarray(blobs).view(DEVICE_SUBLEQ).reshape(blobs.shape[:-1])
+    o = np.zeros(d.shape, ORACLE_SUBLEQ)
+    for k in DEVICE_SUBLEQ.names:
+        o[k] = d[k]
+    o["memory"][..., W:] = 0
+    return o.view(np.uint8).reshape(*d.shape, 1168)

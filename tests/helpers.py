@@ -37,28 +37,9 @@ def random_states_deepsea(G, B, seed=0):
     return blob
 
 
-# ---- Subleq state blobs: oracle layout (int32 memory[256], int32 io) <-> device layout (include/eaz.h eaz_subleq_state) ----
-ORACLE_SUBLEQ = np.dtype([("step_count", "<i4"), ("task", "<i4"), ("reward", "<f4"), ("terminated", "u1"), ("truncated", "u1"),
-                          ("solved", "u1"), ("pad", "u1"), ("memory", "<i4", 256), ("ex_in", "<i4", 8), ("ex_in_after", "<i4", 8),
-                          ("ex_out", "<i4", 8), ("ex_out_after", "<i4", 8)])
-DEVICE_SUBLEQ = np.dtype([("step_count", "<i4"), ("task", "<i4"), ("reward", "<f4"), ("terminated", "u1"), ("truncated", "u1"),
-                          ("solved", "u1"), ("pad", "u1"), ("ex_in", "<u2", 8), ("ex_in_after", "<u2", 8), ("ex_out", "<u2", 8),
-                          ("ex_out_after", "<u2", 8), ("memory", "u1", 256)])
-assert ORACLE_SUBLEQ.itemsize == 1168 and DEVICE_SUBLEQ.itemsize == 336
+# ---- Subleq state blobs: oracle layout (int32 memory[256], int32 io) <-> device layout (include/eaz.h eaz_subleq_state): oracle/eaz_oracle.py ----
+import os as _os
+import sys as _sys
 
-
-def subleq_oracle_to_device(blobs):
-    o = np.ascontiguousarray(blobs).view(ORACLE_SUBLEQ).reshape(blobs.shape[:-1])
-    d = np.zeros(o.shape, DEVICE_SUBLEQ)
-    for k in DEVICE_SUBLEQ.names:
-        d[k] = o[k]
-    return d.view(np.uint8).reshape(*o.shape, 336)
-
-
-def subleq_device_to_oracle(blobs, W):
-    d = np.ascontiguousarray(blobs).view(DEVICE_SUBLEQ).reshape(blobs.shape[:-1])
-    o = np.zeros(d.shape, ORACLE_SUBLEQ)
-    for k in DEVICE_SUBLEQ.names:
-        o[k] = d[k]
-    o["memory"][..., W:] = 0
-    return o.view(np.uint8).reshape(*d.shape, 1168)
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "oracle"))
+from eaz_oracle import DEVICE_SUBLEQ, ORACLE_SUBLEQ, subleq_device_to_oracle, subleq_oracle_to_device  # noqa: E402,F401

@@ -115,3 +115,15 @@ def test_subleq16_test_vector_table_matches_the_oracle_generator(eaz, oracle):
             b = np.zeros(8, np.uint16)
             assert lib.eaz_subleq16_test_vectors(task, c, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)) == 0
             assert np.array_equal(a.astype(np.int32), tin[c]) and np.array_equal(b.astype(np.int32), tout[c]), (task, c)
+    # the run-time generator the per-lane kernel evaluates for the other word sizes (csrc/envs.hpp subleq_test_case, compiled for the host too):
+    # at 16 it must agree with the table, and at every other size with the oracle
+    for W in (16, 17, 32, 100, 256):
+        for task in range(0, 16):
+            tin = np.zeros((3, 8), np.int32)
+            tout = np.zeros((3, 8), np.int32)
+            oracle.lib().eazo_subleq_test_cases(task, W, tin.ctypes.data, tout.ctypes.data)
+            for c in range(3):
+                a = np.zeros(8, np.uint16)
+                b = np.zeros(8, np.uint16)
+                assert lib.eaz_subleq_test_vectors(W, task, c, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)) == 0
+                assert np.array_equal(a.astype(np.int32), tin[c]) and np.array_equal(b.astype(np.int32), tout[c]), (W, task, c)

@@ -10,4 +10,4 @@ for c in MfmaUtil SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT
   DIRS="$DIRS $OUT/${TAG}_${WL}_sq_$c"
   echo "pass $c done"
 done
-python3 $R/tools/pmc_summary.py $OUT/${TAG}_${WL}_pmc_sq.json "$WL" $DIRS | grep -A12 "search_kernel\|search_persist" | head -40
+python3 $R/tools/pmc_summary.py $OUT/${TAG}_${WL}_pmc_sq.json "$WL" $DIRS | grep -A12 "search_kernel\|selfplay_kernel\|search_persist" | head -40

@@ -8,4 +8,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_${WL}_pmc_$c -- python3 $R/bench.py --workload $WL --steps 1 --warmup 1 --no-cpu-baseline --no-extra > $OUT/${TAG}_${WL}_pmc_$c.log 2>&1
   echo "pass $c done"
 done
-python3 $R/tools/pmc_summary.py $OUT/${TAG}_${WL}_pmc_traffic.json "$DESC" $OUT/${TAG}_${WL}_pmc_FETCH_SIZE $OUT/${TAG}_${WL}_pmc_WRITE_SIZE | grep -i "search_kernel\|resnet_forward" | cut -c1-300
+python3 $R/tools/pmc_summary.py $OUT/${TAG}_${WL}_pmc_traffic.json "$DESC" $OUT/${TAG}_${WL}_pmc_FETCH_SIZE $OUT/${TAG}_${WL}_pmc_WRITE_SIZE | grep -i "search_kernel\|selfplay_kernel\|resnet_forward" | cut -c1-300

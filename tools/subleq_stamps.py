@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Phase breakdown of subleq16_search_kernel at C3 from the diagnostic build (make -C e-alphazero_amd/csrc diag): s_memtime stamps of
-simulation S/2, lane 0 of each of the four waves of every workgroup."""
+"""Phase breakdown of subleq16_search_kernel (one launch per SEARCH: EAZ_TUNE_PERSIST = 2, the round-2 production path; round 3's is
+subleq16_selfplay_kernel, tools/sqp_stamps.py) at C3 from the diagnostic build (make -C e-alphazero_amd/csrc diag): s_memtime stamps of
+simulation S/2, lane 0 of each of the four waves of every workgroup.  A stamp slot that was never written stays 0: differences are taken
+only between slots that were both written (a wave that claimed no second environment has no stamp for it), never against a zero."""
 import ctypes as C
 import os
 import sys
@@ -21,6 +23,7 @@ in_dim, hash_off = rows * cols, W * cols
 params = eaz.params.init_fc_params(in_dim, 256, W, seed=0)
 env = engine.EnvHandle.subleq(W, (1,), True, device=0)
 net = engine.FCNet(env.ctx, in_dim, 256, W, params, eaz.params.init_hash_state(fill=0.5), hash_off=hash_off, hash_len=in_dim - hash_off)
+engine.tune(persist=2)
 search = engine.Search(env, net, B, S, discount=0.97)
 states = env.init(B, key=0)
 search.selfplay(states, 6, key=0, use_graph=False)   # mid-episode states
@@ -44,7 +47,19 @@ st = st[st[:, 0, 0] > 0]
 
 
 def seg(name, d):
-    print(f"   {name:58s} median {np.median(d):8.0f}   p10 {np.percentile(d, 10):8.0f}   p90 {np.percentile(d, 90):8.0f} cycles")
+    d = np.asarray(d).reshape(-1)
+    if d.size == 0:
+        print(f"   {name:58s} (no wave wrote both stamps)")
+        return
+    assert (d >= 0).all(), f"{name}: negative interval -- a stamp pair was read out of order"
+    print(f"   {name:58s} median {np.median(d):8.0f}   p10 {np.percentile(d, 10):8.0f}   p90 {np.percentile(d, 90):8.0f} cycles   ({d.size} samples)")
+
+
+def span(a, b):
+    """b - a where both stamps were written by THIS launch (the buffer is not cleared between launches: a slot the wave did not reach
+    this time holds an older, i.e. smaller, stamp or 0)"""
+    ok = (a > 0) & (b > a)
+    return (b - a)[ok]
 
 
 w0 = st[:, 0, :]
@@ -87,11 +102,18 @@ lib.eaz_diag_persist_stamps2(search.h, eb.ctypes.data)
 eb = eb.reshape(256, 8, 4).astype(np.int64)
 eb = eb[eb[:, 0, 0] > 0]
 print("interpreter phase, all 8 waves of every workgroup:")
-seg("first environment of a wave", (eb[:, :, 1] - eb[:, :, 0]).reshape(-1))
-seg("second environment of a wave", (eb[:, :, 2] - eb[:, :, 1]).reshape(-1))
-seg("slowest wave of the workgroup (both)", (eb[:, :, 2] - eb[:, :, 0]).max(axis=1))
-seg("fastest wave of the workgroup (both)", (eb[:, :, 2] - eb[:, :, 0]).min(axis=1))
-seg("slowest single environment of the workgroup", np.maximum(eb[:, :, 1] - eb[:, :, 0], eb[:, :, 2] - eb[:, :, 1]).max(axis=1))
+# slots: 0 = phase start, 1 / 2 / 3 = after the wave's first / second / third-or-later environment; a wave that got no further environment
+# from the work queue leaves the later slots at 0
+e0 = eb[:, :, 0]
+last = np.where(eb[:, :, 3] > e0, eb[:, :, 3], np.where(eb[:, :, 2] > e0, eb[:, :, 2], eb[:, :, 1]))   # the wave's last stamp of this launch
+seg("first environment of a wave", span(eb[:, :, 0], eb[:, :, 1]))
+seg("second environment of a wave (waves that claimed one)", span(eb[:, :, 1], eb[:, :, 2]))
+busy = np.where((e0 > 0) & (last > e0), last - e0, 0)
+seg("slowest wave of the workgroup (all its environments)", busy.max(axis=1))
+seg("fastest wave of the workgroup (all its environments)", np.where(busy > 0, busy, np.iinfo(np.int64).max).min(axis=1))
+first = np.where(eb[:, :, 1] > e0, eb[:, :, 1] - e0, 0)
+second = np.where(eb[:, :, 2] > eb[:, :, 1], eb[:, :, 2] - eb[:, :, 1], 0)
+seg("slowest single environment of the workgroup (first two per wave)", np.maximum(first, second).max(axis=1))
 
 # fc16p_body's own stamps (net_fc.hpp EAZ_STAMP), thread 0 of each workgroup: its last call = the head that runs alone in round 2
 lib.eaz_diag_fc_stamps.argtypes = [C.c_void_p]
