@@ -855,14 +855,13 @@ static int make_shard(eaz_search* p, int b0, int Bs, eaz_search** out) {
     c->B = Bs;
     c->side = c->main = nullptr;
     c->ev_fork = c->ev_join = c->ev_in = c->ev_out = c->ev_shard_fork = c->ev_shard_join = nullptr;
-    // its own stream, and its own side stream + events for the novelty lookup beside the forward (infer_launch): a second level of fork / join
-    // inside the captured step.  Round 2 ran the lookup in line after a host crash in hipGraphInstantiate during development; the sequence
-    // itself is legal and works on ROCm 7.2 (tools/graph_nested_fork.hip: every forked stream joined before hipStreamEndCapture, no captured
-    // event waited on outside the capture), so the crash belonged to that uncommitted state of the code, not to the runtime.
+    // No side stream of its own: the novelty lookup of a sub-batch runs in line on the sub-batch's stream (the sub-batches overlap each other
+    // instead).  A side stream per sub-batch would be a SECOND level of fork / join inside the captured step (capturing stream -> sub-batch
+    // stream -> lookup stream and back), and hipStreamEndCapture of the HIP runtime this library runs on -- PyTorch's bundled
+    // libamdhip64.so 7.0.2, the one runtime of the process -- recurses without bound in hip::Stream::EndCapture() on
+    // such a capture and overflows the stack (the round-2 host crash; rocgdb backtrace and the 60-line reproducer: DESIGN.md 4.3,
+    // tools/graph_nested_fork.hip -- two sub-batches x one simulation are enough; /opt/rocm 7.2.0's runtime handles the same sequence).
     HIP_OK(hipStreamCreateWithFlags(&c->main, hipStreamNonBlocking));
-    HIP_OK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-    HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    HIP_OK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     const long N = p->N, A = p->A, SB = p->tree.state_bytes, Sn = p->S, OD = p->env->dev.obs_dim;
     TreeDev& t = c->tree;
     t.B = Bs;

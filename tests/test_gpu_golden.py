@@ -239,6 +239,46 @@ def test_subleq_word_sizes_that_are_not_multiples_of_four(oracle, eaz, torch, W,
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
 
 
+@pytest.mark.parametrize("case", [
+    dict(B=1, S=8, T=3),                                                        # a single environment: 15 of the workgroup's trees mirror it
+    dict(B=17, S=80, T=2),                                                      # the largest trees whose workgroup set fits into LDS (81 nodes)
+    dict(B=17, S=81, T=2),                                                      # one more: the call falls back to the per-search kernels
+    dict(B=33, S=16, T=15, rescale=False, gumbel_scale=0.5, max_considered=4),  # qtransform / root-selection options
+    dict(B=20, S=12, T=14, two_player=True),                                    # negated discount (context.py:143) in the node records
+    dict(B=24, S=16, T=15, reward_fn="lowest_bytes", explicit_gumbel=True, tasks=(1, 5)),
+], ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items() if k not in ("tasks",)))
+def test_subleq16_one_launch_selfplay_edges(oracle, eaz, torch, case, kernel_variant):
+    """Edges of subleq16_selfplay_kernel's eligibility and options (the other variants run the same inputs through their own kernels): batch
+    sizes that leave mirror trees in a workgroup, the LDS limit on the tree size and the first size beyond it, the search options self-play
+    exposes, the two-player discount, the lowest_bytes reward with a caller's root noise -- all across at least one episode boundary
+    where T allows."""
+    from e_alphazero_amd import engine
+
+    if kernel_variant not in ("persist", "persist-step", "auto-fused"):
+        pytest.skip("one-launch variants + one per-simulation variant")
+    c = dict(case)
+    W, B, S, T = 16, c.pop("B"), c.pop("S"), c.pop("T")
+    tasks, reward_fn, explicit = c.pop("tasks", (1,)), c.pop("reward_fn", "solved_or_not"), c.pop("explicit_gumbel", False)
+    dims, params, state = subleq_setup(eaz, W, seed=B + S, fill=0.4)
+    env = engine.EnvHandle.subleq(W, tasks, True, device=0, reward_fn=reward_fn)
+    net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
+    oenv = oracle.OracleEnv.subleq(W, tasks, True, reward_fn=reward_fn)
+    onet = oracle.OracleNet(dims["in_dim"], 256, W, eaz.params.fc_weight_list(params), hash_off=dims["hash_off"],
+                            hash_len=dims["hash_len"], bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+    search = engine.Search(env, net, B, S, discount=0.97, two_players_game=c.get("two_player", False), rescale_values=c.get("rescale", True),
+                           gumbel_scale=c.get("gumbel_scale", 1.0), max_num_considered_actions=c.get("max_considered", 16))
+    st = env.init(B, key=19)
+    ost = oenv.init(B, key=(19, 0))
+    gum = oracle.gumbel((8, 1), T * B * W).reshape(T, B, W) if explicit else None
+    out = search.selfplay(st, T, key=73, gumbel=None if gum is None else torch.from_numpy(gum).cuda())
+    ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(73, 0), discount=0.97, gumbel=gum, **c)
+    assert np.array_equal(out["action"].cpu().numpy(), ref["action"])
+    assert np.array_equal(subleq_device_to_oracle(out["state"].cpu().numpy(), W), ref["state"])
+    assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost)
+    for k in ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction", "q_values_epistemic_variance"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
+
+
 def test_empty_batches_are_no_ops(eaz, torch):
     """B = 0 through the C ABI: every batched entry point accepts an empty batch (null data pointers included)."""
     from e_alphazero_amd import engine
