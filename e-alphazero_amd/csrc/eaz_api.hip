@@ -923,6 +923,10 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     HIP_OK(hipMemset(t.embeddings, 0, bn * t.state_bytes));
     DALLOC(t.sim_parent, B); DALLOC(t.sim_action, B); DALLOC(t.sim_next, B);
     DALLOC(t.path_node, static_cast<size_t>(B) * s->S); DALLOC(t.path_action, static_cast<size_t>(B) * s->S); DALLOC(t.path_len, B);
+    // read by mirror groups before their owner has written them (tree.hpp): never leftovers of a freed allocation
+    HIP_OK(hipMemset(t.sim_parent, 0, sizeof(int32_t) * B)); HIP_OK(hipMemset(t.sim_action, 0, sizeof(int32_t) * B));
+    HIP_OK(hipMemset(t.sim_next, 0, sizeof(int32_t) * B)); HIP_OK(hipMemset(t.path_len, 0, sizeof(int32_t) * B));
+    HIP_OK(hipMemset(t.path_node, 0, sizeof(int32_t) * B * s->S)); HIP_OK(hipMemset(t.path_action, 0, sizeof(int32_t) * B * s->S));
     // sequential-halving table
     const int mc = opts->max_num_considered_actions;
     std::vector<int32_t> table(static_cast<size_t>(mc + 1) * s->S);

@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
         if (wave < 4) {
             SqArgsPtr a = sq_args();
             const int pt = phase_tid(), sub = pt & 15;
-            const TreeSel sel = tree_step_body<16, 1>(a->t, sim, mode, b0 + (pt >> 4), sub);
+            const TreeSel sel = tree_step_body<16, 1>(a->t, sim, mode, b0 + (pt >> 4), sub, b0);
             EAZ_QSTAMP(1);
             if (sub == 0) { sel_node[pt >> 4] = sel.node; sel_action[pt >> 4] = sel.action; sel_dst[pt >> 4] = sel.dst; }
         }
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
     if (expand_last && wave < 4) {
         SqArgsPtr a = sq_args();
         const int pt = phase_tid();
-        tree_step_body<16, 1>(a->t, sim0 + n_sims, kTreeExpand, b0 + (pt >> 4), pt & 15);
+        tree_step_body<16, 1>(a->t, sim0 + n_sims, kTreeExpand, b0 + (pt >> 4), pt & 15, b0);
     }
 }
 

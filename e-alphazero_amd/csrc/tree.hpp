@@ -362,11 +362,14 @@ struct TreeSel {
 
 // The body of tree_step_kernel for tree `b`, lane `sub` of its LPT * spread lanes (also called by the fused tree + leaf kernel of
 // search_kernels.hpp, one wavefront per tree).
+// `mirror`: the tree a group beyond the batch walks (without storing): tree 0 in the per-simulation launches, where every group of the grid is
+// in the same simulation; the one-launch search passes a tree of its OWN workgroup (another workgroup's tree would be read at whatever
+// simulation that workgroup happens to be in).
 template <int LPT, int APL>
-__device__ __forceinline__ TreeSel tree_step_body(const TreeDev& t, int sim, int mode, int b, int sub) {
+__device__ __forceinline__ TreeSel tree_step_body(const TreeDev& t, int sim, int mode, int b, int sub, int mirror = 0) {
     TreeSel sel{0, 0, 0};
     const bool live = b < t.B && sub < LPT;  // mirror / dead groups keep executing (shuffles need every lane) without storing
-    const Group<LPT, APL> g = make_group<LPT, APL>(b < t.B ? b : 0, sub % LPT, t.A);
+    const Group<LPT, APL> g = make_group<LPT, APL>(b < t.B ? b : mirror, sub % LPT, t.A);
     const int N = t.N, A = t.A;
     const long nb = static_cast<long>(g.b) * N;
     const float beta = t.beta[g.b];
@@ -380,7 +383,13 @@ __device__ __forceinline__ TreeSel tree_step_body(const TreeDev& t, int sim, int
         constexpr int kChunk = 8;
         const long pb = static_cast<long>(g.b) * t.S;
         const int parent = t.sim_parent[g.b], action = t.sim_action[g.b], nxt = t.sim_next[g.b];
-        const int D = t.path_len[g.b];
+        // A group beyond the batch mirrors another tree without storing.  Round 2's one-launch Subleq search mirrored tree 0, which belongs to
+        // ANOTHER workgroup that may not have finished its first select yet: the mirror then read the array's initial content, and a leftover
+        // 0x7F...... of a freed allocation turned the loop below into 2^28 chunks -- a 257 s launch with correct results (round 3: rocprofv3
+        // trace of the GPU suite).  Now: mirrors stay inside their workgroup, the arrays are zero-filled at creation, and the
+        // depth is clamped.
+        int D = t.path_len[g.b];
+        D = D < 0 ? 0 : (D > t.S ? t.S : D);
         int p0n[kChunk], p0a[kChunk];
 #pragma unroll
         for (int j = 0; j < kChunk; ++j) {
