@@ -1031,6 +1031,8 @@ extern "C" int eaz_search_destroy(eaz_search* s) {
 }
 
 static int tree_grid(const eaz_search* s) { return cdiv(static_cast<long>(s->B) * s->lpt, 256); }
+static bool sqp_eligible(const eaz_search* s);
+static int sqp_launch(eaz_search* s, const PersistSelfplay& sp, hipStream_t st);
 
 extern "C" int eaz_search_begin(eaz_search* s, const float* d_prior_logits, const float* d_value, const float* d_value_var,
                                 const void* d_root_states, const float* d_beta, const uint8_t* d_invalid, const float* d_gumbel,
@@ -1041,7 +1043,8 @@ extern "C" int eaz_search_begin(eaz_search* s, const float* d_prior_logits, cons
         ProfScope ps(s, EAZ_K_MISC, st);
         // The persistent kernel rewrites every tree array, so its searches skip the 24 MB clear; a caller that steps the search
         // simulation by simulation instead gets the (root-preserving) clear from ensure_cleared() before its first tree kernel.
-        s->clear_pending = s->persist_ok && g_persist;
+        // (likewise the Subleq-16 one-launch kernel, search_subleq_persist.hpp)
+        s->clear_pending = (s->persist_ok && g_persist) || (g_persist == 1 && sqp_eligible(s));
         if (!s->clear_pending) {
             const long bna = static_cast<long>(s->B) * s->N * s->A;
             tree_clear_kernel<<<cdiv(bna, 256) < 4096 ? cdiv(bna, 256) : 4096, 256, 0, st>>>(s->tree, 0);
@@ -1291,8 +1294,21 @@ extern "C" int eaz_search_run(eaz_search* s, void* stream) {
         s->sims_done = s->S;
         return 0;
     }
+    if (g_persist == 1 && s->clear_pending && s->sims_done == 0 && s->pending_expand < 0 && sqp_eligible(s)) {
+        // Subleq-16: all S simulations in one launch on LDS node-record trees, the whole tree written back at the end
+        // (search_subleq_persist.hpp, search-only mode)
+        ProfScope ps(s, EAZ_K_SEARCH, S(stream));
+        PersistSelfplay sp;
+        std::memset(&sp, 0, sizeof sp);
+        int rc = sqp_launch(s, sp, S(stream));
+        if (rc) return rc;
+        s->clear_pending = 0;
+        s->sims_done = s->S;
+        return 0;
+    }
     if (g_persist && s->sims_done == 0 && s->pending_expand < 0 && sq16_persist_eligible(s)) {
-        // Subleq-16: all S simulations in one launch, 16 trees per workgroup (search_subleq.hpp)
+        // Subleq-16 with global-memory trees (EAZ_TUNE_PERSIST = 2, or trees beyond the LDS limit): all S simulations in one launch,
+        // 16 trees per workgroup (search_subleq.hpp)
         hipStream_t st = S(stream);
         int rc = ensure_cleared(s, st);
         if (rc) return rc;

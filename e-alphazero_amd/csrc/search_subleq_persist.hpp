@@ -1,4 +1,6 @@
-// search_subleq_persist.hpp -- subleq16_selfplay_kernel: a whole selfplay() call for Subleq word_size 16 in ONE launch (C3 production path).
+// search_subleq_persist.hpp -- subleq16_selfplay_kernel: a whole selfplay() call for Subleq word_size 16 in ONE launch (C3 production path);
+// with PersistSelfplay::on == 0 the same kernel is ONE search (eaz_search_run: the emctx call shape, reanalyze, evaluate): root from, whole
+// tree back to the mctx structure-of-arrays layout of tree.hpp.
 //
 // Reference: step_fn of src/selfplay.py:86-143 (root inference :89-91, root preparation :92-106, emctx policy :107-117 [EXT] = SURVEY.md
 // A.2-A.7, action choice :118-134, auto-reset env.step :135, SelfplayOutput :136-143), with the recurrent fn of src/context.py:117-155
@@ -70,6 +72,9 @@ struct QpMisc {
     int real_action[kQpTrees];
     int env_next;
     int pad[3];
+    float beta[kQpTrees];               // selfplay.py:105 beta * linspace(0, 1, B)[b]; search only: the caller's per-tree beta
+    int nc[kQpTrees];                   // min(valid root actions, max_num_considered_actions): row of the considered-visit table
+    uint8_t invalid[kQpTrees][kQpA];    // root_invalid_actions (self-play: none, subleq.py:626)
     float o_value[kQpTrees], o_ube[kQpTrees];
     float b3[20];                       // output biases: value, ube, the 16 policy logits
     float b12[3][2][kFcH];              // hidden-layer biases of the three heads (layer 1, layer 2)
@@ -383,14 +388,13 @@ __device__ __forceinline__ QpArgsPtr qp_args() {
 
 __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16SelfplayArgs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    int N, S, B, n_steps, nc, max_depth;
-    float sbeta;
+    int N, S, B, n_steps, max_depth;
+    bool search_only;
     float* logits_base;
     {
         EAZ_QP_ARGS;
-        N = t.N; S = t.S; B = t.B; n_steps = a.sp.T; max_depth = t.max_depth;
-        nc = kQpA < t.max_considered ? kQpA : t.max_considered;  // every action is legal (subleq.py:626): 16 valid root actions
-        sbeta = a.sp.sbeta;
+        search_only = a.sp.on == 0;
+        N = t.N; S = t.S; B = t.B; n_steps = search_only ? 1 : a.sp.T; max_depth = t.max_depth;
         logits_base = a.logits;
     }
     const QpLds L = qp_lds(N, S);
@@ -420,7 +424,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
     const int gb = tree_live ? b0 + ti : B - 1;                                                                      \
     float* LG = logits_base + static_cast<long>(b0 + ti) * N * (2 * kQpA);                                           \
     const Group<4, 4> g = make_group<4, 4>(gb, q, kQpA);                                                             \
-    const float beta = sbeta * (B > 1 ? static_cast<float>(gb) / static_cast<float>(B - 1) : 0.0f); /* selfplay.py:105 */ \
+    const float beta = M.beta[ti];                                                                                   \
     const bool need_var = beta != 0.0f;                                                                              \
     (void)ST; (void)P; (void)LG; (void)slot; (void)need_var; (void)tree_live
     // forward lanes: lane (r, kq) of wave w owns hidden columns 64 w + 4 r .. + 3
@@ -451,7 +455,9 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
         // the current states of two of the workgroup's environments: 336-byte blob -> compact root state + the observation's row-words
         const int j = 2 * wave + k;
         const int bj = b0 + j < B ? b0 + j : B - 1;
-        const char* sp = a.sp.states + static_cast<long>(bj) * sizeof(eaz_subleq_state);
+        // self-play: the caller's state batch; search only: the root embedding tree_root_kernel wrote
+        const char* sp = search_only ? t.embeddings + static_cast<long>(bj) * N * sizeof(eaz_subleq_state)
+                                     : a.sp.states + static_cast<long>(bj) * sizeof(eaz_subleq_state);
         const uint4 hv = *reinterpret_cast<const uint4*>(sp);
         const uint4 r0 = *reinterpret_cast<const uint4*>(sp + 16), r1 = *reinterpret_cast<const uint4*>(sp + 32);
         const uint4 r2 = *reinterpret_cast<const uint4*>(sp + 48), r3 = *reinterpret_cast<const uint4*>(sp + 64);
@@ -471,7 +477,56 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
         }
         qp_emit_obs(M.words[j], M.xbits[j], mem, exin, inaf, exout, outaf, lane);
     }
+    {
+        // per-tree scalars of the whole launch; search only: the root the caller prepared (eaz_search_begin -> tree_root_kernel: masked prior
+        // logits, value, variance, beta, scaled Gumbel noise, invalid actions) into an empty tree (mctx instantiate_tree_from_root, A.3)
+        EAZ_QP_ARGS;
+        const int pt_ = phase_tid();
+        const int ti = pt_ >> 5, tl = pt_ & 31;
+        const int gb = b0 + ti < B ? b0 + ti : B - 1;
+        uint32_t* T = trees + ti * L.tstride;
+        if (!search_only) {
+            if (tl == 0) {
+                M.beta[ti] = a.sp.sbeta * (B > 1 ? static_cast<float>(gb) / static_cast<float>(B - 1) : 0.0f);  // selfplay.py:105
+                M.nc[ti] = kQpA < t.max_considered ? kQpA : t.max_considered;  // every action is legal (subleq.py:626)
+            }
+            if (tl < 16) M.invalid[ti][tl] = 0;
+        } else {
+            for (int n = tl; n < N; n += 32) {
+                uint32_t* R = T + n * QN_WORDS;
+#pragma unroll
+                for (int w = 0; w < QN_WORDS; ++w) R[w] = w >= QN_SEL ? 0xFFFFFFFFu : 0u;
+            }
+            ps_wave_sync();
+            const long nb = static_cast<long>(gb) * N;
+            float lgv = -kInf;
+            int inv = 1;
+            if (tl < 16) {
+                lgv = t.children_prior_logits[nb * kQpA + tl];
+                inv = t.root_invalid[static_cast<long>(gb) * kQpA + tl] != 0;
+                M.gumbel[ti][tl] = t.root_gumbel[static_cast<long>(gb) * kQpA + tl];
+                M.invalid[ti][tl] = static_cast<uint8_t>(inv);
+            }
+            const int nvalid = gsumi<16>(tl < 16 ? 1 - inv : 0);
+            const float pm = gmax<16>(lgv);
+            const float pe = tl < 16 ? det_exp(lgv - pm) : 0.0f;
+            const float ps = gsum<16>(pe);
+            if (tl < 16) { M.root_logits[ti][tl] = lgv; M.root_probs[ti][tl] = pe / ps; }
+            if (tl == 0) {
+                M.beta[ti] = t.beta[gb];
+                M.nc[ti] = nvalid < t.max_considered ? nvalid : t.max_considered;
+                T[QN_RAW_VALUE] = f2u(t.raw_values[nb]); T[QN_NODE_VALUE] = f2u(t.node_values[nb]);
+                T[QN_RAW_VAR] = f2u(t.raw_var[nb]); T[QN_NODE_VAR] = f2u(t.node_var[nb]);
+                T[QN_META] = static_cast<uint32_t>(t.node_visits[nb] & 0xFF) | (0xFFu << 8);
+                M.D[ti] = 0; M.parent[ti] = 0; M.action[ti] = 0; M.dst[ti] = 0;
+            }
+        }
+    }
     __syncthreads();
+    if (search_only) {
+        EAZ_QP_TREE_LANES;
+        if (tl < QS_WORDS) ST[tl] = M.root_state[ti][tl];  // embedding of node 0
+    }
 
     // output `slot` (0 value, 1 ube, 2.. policy logits) of row `row` from the four quarter sums: ((c0 + c1) + (c2 + c3)) + b (o_linear_parts)
     auto head_out = [&](int row, int slot) {
@@ -483,7 +538,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
     floatx4 pre_lg = floatx4{0.0f, 0.0f, 0.0f, 0.0f}, pre_pr = floatx4{0.0f, 0.0f, 0.0f, 0.0f};  // prefetched logits / probabilities of path level `slot`
     int pre_node = -1;
 #pragma unroll 1
-    for (int it = 0; it <= n_iter; ++it) {
+    for (int it = search_only ? 1 : 0; it <= n_iter; ++it) {  // search only: no root forward, the caller evaluated the root
         const int step = it / (S + 1), s = it - step * (S + 1);  // s = 0: root of real step `step`; s >= 1: simulation s - 1
         int env_mode = 0;
         Key env_key{0u, 0u};
@@ -571,6 +626,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             ps_wave_sync();
             EAZ_QPSTAMP(1);
         }
+        if (search_only && it == n_iter) break;  // the last expand + backward is done: the tree goes back to the caller's arrays below
         if (s == 0 && it > 0) {
             // ---- the search of real step `step - 1` is complete: gumbel_muzero_policy tail (A.2, tree_finish_kernel), epistemic_summary
             // (A.7, tree_summary_kernel), action choice (selfplay.py:118-134), SelfplayOutput[t] except the state ----
@@ -582,13 +638,14 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 NodeRows<4> rw;
                 const uint32_t cw = T[QN_CHILD + q];
                 float gum[4];
-                const uint8_t inv[4] = {0, 0, 0, 0};
+                uint8_t inv[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int c = (cw >> (8 * j)) & 0xFFu;
                     const bool has = c != 0xFF;
                     const uint32_t* Cn = T + (has ? c : 0) * QN_WORDS;
                     const uint32_t meta = Cn[QN_META];
+                    inv[j] = M.invalid[ti][4 * q + j];
                     rw.logits[j] = M.root_logits[ti][4 * q + j];
                     rw.values[j] = has ? u2f(Cn[QN_NODE_VALUE]) : 0.0f;
                     rw.rewards[j] = has ? u2f(Cn[QN_REWARD]) : 0.0f;
@@ -616,7 +673,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 for (int j = 0; j < 4; ++j) x[j] = rw.logits[j] + cq[j];
                 const float mx = g.vmax(x);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) x[j] = x[j] - mx;  // no invalid actions
+                for (int j = 0; j < 4; ++j) x[j] = inv[j] ? kF32Min : x[j] - mx;
                 g.softmax(x, aw);
                 const float ftot = static_cast<float>(totN);
                 float qvar[4], vprob[4];
@@ -703,11 +760,11 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 if (node == 0) {
                     // gumbel_muzero_root_action_selection (A.4)
                     float gum[4];
-                    const uint8_t inv[4] = {0, 0, 0, 0};
+                    uint8_t inv[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) gum[j] = M.gumbel[ti][4 * q + j];
+                    for (int j = 0; j < 4; ++j) { gum[j] = M.gumbel[ti][4 * q + j]; inv[j] = M.invalid[ti][4 * q + j]; }
                     const int simidx = sumN > S - 1 ? S - 1 : sumN;
-                    const float cvis = static_cast<float>(t.table[static_cast<long>(nc) * S + simidx]);
+                    const float cvis = static_cast<float>(t.table[static_cast<long>(M.nc[ti]) * S + simidx]);
                     act = root_pick<4, 4>(t, g, rw, cq, cvis, gum, inv);
                 } else {
                     // gumbel_muzero_interior_action_selection (A.4)
@@ -965,6 +1022,85 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             }
             if (tl < QS_WORDS) ST[tl] = M.root_state[ti][tl];
             ps_wave_sync();
+        }
+    }
+    if (!search_only) return;  // self-play never reads the tree arrays
+    // ---------------------------------------------------------------- search only: the trees back to the mctx arrays -----------------------
+    // Every field of every node (the caller's eaz_search_begin skipped the clear: unexpanded nodes get mctx's initial values, ints -1 / 0,
+    // floats 0); children_X[n, a] = the child's node field, the edge's reward / discount from the child's record (header of this file).
+    {
+        EAZ_QP_ARGS;
+        EAZ_QP_TREE_LANES;
+        ps_wave_sync();
+        if (tree_live) {
+            const long nb = static_cast<long>(gb) * N;
+            const float disc_live = t.two_player ? (1.0f * t.discount) * -1.0f : 1.0f * t.discount;
+            for (int n = tl; n < N; n += 32) {
+                const uint32_t* R = T + n * QN_WORDS;
+                const uint32_t meta = R[QN_META];
+                const int visits = static_cast<int>(meta & 0xFFu);
+                t.raw_values[nb + n] = u2f(R[QN_RAW_VALUE]); t.node_values[nb + n] = u2f(R[QN_NODE_VALUE]);
+                t.raw_var[nb + n] = u2f(R[QN_RAW_VAR]); t.node_var[nb + n] = u2f(R[QN_NODE_VAR]);
+                t.node_visits[nb + n] = visits;
+                const bool linked = n > 0 && visits > 0;
+                t.parents[nb + n] = linked ? static_cast<int>((meta >> 8) & 0xFFu) : -1;
+                t.action_from_parent[nb + n] = linked ? static_cast<int>((meta >> 16) & 0xFu) : -1;
+            }
+            for (int i = tl; i < N * kQpA; i += 32) {
+                const int n = i >> 4, act = i & 15;
+                const uint32_t* R = T + n * QN_WORDS;
+                const int c = (R[QN_CHILD + (act >> 2)] >> (8 * (act & 3))) & 0xFFu;
+                const bool has = c != 0xFF;
+                const uint32_t* Cn = T + (has ? c : 0) * QN_WORDS;
+                const uint32_t cm = Cn[QN_META];
+                const long o = (nb + n) * kQpA + act;
+                t.children_index[o] = has ? c : -1;
+                t.children_visits[o] = has ? static_cast<int>(cm & 0xFFu) : 0;
+                t.children_values[o] = has ? u2f(Cn[QN_NODE_VALUE]) : 0.0f;
+                t.children_var[o] = has ? u2f(Cn[QN_NODE_VAR]) : 0.0f;
+                t.children_rewards[o] = has ? u2f(Cn[QN_REWARD]) : 0.0f;
+                t.children_discounts[o] = has ? ((cm >> 20) & 1u ? 0.0f : disc_live) : 0.0f;
+                t.children_reward_var[o] = 0.0f;
+                const bool expanded = (R[QN_META] & 0xFFu) != 0;
+                t.children_prior_logits[o] = n == 0 ? M.root_logits[ti][act] : (expanded ? LG[n * (2 * kQpA) + act] : 0.0f);
+            }
+            // embeddings of the expanded nodes: compact state -> the 336-byte blob of include/eaz.h (node 0 is the caller's)
+            for (int n = 1 + (tl >> 4); n < N; n += 2) {
+                const int l16 = tl & 15;
+                const uint32_t* R = T + n * QN_WORDS;
+                if ((R[QN_META] & 0xFFu) == 0) continue;
+                const uint32_t* sw = ST + n * QS_WORDS;
+                const unsigned long long mem = qp_u64(sw[QS_MEM], sw[QS_MEM + 1]), inaf = qp_u64(sw[QS_INAF], sw[QS_INAF + 1]);
+                const unsigned long long outaf = qp_u64(sw[QS_OUTAF], sw[QS_OUTAF + 1]);
+                const uint32_t hdr = sw[QS_HDR];
+                const int task = qp_hdr_task(hdr);
+                const int branch = task - 1 < 0 ? 0 : (task - 1 > 5 ? 5 : task - 1);
+                const bool exroot = ((hdr >> 11) & 1u) != 0;
+                const unsigned long long exin = exroot ? qp_u64(M.root_ex[ti][0], M.root_ex[ti][1]) : kSq16Cases.v[branch][0][0];
+                const unsigned long long exout = exroot ? qp_u64(M.root_ex[ti][2], M.root_ex[ti][3]) : kSq16Cases.v[branch][0][1];
+                char* blob = t.embeddings + (nb + n) * sizeof(eaz_subleq_state);
+                if (l16 == 0)
+                    *reinterpret_cast<uint4*>(blob) = make_uint4(hdr & 0xFFu, static_cast<uint32_t>(task), sw[QS_REWARD],
+                                                                 ((hdr >> 8) & 1u) | (((hdr >> 9) & 1u) << 8) | (((hdr >> 10) & 1u) << 16));
+                // rows: 32 uint16 = lane l16 writes elements 2 l16 and 2 l16 + 1
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int el = 2 * l16 + e, row = el >> 3, sh = 8 * (el & 7);
+                    const unsigned long long srcv = row == 0 ? exin : (row == 1 ? inaf : (row == 2 ? exout : outaf));
+                    reinterpret_cast<uint16_t*>(blob + 16)[el] = static_cast<uint16_t>((srcv >> sh) & 0xFFull);
+                }
+                uint4 cbytes = make_uint4(0u, 0u, 0u, 0u);
+                if (l16 == 0) {
+                    uint32_t w[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t n4 = static_cast<uint32_t>(mem >> (16 * i)) & 0xFFFFu;
+                        w[i] = (n4 & 0xFu) | ((n4 & 0xF0u) << 4) | ((n4 & 0xF00u) << 8) | ((n4 & 0xF000u) << 12);
+                    }
+                    cbytes = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                *reinterpret_cast<uint4*>(blob + 80 + 16 * l16) = cbytes;
+            }
         }
     }
 }

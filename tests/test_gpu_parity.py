@@ -216,6 +216,93 @@ def test_search_run_whole_tree(oracle, eaz, torch, G, B, S, beta_max, opts, mask
     print(f"run(): tree float fields bit-exact vs oracle: {exact}")
 
 
+@pytest.mark.parametrize("B,S,beta_max,opts,masked", [
+    (64, 16, 0.0, {}, False),
+    (37, 32, 1.0, {}, False),                                          # epistemic twin; 37 = 2 * 16 + 5: mirror trees in the last workgroup
+    (300, 64, 0.0, {}, False),                                         # C3's tree shape
+    (5, 80, 0.5, {}, False),                                           # the largest tree the LDS record set holds (one ragged workgroup)
+    (5, 81, 0.0, {}, False),                                           # first size beyond it: subleq16_search_kernel / per-simulation kernels
+    (40, 24, 0.0, dict(max_depth=4), False),                           # depth limit: re-expansion of existing nodes
+    (33, 24, 0.0, dict(max_depth=1), False),
+    (40, 40, 0.0, dict(rescale=False), True),                          # invalid root actions (incl. a row with every action invalid)
+    (40, 24, 0.5, dict(use_mixed=False, max_considered=1), True),
+    (40, 24, 0.0, dict(max_considered=5), True),
+    (17, 8, 0.0, dict(two_player=True), False),                        # negated discount (context.py:143)
+    (50, 24, 2.0, dict(bonus_after_rescale=True), False),
+    (50, 24, 1.0, dict(var_backup=1, max_depth=9), False),
+])
+def test_subleq16_search_run_whole_tree(oracle, eaz, torch, kernel_variant, B, S, beta_max, opts, masked):
+    """The emctx call shape on Subleq-16 (begin -> run -> finish, the path of evaluate / reanalyze / a caller's own loop): every tree
+    field, the state blobs of visited nodes, action, weights and summary against the oracle.  Under the default variant an eligible
+    search is ONE launch of subleq16_selfplay_kernel in its search-only mode (root read from, whole tree written back to the mctx
+    arrays) -- asserted through the launch counters; S = 81 and the other variants take their own kernels and must agree all the same."""
+    from e_alphazero_amd import engine
+    from helpers import subleq_setup, subleq_device_to_oracle
+
+    W = 16
+    dims, params, state = subleq_setup(eaz, W, seed=B + S, fill=0.4)
+    env = engine.EnvHandle.subleq(W, (1, 3), True, device=0)
+    net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
+    oenv = oracle.OracleEnv.subleq(W, (1, 3), True)
+    onet = oracle.OracleNet(dims["in_dim"], 256, W, eaz.params.fc_weight_list(params), hash_off=dims["hash_off"], hash_len=dims["hash_len"],
+                            bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+    # root states: a few random steps into the episodes, so that programs, step counts and reachable rewards differ across the batch
+    st = env.init(B, key=7)
+    rng = np.random.default_rng(B * 131 + S)
+    for t in range(5):
+        a = rng.integers(0, W, B).astype(np.int32)
+        a[rng.random(B) < 0.5] = 0 if t else W - 2
+        st = env.step(st, torch.from_numpy(a).cuda(), key=50 + t, autoreset=False)
+    blobs = subleq_device_to_oracle(st.cpu().numpy(), W)
+    ex, xp, v, u, _ = onet.forward(oenv.observe(blobs))
+    beta = (beta_max * np.linspace(0, 1, B)).astype(np.float32)
+    g = oracle.gumbel((61, 62), B * W).reshape(B, W)
+    invalid = None
+    if masked:
+        invalid = (rng.random((B, W)) < 0.4).astype(np.uint8)
+        invalid[0] = 1
+        invalid[1] = 1
+        invalid[1, 9] = 0
+    explore = beta_max > 0
+    logits = xp if explore else ex
+    okw = dict(discount=0.97, use_exploration_logits=explore, rescale=opts.get("rescale", True), use_mixed=opts.get("use_mixed", True),
+               max_considered=opts.get("max_considered", 16), max_depth=opts.get("max_depth", 0), two_player=opts.get("two_player", False),
+               bonus_after_rescale=opts.get("bonus_after_rescale", False), var_backup=opts.get("var_backup", 0))
+    otree = oracle.OracleTree(oenv, onet, B, S)
+    otree.begin(logits, v, u, blobs, beta, invalid, g, **okw)
+    for sim in range(S):
+        otree.sim(sim)
+    search = engine.Search(env, net, B, S, discount=0.97, exploration=explore, rescale_values=okw["rescale"], use_mixed_value=okw["use_mixed"],
+                           max_num_considered_actions=okw["max_considered"], max_depth=okw["max_depth"] or None,
+                           two_players_game=okw["two_player"], epistemic_bonus_after_rescale=okw["bonus_after_rescale"],
+                           epistemic_variance_backup=okw["var_backup"])
+    cu = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for rep in range(2):  # the second search reuses the (dirty) tree buffers of the first
+        search.begin(cu(logits), cu(v), cu(u), st, cu(beta), cu(invalid), cu(g))
+        search.profile(True)
+        search.profile_read()
+        search.run()
+        torch.cuda.synchronize()
+        prof = search.profile_read()
+        search.profile(False)
+        if kernel_variant == "persist" and S <= 80:
+            assert prof["search"]["launches"] == 1 and prof["tree"]["launches"] == 0 and prof["net"]["launches"] == 0, prof
+        act, aw = search.finish()
+        oact, oaw = otree.finish()
+        exact = _compare_tree(search, otree, f"run rep={rep}")
+        emb = subleq_device_to_oracle(search.field("embeddings").cpu().numpy().reshape(B * (S + 1), -1), W).reshape(B, S + 1, -1)
+        visited = search.dump()["node_visits"] > 0
+        assert np.array_equal(emb[visited], otree.field("embeddings")[visited]), "state blobs of visited nodes differ"
+        assert np.array_equal(act.cpu().numpy(), oact)
+        np.testing.assert_allclose(aw.cpu().numpy(), oaw, rtol=0, atol=ATOL)
+        s_, os_ = search.summary(), otree.summary()
+        for k in os_:
+            np.testing.assert_allclose(s_[k].cpu().numpy(), os_[k], rtol=0, atol=ATOL, err_msg=k)
+    if opts.get("max_depth"):
+        assert (search.dump()["node_visits"][:, 1:] > 1).any(), "the depth limit never re-expanded a node"
+    print(f"Subleq-16 run(): tree float fields bit-exact vs oracle: {exact}")
+
+
 def test_search_begin_then_stepwise_after_persist_default(oracle, eaz, torch):
     """With the persistent launch enabled eaz_search_begin skips the tree clear; stepping the same search simulation by simulation
     (eaz_search_simulate) must then clear lazily without losing the root, also on buffers a previous run() left dirty."""
