@@ -129,7 +129,7 @@ def build_workload(name, args, device, rank, beta=0.0):
             onet = O.OracleNet(G * G, H, A, eaz.params.fc_weight_list(params), bitset=hstate[eaz.params.HASH_MODULE]["binary_set"])
             return oenv, onet, dict(discount=0.997), f"DeepSea-{G}"
     elif name == "c3":
-        W = 16
+        W = args.word_size
         cols, rows = (W - 1).bit_length() + 1, W + 32                   # binary encoding, envs/subleq.py:59-60,697-705
         in_dim, hash_off = rows * cols, W * cols                        # hash_io: rows W.. only (fully_connected.py:85-87)
         params = eaz.params.init_fc_params(in_dim, H, W, seed=0)
@@ -138,10 +138,15 @@ def build_workload(name, args, device, rank, beta=0.0):
         net = engine.FCNet(env.ctx, in_dim, H, W, params, hstate, hash_off=hash_off, hash_len=in_dim - hash_off)
         search = engine.Search(env, net, B, S, discount=0.97, exploration=explore)
         A = W
-        desc = f"Subleq word_size={W} task=1 binary obs, batch={B}/GPU, {S} sims, {T} real steps per selfplay() call, FC H={H} (BASELINE.json configs[2])"
+        desc = (f"Subleq word_size={W} task=1 binary obs, batch={B}/GPU, {S} sims, {T} real steps per selfplay() call, FC H={H} "
+                + ("(BASELINE.json configs[2])" if W == 16 else "(configs[2] at another word size: the per-simulation kernels)"))
         data = "synthetic (random-init FC net, half-filled novelty set)"
-        net_kernel, net_flops = "fc16p_forward_kernel", fc_flops_per_eval(in_dim, A, (0, 1, 2)) * B   # dense rows, narrow heads: the pipelined kernel
-        pmc_tag, gather_kernel = f"Subleq-{W}, B={B}, {S} sims", "subleq16_tree_leaf_kernel (tree step + env step + observation row + novelty)"
+        # dense rows: narrow heads run the pipelined 16-row kernel, wide heads (W > 16) the 64-row tiles
+        net_kernel, net_flops = "fc16p_forward_kernel" if W == 16 else "fc_forward_kernel", fc_flops_per_eval(in_dim, A, (0, 1, 2)) * B
+        pmc_tag = f"Subleq-{W}, B={B}, {S} sims"
+        gather_kernel = ("subleq16_tree_leaf_kernel (tree step + env step + observation row + novelty)" if W == 16 else
+                         "subleq_step_kernel + obs_emit_kernel")
+        w["metric"] = w["metric"].replace("Subleq-16", f"Subleq-{W}")
 
         def oracle(O):
             oenv = O.OracleEnv.subleq(W, (1,), True)
@@ -238,6 +243,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--word-size", type=int, default=16, help="c3: Subleq word size (16 = configs[2]; the reference's code default is 256, main.py:159)")
     ap.add_argument("--grid", type=int, default=32, help="DeepSea size (c2)")
     ap.add_argument("--batch", type=int, default=0, help="environments per GPU (default: the workload's)")
     ap.add_argument("--sims", type=int, default=0)
@@ -436,7 +442,7 @@ def parity_gate(wl, args):
     ost = oenv.init(nb)
     ref = O.selfplay(oenv, onet, ost, T=nt, S=S, key=engine.key_pair(4242), **okw, **wl["sp_kw"])
     # Subleq: the oracle keeps words as int32, the device blob of include/eaz.h as bytes -- same fields, compared in the oracle's layout
-    conv = (lambda a: O.subleq_device_to_oracle(a, 16)) if wl["name"] == "c3" else (lambda a: a)
+    conv = (lambda a: O.subleq_device_to_oracle(a, wl["A"])) if wl["name"] == "c3" else (lambda a: a)
     ok_int = bool(np.array_equal(out["action"].cpu().numpy(), ref["action"]) and np.array_equal(conv(out["state"].cpu().numpy()), ref["state"])
                   and np.array_equal(conv(st.cpu().numpy()), ost))
     err = max(float(np.max(np.abs(out[k].cpu().numpy() - ref[k]))) for k in
@@ -558,7 +564,7 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
         kname = wl["net_kernel"]
         k_ms = search.profile_replay("net", 200 if name != "c4" else 10)
         n_launch = max(prof["net"]["launches"], 1)
-        if kname in ("fc16_forward_kernel", "fc16p_forward_kernel"):
+        if kname in ("fc16_forward_kernel", "fc16p_forward_kernel", "fc_forward_kernel"):
             # counter unit: one k-step of a 16-row tile; never more than the dense layer 1 (padded k-steps of a partial block are not work)
             l1 = min(prof["net"]["layer1_ksteps"] * (16 * H * 4 * 2) / n_launch, sum(2 * wl["in_dim"] * H for _ in heads) * B)
             flops = l23 + l1

@@ -286,7 +286,7 @@ static int subleq_envs_per_wg(int B) {
     while (epw > 8 && cdiv(B, epw) < 256) epw /= 2;
     return epw;
 }
-static int subleq_lds_bytes(int W) { return 2 * 64 * ((W + 3) & ~3); }  // program + snapshot per lane, rows padded to whole 32-bit words
+static int subleq_lds_bytes(int W) { return 2 * 64 * (((W + 3) & ~3) + 4); }  // program + snapshot per lane, rows of whole 32-bit words + one (bank spread)
 
 static int env_step_launch(eaz_env* env, int B, const void* in, const int32_t* action, Key key, int mode, void* out,
                            void* out_copy, hipStream_t st, const Key* d_key = nullptr, float* mover_reward = nullptr) {

@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src,
                                                          float* next_reward, uint8_t* next_term, uint8_t* next_legal,
                                                          int envs_per_wg, int mem_copy) {
     const Key key = key_ptr ? *key_ptr : key_arg;  // device-resident key: lets a captured hipGraph serve every real step
-    extern __shared__ __attribute__((aligned(16))) uint8_t lmem[];  // 2 * 64 * Wp (working memory + snapshot)
+    extern __shared__ __attribute__((aligned(16))) uint8_t lmem[];  // 2 * 64 * (Wp + 4) (working memory + snapshot)
     const int W = e.W;
     const int Wp = (W + 3) & ~3;  // any word_size in 16..256 (subleq.py:606): the LDS rows are whole 32-bit words, the bytes W..Wp-1 stay zero
                                   // (state bytes beyond W are zero) and no Subleq address reaches them
@@ -159,7 +159,9 @@ __global__ void __launch_bounds__(64) subleq_step_kernel(EnvDev e, StateRef src,
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { ex_in[i] = tin[i]; ex_out[i] = tout[i]; }
             }
-            MemLds mem{lmem + static_cast<long>(el) * Wp, lmem + static_cast<long>(64 + el) * Wp, Wp};
+            // row stride Wp + 4: an odd number of 32-bit words, so that lanes reading the same program address (the common case: every
+            // program starts at cursor 0) hit different LDS banks (Wp = 256 put all 64 lanes on one)
+            MemLds mem{lmem + static_cast<long>(el) * (Wp + 4), lmem + static_cast<long>(64 + el) * (Wp + 4), Wp};
             if (do_init) { for (int i = 0; i < Wp; i += 4) *reinterpret_cast<uint32_t*>(mem.m + i) = 0u; }
             else {
                 for (int i = 0; i < Wp; i += 4) *reinterpret_cast<uint32_t*>(mem.m + i) = *reinterpret_cast<const uint32_t*>(sp->memory + i);

@@ -229,17 +229,23 @@ struct MemLds {
     uint8_t* m;
     uint8_t* snap;
     int W;
+    int ndiff = 0;  // bytes of m that differ from snap (meaningful once snapshot() has run): m == snap <=> ndiff == 0
     __device__ __forceinline__ int get(int i) const { return m[i]; }
+    __device__ __forceinline__ int snap_get(int i) const { return snap[i]; }
     static constexpr bool kWordsInRange = false;  // bytes of a hand-made state may exceed W
-    __device__ __forceinline__ void set_if(bool cond, int i, int v) { if (cond) m[i] = static_cast<uint8_t>(v); }
+    // old / s: the byte at i before the write and the snapshot's byte at i (the caller reads them with the operands, one LDS round trip).
+    // The periodicity test used to compare the W bytes word by word whenever the cursor came back to the snapshot's: a counting loop
+    // does that every iteration and differs only far up in memory -- 50 dependent LDS reads per Subleq cycle at word_size 256 (launches
+    // of 600-700 us, profiles/r03_d_*); the running count makes the test one compare, exactly.
+    __device__ __forceinline__ void set_if(bool cond, int i, int v, int old, int s) {
+        if (cond) m[i] = static_cast<uint8_t>(v);
+        ndiff += cond ? (static_cast<int>(v != s) - static_cast<int>(old != s)) : 0;
+    }
     __device__ __forceinline__ void snapshot() {
         for (int i = 0; i < W; i += 4) *reinterpret_cast<uint32_t*>(snap + i) = *reinterpret_cast<const uint32_t*>(m + i);
+        ndiff = 0;
     }
-    __device__ __forceinline__ bool same() const {
-        bool eq = true;
-        for (int i = 0; i < W && eq; i += 4) eq = *reinterpret_cast<const uint32_t*>(m + i) == *reinterpret_cast<const uint32_t*>(snap + i);
-        return eq;
-    }
+    __device__ __forceinline__ bool same() const { return ndiff == 0; }
 };
 
 // subleq.py:297-398 `simulate`.
@@ -277,7 +283,7 @@ __device__ __forceinline__ bool subleq_simulate(int W, Mem& mem, uint16_t in_arr
         const int cc = oob ? 0 : cur;
         const int a = mem.get(cc), b = mem.get(cc + 1), c = mem.get(cc + 2);
         const bool a_mem = a <= AMAX, b_mem = b <= AMAX;
-        const int ma = mem.get(a_mem ? a : 0), mb = mem.get(b_mem ? b : 0);
+        const int ma = mem.get(a_mem ? a : 0), mb = mem.get(b_mem ? b : 0), sa = mem.snap_get(a_mem ? a : 0);
         const bool uses_in = (a == AIN) || (b == AIN), wr_out = a == AOUT;
         bool err = false;
         int value;
@@ -323,7 +329,7 @@ __device__ __forceinline__ bool subleq_simulate(int W, Mem& mem, uint16_t in_arr
         }
         // :322 (ra - rb) mod W: words are < W, so one conditional add is the whole modulo; the general form (an integer division)
         // only runs for out-of-range bytes of a hand-made state.  write_memory :243-295 (memory)
-        mem.set_if(ok && a_mem, a, value);
+        mem.set_if(ok && a_mem, a, value, ma, sa);
         const bool jump = (value == 0) || (2 * value >= W);  // :329
         cur = oob ? cur : (jump ? c : cur + 3);              // :330
         // :340-345 `(execute_jump & c > ADDRESS_MAX)` == `(execute_jump & c) > ADDRESS_MAX` (Python precedence): {0,1} > W-4
@@ -332,8 +338,7 @@ __device__ __forceinline__ bool subleq_simulate(int W, Mem& mem, uint16_t in_arr
         // ---- periodicity (exact, see above) ----
         const bool watching = !skipped && !error && !halt;
         bool hit = (static_cast<int>(watching) & static_cast<int>(cur == s_cur) & static_cast<int>(io_epoch == s_epoch)) != 0;
-        if constexpr (Mem::kWordsInRange) hit = (static_cast<int>(hit) & static_cast<int>(mem.same())) != 0;
-        else hit = hit && mem.same();
+        hit = (static_cast<int>(hit) & static_cast<int>(mem.same())) != 0;
         if (hit) {
             const int p = cycles - s_cycle;
             cycles += ((200 - cycles) / p) * p;
