@@ -142,7 +142,7 @@ def build_workload(name, args, device, rank, beta=0.0):
                 + ("(BASELINE.json configs[2])" if W == 16 else "(configs[2] at another word size: the per-simulation kernels)"))
         data = "synthetic (random-init FC net, half-filled novelty set)"
         # dense rows: narrow heads run the pipelined 16-row kernel, wide heads (W > 16) the 64-row tiles
-        net_kernel, net_flops = "fc16p_forward_kernel" if W == 16 else "fc_forward_kernel", fc_flops_per_eval(in_dim, A, (0, 1, 2)) * B
+        net_kernel, net_flops = "fc16p_forward_kernel" if W == 16 else "fc16_forward_kernel | fc_forward_kernel (by sub-batch size)", fc_flops_per_eval(in_dim, A, (0, 1, 2)) * B
         pmc_tag = f"Subleq-{W}, B={B}, {S} sims"
         gather_kernel = ("subleq16_tree_leaf_kernel (tree step + env step + observation row + novelty)" if W == 16 else
                          "subleq_step_kernel + obs_emit_kernel")
@@ -564,7 +564,7 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
         kname = wl["net_kernel"]
         k_ms = search.profile_replay("net", 200 if name != "c4" else 10)
         n_launch = max(prof["net"]["launches"], 1)
-        if kname in ("fc16_forward_kernel", "fc16p_forward_kernel", "fc_forward_kernel"):
+        if kname.startswith("fc"):
             # counter unit: one k-step of a 16-row tile; never more than the dense layer 1 (padded k-steps of a partial block are not work)
             l1 = min(prof["net"]["layer1_ksteps"] * (16 * H * 4 * 2) / n_launch, sum(2 * wl["in_dim"] * H for _ in heads) * B)
             flops = l23 + l1

@@ -18,7 +18,32 @@ __device__ __forceinline__ void emit_obs_row(const EnvDev& e, const char* sp, ui
     const int D = e.obs_dim;
     const int hot = e.kind == EAZ_ENV_DEEPSEA ? ds_hot_index(e, ds_load(sp)) : 0;
     const bool vec = (D % 16 == 0) && ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
-    if (vec) {
+    if (vec && e.kind == EAZ_ENV_SUBLEQ) {
+        // Subleq (subleq.py:679-707, encoders :26-56 / :63-98): a lane's 16 bytes span at most three row-words at >= 8 columns per word; the word
+        // and its `mod W` (one integer division) are fetched when the row changes, not per byte (the generic path: 17 us per 1024 rows of
+        // word_size 256)
+        const eaz_subleq_state* st = reinterpret_cast<const eaz_subleq_state*>(sp);
+        const int cols = e.obs_cols, W = e.W;
+        for (int base = lane * 16; base < D; base += 64 * 16) {
+            int r = base / cols, c = base - r * cols;
+            int v = subleq_row_word(e, st, r);
+            int m = pymod(v, W);
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                uint32_t byte;
+                if (e.binary) byte = c == cols - 1 ? static_cast<uint32_t>(v == W) : (c < 8 ? (static_cast<uint32_t>(m & 0xFF) >> c) & 1u : 0u);  // :90-96
+                else byte = static_cast<uint32_t>(c == (v == W ? W : m));                                                                     // :52
+                w[i >> 2] |= byte << (8 * (i & 3));
+                if (++c == cols) {
+                    c = 0;
+                    r += 1;
+                    if (r < e.obs_rows) { v = subleq_row_word(e, st, r); m = pymod(v, W); }
+                }
+            }
+            *reinterpret_cast<uint4*>(row + base) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    } else if (vec) {
         for (int base = lane * 16; base < D; base += 64 * 16) {
             uint32_t w[4] = {0u, 0u, 0u, 0u};
             if (e.kind == EAZ_ENV_DEEPSEA) {
