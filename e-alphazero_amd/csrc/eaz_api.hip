@@ -1116,7 +1116,12 @@ static int sq16_persist_launch(eaz_search* s, int sim0, int n_sims, bool expand_
 }
 
 // Subleq-16 fused self-play: T real steps in one launch (search_subleq_persist.hpp)
-static bool sqp_eligible(const eaz_search* s) { return s->sqp_lds > 0 && sq16_persist_eligible(s) && s->tree.max_depth >= 1; }
+static bool sqp_eligible(const eaz_search* s) {
+    if (!(s->sqp_lds > 0 && sq16_persist_eligible(s) && s->tree.max_depth >= 1)) return false;
+    for (int i = 0; i < s->env->dev.n_tasks; ++i)  // the kernel keeps a tree's task as 16 bits (QpMisc::task); a root blob's own task field likewise
+        if (s->env->dev.tasks[i] < -32768 || s->env->dev.tasks[i] > 32767) return false;
+    return true;
+}
 static int sqp_launch(eaz_search* s, const PersistSelfplay& sp, hipStream_t st) {
     Sq16SelfplayArgs a;
     a.sp = sp;
@@ -1805,6 +1810,27 @@ extern "C" __attribute__((visibility("default"))) int eaz_diag_qp_stamps(eaz_sea
 extern "C" __attribute__((visibility("default"))) int eaz_diag_qp_dhist(unsigned long long* h_out /* [72] */) {
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_qp_dhist), sizeof(unsigned long long) * 72));
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int eaz_diag_qp_fine(unsigned long long* h_out /* [2048*8] */) {
+    ARG_OK(h_out != nullptr);
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_qp_fine), sizeof(unsigned long long) * 2048 * 8));
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int eaz_diag_qp_its(uint32_t* h_out /* [64*64*16] */) {
+    ARG_OK(h_out != nullptr);
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_qp_its), sizeof(uint32_t) * 64 * 64 * 16));
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int eaz_diag_qp_ehist(unsigned long long* h_out /* [128] */, int reset) {
+    ARG_OK(h_out != nullptr);
+    HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_qp_ehist), sizeof(unsigned long long) * 128));
+    if (reset) {
+        static const unsigned long long zeros[128] = {};
+        HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_qp_ehist), zeros, sizeof zeros));
+    }
     return 0;
 }
 extern "C" __attribute__((visibility("default"))) int eaz_diag_sq_stamps(unsigned long long* h_out /* [16] */) {

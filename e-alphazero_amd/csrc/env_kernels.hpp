@@ -283,7 +283,9 @@ extern __device__ unsigned long long g_sq_stamps[16];
 // it cannot recur).  The IO buffers are bytes of 64-bit scalars as well (first version: lanes of VGPRs -- every IO cycle then paid
 // three VALU <-> SALU round trips, and the programs the search likes best are the ones full of IO instructions).
 __device__ __forceinline__ bool subleq16_wave_run(unsigned long long smem, const unsigned long long sin, const unsigned long long stout,
-                                                  unsigned long long& in_after, unsigned long long& out, int& bytes_used) {
+                                                  unsigned long long& in_after, unsigned long long& out, int& bytes_used,
+                                                  int* iterations = nullptr /* interpreted cycles of this run */,
+                                                  unsigned* touched = nullptr /* |= bit l for every word l fetched, read or written; kept in a VGPR */) {
     constexpr int W = 16, AMAX = 12, AIN = 13, AOUT = 14, kStop = 1000;
     constexpr unsigned long long kAllW = 0x1010101010101010ull;
     unsigned long long sout = kAllW, ssnap = 0ull;
@@ -298,8 +300,9 @@ __device__ __forceinline__ bool subleq16_wave_run(unsigned long long smem, const
     auto cycle_end = [&]() {
         cycles += inc;
         it += 1;
-        if (cur == s_cur) {
-            if (cycles < 200 && smem == ssnap) {
+        if (smem == ssnap) {  // the rare one of the three conditions first: one compare + branch on the common path
+            asm volatile("");  // (keeps the compiler from folding the three tests into one mask expression evaluated every cycle)
+            if (cur == s_cur && cycles < 200) {
                 const int p = cycles - s_cycle;
                 cycles += ((200 - cycles) / p) * p;
             }
@@ -314,16 +317,23 @@ __device__ __forceinline__ bool subleq16_wave_run(unsigned long long smem, const
         bool oob;
         for (;;) {
             oob = cur >= W - 2;  // :364-370
-            if (oob) break;
+            if (oob) { asm volatile(""); break; }  // (the empty asm keeps the loop's two exits two branches instead of a mask expression per cycle)
             top_cur = max(top_cur, cur);
             const unsigned t = static_cast<unsigned>(smem >> (4 * cur));
             a = t & 15; b = (t >> 4) & 15; c = (t >> 8) & 15;
+            if (touched) {
+                // three VALU instructions on a wavefront-uniform value: the scalar port is what the interpreters of a workgroup compete for
+                // (two waves per SIMD), the vector port is idle
+                unsigned tv = *touched;
+                asm volatile("v_lshl_or_b32 %0, 7, %1, %0\n\tv_lshl_or_b32 %0, 1, %2, %0\n\tv_lshl_or_b32 %0, 1, %3, %0" : "+v"(tv) : "s"(cur), "s"(a), "s"(b));
+                *touched = tv;
+            }
             if (max(a, b) > AMAX) break;
             const int v = (word(a) - word(b)) & 15;  // :322
             store(a, v);
             cur = static_cast<unsigned>(v - 1) >= 7u ? c : cur + 3;  // :329-330 jump when value == 0 or 2 * value >= 16
             cycle_end();
-            if (cycles >= 200) break;
+            if (cycles >= 200) { asm volatile(""); break; }
         }
         if (cycles >= 200) break;
         if (oob) { error = 1; break; }  // nothing else changes
@@ -364,6 +374,7 @@ __device__ __forceinline__ bool subleq16_wave_run(unsigned long long smem, const
 #ifdef EAZ_FC_STAMPS
     if (blockIdx.x == 0 && threadIdx.x == 0) { g_sq_stamps[8] += static_cast<unsigned long long>(it); g_sq_stamps[9] += 1; if (static_cast<unsigned long long>(it) > g_sq_stamps[10]) g_sq_stamps[10] = it; }
 #endif
+    if (iterations) *iterations = it;
     in_after = in_cur == 0 ? sin : (in_cur >= 8 ? kAllW : ((sin >> (8 * in_cur)) | (kAllW << (64 - 8 * in_cur))));
     out = sout;
     bytes_used = top_cur + 3;

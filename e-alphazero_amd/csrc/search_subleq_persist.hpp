@@ -72,6 +72,8 @@ struct QpMisc {
     int real_action[kQpTrees];
     int env_next;
     int pad[3];
+    uint8_t qkey[kQpTrees];             // expected cost of the environment's next interpreter step (queue order)
+    int16_t task[kQpTrees];             // the environments' tasks: constant between two resets (subleq.py:624), so not stored per node
     float beta[kQpTrees];               // selfplay.py:105 beta * linspace(0, 1, B)[b]; search only: the caller's per-tree beta
     int nc[kQpTrees];                   // min(valid root actions, max_num_considered_actions): row of the considered-visit table
     uint8_t invalid[kQpTrees][kQpA];    // root_invalid_actions (self-play: none, subleq.py:626)
@@ -138,10 +140,25 @@ struct Sq16SelfplayArgs {
         }                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                             \
     } while (0)
+__device__ unsigned long long g_qp_fine[2048 * 8];  // diagnostic build: raw stamps inside the interpreter segment of the stamped step, [workgroup * 8 + wave][8]
+#define EAZ_QFSTAMP(sp, i)                                                                             \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        if ((sp) != nullptr && lane == 0 && blockIdx.x < 256) {                                        \
+            unsigned long long t_;                                                                     \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+            g_qp_fine[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = t_;                           \
+        }                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    } while (0)
+__device__ uint32_t g_qp_its[64 * 64 * 16];  // diagnostic build, first real step of workgroups 0..63: [workgroup][simulation][environment] = cost of the step | parent's cost << 8 | written << 16
+__device__ unsigned long long g_qp_ehist[128];  // diagnostic build: interpreter steps of workgroups 0..63 -- [0..3] by test cases run, [4..35] by interpreted cycles / 4 of
+                                                 // the whole step, [36..67] of test case 0 alone, [68..99] of the steps that ran more than one case; [100] sum of cycles
 __device__ unsigned long long g_qp_dhist[72];  // diagnostic build: histogram of the select depth D over all trees and simulations (+ [64..71]: by simulation octile, sum of D)
 #else
 #define EAZ_QPSTAMP(i)
 #define EAZ_QESTAMP(sp, i)
+#define EAZ_QFSTAMP(sp, i)
 #endif
 
 __device__ __forceinline__ unsigned long long qp_u64(uint32_t lo, uint32_t hi) { return static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32); }
@@ -165,10 +182,17 @@ __device__ __forceinline__ unsigned long long qp_row_bytes(const uint4& r) {
     for (int i = 0; i < 4; ++i) v |= static_cast<unsigned long long>((w[i] & 0xFFu) | ((w[i] >> 8) & 0xFF00u)) << (16 * i);
     return v;
 }
-__device__ __forceinline__ int qp_hdr_task(uint32_t hdr) { return static_cast<int>(hdr) >> 12; }
-__device__ __forceinline__ uint32_t qp_hdr(int step, int task, int term, int trunc, int solved, int exroot) {
+// header word of a compact state: step count (8 bits) | terminated, truncated, solved, "example rows from the root blob" | cost hint (4 bits) |
+// touched mask (16 bits).  The last two are not part of the environment state (they never leave LDS): `touched` bit l = the interpreter runs
+// whose results this state carries (input_after, output_after, solved) fetched, read or wrote program word l -- all ones when unknown (a
+// caller's root blob, states no run produced); `hint` = min(15, interpreted cycles / 4) of those runs.  The task is a constant of the tree
+// between two resets (QpMisc::task).
+__device__ __forceinline__ int qp_hdr_hint(uint32_t hdr) { return static_cast<int>((hdr >> 12) & 15u); }
+__device__ __forceinline__ uint32_t qp_hdr_touched(uint32_t hdr) { return hdr >> 16; }
+__device__ __forceinline__ uint32_t qp_hdr(int step, int term, int trunc, int solved, int exroot, int hint = 0, uint32_t touched = 0xFFFFu) {
     return static_cast<uint32_t>(step & 0xFF) | (static_cast<uint32_t>(term != 0) << 8) | (static_cast<uint32_t>(trunc != 0) << 9) |
-           (static_cast<uint32_t>(solved != 0) << 10) | (static_cast<uint32_t>(exroot != 0) << 11) | (static_cast<uint32_t>(task) << 12);
+           (static_cast<uint32_t>(solved != 0) << 10) | (static_cast<uint32_t>(exroot != 0) << 11) | (static_cast<uint32_t>(hint & 15) << 12) |
+           (touched << 16);
 }
 // observation code of a row-word: bits 0..3 = v mod 16, bit 4 = (v == 16)  (subleq.py:88-98)
 __device__ __forceinline__ uint8_t qp_code(uint32_t v) { return static_cast<uint8_t>((v & 15u) | (v == 16u ? 16u : 0u)); }
@@ -232,7 +256,7 @@ __device__ __forceinline__ void qp_round(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDep
 // blob: also the 336-byte state of include/eaz.h (real steps); words: the observation's row-words.  Returns the reward / terminated flag.
 __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src, uint32_t* dst, const uint32_t* root_ex, uint8_t* words,
                                             unsigned long long* xb, const int action, const int mode, const Key envkey, const int b, const int lane, char* blob0,
-                                            char* blob1, float& reward_out, int& term_out, unsigned long long* dstamp = nullptr) {
+                                            char* blob1, float& reward_out, int& term_out, int16_t* tree_task, unsigned long long* dstamp = nullptr) {
     EAZ_QESTAMP(dstamp, 8);
     uint32_t s[QS_WORDS];
 #pragma unroll
@@ -246,11 +270,12 @@ __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src
     const bool done = (s_term | s_trunc) != 0;
     const bool do_init = mode == 1 && done;
     bool finish = false, run = false;
-    int step_count, task = qp_hdr_task(hdr);
+    int step_count, task = __builtin_amdgcn_readfirstlane(static_cast<int>(*tree_task));
     if (do_init) {
         const Key ki = fold(fold(envkey, static_cast<uint32_t>(b)), 1u);
         const int idx = e.n_tasks > 1 ? static_cast<int>(rbits(ki, 0) % static_cast<uint32_t>(e.n_tasks)) : 0;  // subleq.py:624
         task = __builtin_amdgcn_readfirstlane(e.tasks[idx]);
+        if (lane == 0) *tree_task = static_cast<int16_t>(task);
         step_count = 0;
         run = true;
         mem = 0ull;
@@ -270,21 +295,62 @@ __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src
     unsigned long long exin = exroot ? qp_u64(root_ex[0], root_ex[1]) : t_in, exout = exroot ? qp_u64(root_ex[2], root_ex[3]) : t_out;
     bool all_correct = false;
     int bytes_used = 0;
+    int cost = 0;  // interpreted cycles of this step (all cases)
+    int hint = 0;
+    uint32_t touched = 0xFFFFu;
+#ifdef EAZ_FC_STAMPS
+    int dg_it0 = 0, dg_cases = 0;
+#endif
     EAZ_QESTAMP(dstamp, 9);
     if (run) {
         const int idx = step_count - 1;  // the action is word step_count - 1 (subleq.py:654)
         if (!do_init && idx >= 0 && idx < 16) mem = (mem & ~(15ull << (4 * idx))) | (static_cast<unsigned long long>(action & 15) << (4 * idx));
-        all_correct = true;
+        EAZ_QFSTAMP(dstamp, 0);
+        // The runs whose results the parent state carries never fetched, read or wrote word idx: on the child's program they take the same
+        // cycles to the same results whatever the word holds -- input_after / output_after stay, and the runs failed (a solved parent finishes,
+        // :671-673, it does not run), so solved = 0 and the reward is 0.  Exact, and two thirds of the leaf steps of a search.
+        const bool same_runs = !do_init && idx >= 0 && idx < 16 && ((qp_hdr_touched(hdr) >> idx) & 1u) == 0u;
+        if (same_runs) {
+            all_correct = false;
+            hint = qp_hdr_hint(hdr);
+            touched = qp_hdr_touched(hdr);
+        } else {
+            all_correct = true;
+            unsigned tmask = 0u;
+            asm volatile("" : "+v"(tmask));  // lives in a VGPR: subleq16_wave_run accumulates it on the vector port
 #pragma unroll 1
-        for (int c = 0; c < 3 && all_correct; ++c) {  // subleq.py:511 vmap; `solved` is the AND (:525), only case 0 feeds the state
-            const unsigned long long sin = c == 0 ? tv[0][0] : (c == 1 ? tv[1][0] : tv[2][0]), stout = c == 0 ? tv[0][1] : (c == 1 ? tv[1][1] : tv[2][1]);
-            unsigned long long s_after, s_out;
-            int bytes_c;
-            const bool correct = subleq16_wave_run(mem, sin, stout, s_after, s_out, bytes_c);
-            bytes_used = max(bytes_used, bytes_c);  // :530
-            if (c == 0) { inaf = s_after; outaf = s_out; }
-            all_correct = correct;
+            for (int c = 0; c < 3 && all_correct; ++c) {  // subleq.py:511 vmap; `solved` is the AND (:525), only case 0 feeds the state
+                const unsigned long long sin = c == 0 ? tv[0][0] : (c == 1 ? tv[1][0] : tv[2][0]), stout = c == 0 ? tv[0][1] : (c == 1 ? tv[1][1] : tv[2][1]);
+                unsigned long long s_after, s_out;
+                int bytes_c;
+                int it_c = 0;
+#ifdef EAZ_FC_STAMPS
+                if (c == 0) { asm volatile("" ::"s"(sin), "s"(stout)); EAZ_QFSTAMP(dstamp, 1); }
+#endif
+                const bool correct = subleq16_wave_run(mem, sin, stout, s_after, s_out, bytes_c, &it_c, &tmask);
+#ifdef EAZ_FC_STAMPS
+                if (c == 0) { asm volatile("" ::"s"(s_after), "s"(s_out), "s"(bytes_c)); EAZ_QFSTAMP(dstamp, 2); }
+                if (c == 0) dg_it0 = it_c;
+                dg_cases = c + 1;
+#endif
+                cost += it_c;
+                bytes_used = max(bytes_used, bytes_c);  // :530
+                if (c == 0) { inaf = s_after; outaf = s_out; }
+                all_correct = correct;
+            }
+            hint = min(cost >> 2, 15);
+            touched = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(tmask))) & 0xFFFFu;
         }
+#ifdef EAZ_FC_STAMPS
+        if (dstamp != nullptr && lane == 0) dstamp[15] = static_cast<unsigned long long>(cost) + 1ull;  // interpreted cycles of the stamped step (+ 1: "written")
+        if (blockIdx.x < 64 && lane == 0 && mode == 0) {
+            atomicAdd(&g_qp_ehist[dg_cases], 1ull);  // [0]: steps that needed no run
+            atomicAdd(&g_qp_ehist[4 + min(cost >> 2, 31)], 1ull);
+            atomicAdd(&g_qp_ehist[36 + min(dg_it0 >> 2, 31)], 1ull);
+            if (dg_cases > 1) atomicAdd(&g_qp_ehist[68 + min(cost >> 2, 31)], 1ull);
+            atomicAdd(&g_qp_ehist[100], static_cast<unsigned long long>(cost));
+        }
+#endif
         exin = t_in; exout = t_out; exroot = 0;
     }
     EAZ_QESTAMP(dstamp, 10);
@@ -303,7 +369,7 @@ __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src
     if (lane == 0) {
         uint4* d4 = reinterpret_cast<uint4*>(dst);
         d4[0] = make_uint4(static_cast<uint32_t>(mem), static_cast<uint32_t>(mem >> 32), static_cast<uint32_t>(inaf), static_cast<uint32_t>(inaf >> 32));
-        d4[1] = make_uint4(static_cast<uint32_t>(outaf), static_cast<uint32_t>(outaf >> 32), qp_hdr(step_count, task, terminated, truncated, solved, exroot),
+        d4[1] = make_uint4(static_cast<uint32_t>(outaf), static_cast<uint32_t>(outaf >> 32), qp_hdr(step_count, terminated, truncated, solved, exroot, hint, touched),
                            __builtin_bit_cast(uint32_t, reward));
     }
     EAZ_QESTAMP(dstamp, 11);
@@ -470,7 +536,8 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             rs[QS_MEM] = static_cast<uint32_t>(mem); rs[QS_MEM + 1] = static_cast<uint32_t>(mem >> 32);
             rs[QS_INAF] = static_cast<uint32_t>(inaf); rs[QS_INAF + 1] = static_cast<uint32_t>(inaf >> 32);
             rs[QS_OUTAF] = static_cast<uint32_t>(outaf); rs[QS_OUTAF + 1] = static_cast<uint32_t>(outaf >> 32);
-            rs[QS_HDR] = qp_hdr(static_cast<int>(hv.x), static_cast<int>(hv.y), hv.w & 0xFF, (hv.w >> 8) & 0xFF, (hv.w >> 16) & 0xFF, 1);
+            rs[QS_HDR] = qp_hdr(static_cast<int>(hv.x), hv.w & 0xFF, (hv.w >> 8) & 0xFF, (hv.w >> 16) & 0xFF, 1);  // touched: all ones (unknown)
+            M.task[j] = static_cast<int16_t>(static_cast<int>(hv.y));
             rs[QS_REWARD] = hv.z;
             M.root_ex[j][0] = static_cast<uint32_t>(exin); M.root_ex[j][1] = static_cast<uint32_t>(exin >> 32);
             M.root_ex[j][2] = static_cast<uint32_t>(exout); M.root_ex[j][3] = static_cast<uint32_t>(exout >> 32);
@@ -799,6 +866,12 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                     node = nx;
                 }
                 M.parent[ti] = node; M.action[ti] = act; M.dst[ti] = nx == 0xFF ? s : nx; M.D[ti] = depth;  // simulation s - 1 expands node s
+                // place in the interpreter queue: longest expected run first -- a child's program differs from its parent's in one word, and a
+                // step whose word the parent's runs never touched runs nothing (qp_env_step)
+                const uint32_t ph = ST[node * QS_WORDS + QS_HDR];
+                const int widx = static_cast<int>(ph & 0xFFu);  // the action becomes word step_count (of the parent)
+                const bool cheap = ((ph >> 8) & 7u) != 0u || widx >= 12 || ((qp_hdr_touched(ph) >> widx) & 1u) == 0u;
+                M.qkey[ti] = static_cast<uint8_t>(cheap ? 0 : 1 + qp_hdr_hint(ph));
 #ifdef EAZ_FC_STAMPS
                 if (step == 0 && blockIdx.x < 64) { atomicAdd(&g_qp_dhist[depth < 63 ? depth : 63], 1ull); atomicAdd(&g_qp_dhist[64 + ((s - 1) * 8) / S], static_cast<unsigned long long>(depth)); }
 #endif
@@ -830,7 +903,25 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                     asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(env_next_off), "v"(1) : "memory");
                     return n_static + (__builtin_amdgcn_readfirstlane(got) >> 6);
                 };
-                int j = wave;
+                // queue position -> environment: by descending key, ties by index (every wave ranks the 16 keys itself: lanes 0..15)
+                int rank = 0;
+                if (env_mode == 0) {
+                    const int me = lane & 15;
+                    const int kme = M.qkey[me];
+#pragma unroll
+                    for (int o = 0; o < kQpTrees; ++o) {
+                        const int ko = M.qkey[o];
+                        rank += (ko > kme || (ko == kme && o < me)) ? 1 : 0;
+                    }
+                } else {
+                    rank = lane & 15;
+                }
+                auto env_at = [&](int pos) {
+                    if (pos >= kQpTrees) return pos;
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(lane < 16 && rank == pos);
+                    return static_cast<int>(__builtin_ctzll(m));
+                };
+                int j = env_at(wave);
                 int n_done = 0;
                 (void)n_done;
 #pragma unroll 1
@@ -850,8 +941,15 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                         unsigned long long* dsp = nullptr;
 #endif
                         qp_env_step(a.e, SJ + node * QS_WORDS, SJ + dstn * QS_WORDS, M.root_ex[j], M.words[j], M.xbits[j], action, 0, env_key, bj, lane,
-                                    nullptr, nullptr, rew, term, dsp);
+                                    nullptr, nullptr, rew, term, &M.task[j], dsp);
                         EAZ_QESTAMP(dsp, 14);
+#ifdef EAZ_FC_STAMPS
+                        if (step == 0 && blockIdx.x < 64 && s <= 64) {
+                            ps_wave_sync();
+                            if (lane == 0)
+                                g_qp_its[(blockIdx.x * 64 + (s - 1)) * 16 + j] = (4u * qp_hdr_hint(SJ[dstn * QS_WORDS + QS_HDR])) | ((4u * qp_hdr_hint(SJ[node * QS_WORDS + QS_HDR])) << 8) | 0x10000u;
+                        }
+#endif
                         if (lane == 0) { M.o_reward[j] = rew; M.o_term[j] = term; }  // rewards[b, current_player], single player
                     } else {
                         // vmap(auto_reset(env.step, env.init)) (selfplay.py:26-75,135) on the environment's current state
@@ -860,9 +958,9 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                         char* blob0 = (jlive && a.sp.out_states) ? a.sp.out_states + o * sizeof(eaz_subleq_state) : nullptr;
                         char* blob1 = (jlive && step == n_steps) ? a.sp.states + static_cast<long>(bj) * sizeof(eaz_subleq_state) : nullptr;
                         qp_env_step(a.e, M.root_state[j], M.root_state[j], M.root_ex[j], M.words[j], M.xbits[j], action, 1, env_key, bj, lane, blob0, blob1,
-                                    rew, term);
+                                    rew, term, &M.task[j]);
                     }
-                    j = claim();
+                    j = env_at(claim());
                 }
             }
             EAZ_QPSTAMP(5);
@@ -1073,7 +1171,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 const unsigned long long mem = qp_u64(sw[QS_MEM], sw[QS_MEM + 1]), inaf = qp_u64(sw[QS_INAF], sw[QS_INAF + 1]);
                 const unsigned long long outaf = qp_u64(sw[QS_OUTAF], sw[QS_OUTAF + 1]);
                 const uint32_t hdr = sw[QS_HDR];
-                const int task = qp_hdr_task(hdr);
+                const int task = M.task[ti];
                 const int branch = task - 1 < 0 ? 0 : (task - 1 > 5 ? 5 : task - 1);
                 const bool exroot = ((hdr >> 11) & 1u) != 0;
                 const unsigned long long exin = exroot ? qp_u64(M.root_ex[ti][0], M.root_ex[ti][1]) : kSq16Cases.v[branch][0][0];

@@ -85,3 +85,86 @@ tot = max(int(dh[:64].sum()), 1)
 print("select depth D over the first real steps of 64 workgroups (share of tree-simulations): " +
       "  ".join(f"D={d}: {100 * dh[d] / tot:.1f}%" for d in range(1, 16) if dh[d]))
 print("mean D by eighth of the search: " + "  ".join(f"{8 * dh[64 + i] / tot:.2f}" for i in range(8)))
+
+lib.eaz_diag_qp_ehist.argtypes = [C.c_void_p, C.c_int]
+eh = np.zeros(128, np.uint64)
+lib.eaz_diag_qp_ehist(eh.ctypes.data, 0)
+eh = eh.astype(np.int64)
+n = max(int(eh[0:4].sum()), 1)
+print(f"interpreter steps of the leaf env.step (64 workgroups, every simulation of the calls above): {n}; no run needed (the parent's runs never "
+      f"touched the new word): {100 * eh[0] / n:.1f}%; test cases run: " + "  ".join(f"{c}: {100 * eh[c] / n:.1f}%" for c in (1, 2, 3))
+      + f";  mean interpreted cycles per step {eh[100] / n:.1f}")
+
+
+def hist(name, h):
+    tot = max(int(h.sum()), 1)
+    cum = np.cumsum(h) / tot
+    print(f"   {name:48s} " + "  ".join(f"<{4 * (i + 1)}: {100 * cum[i]:.1f}%" for i in (0, 1, 2, 3, 5, 7, 11, 15, 23, 30)) + f"  >=124: {100 * h[31] / tot:.2f}%")
+
+
+hist("interpreted cycles of a whole step (all cases)", eh[4:36])
+hist("of test case 0 alone", eh[36:68])
+hist("of the steps that ran more than one case", eh[68:100])
+
+# cost model of one interpreter step: clocks between stamps 9 and 10 (program patch + test cases + interpreter) against the interpreted cycles
+x, y0, y1 = st[:, :, 15], st[:, :, 9], st[:, :, 10]
+ok = (x > 0) & (y0 > 0) & (y1 > 0)
+cyc, clk = (x[ok] - 1).astype(np.float64), (y1 - y0)[ok].astype(np.float64)
+if len(cyc) > 8:
+    A = np.stack([np.ones_like(cyc), cyc], 1)
+    coef, *_ = np.linalg.lstsq(A, clk, rcond=None)
+    print(f"interpreter segment of the stamped steps ({len(cyc)} samples): clocks = {coef[0]:.0f} + {coef[1]:.0f} x interpreted cycles (least squares); "
+          f"mean cycles {cyc.mean():.1f}, max {cyc.max():.0f}")
+    for lo, hi in ((0, 2), (2, 4), (4, 8), (8, 16), (16, 32), (32, 64), (64, 1000)):
+        m = (cyc >= lo) & (cyc < hi)
+        if m.any():
+            print(f"   cycles in [{lo}, {hi}): {m.sum():5d} steps, median {np.median(clk[m]):7.0f} clocks")
+
+lib.eaz_diag_qp_fine.argtypes = [C.c_void_p]
+fb = np.zeros(2048 * 8, np.uint64)
+lib.eaz_diag_qp_fine(fb.ctypes.data)
+fine = fb.reshape(256, 8, 8).astype(np.int64)
+raw = buf.reshape(256, 8, 16).astype(np.int64)
+okf = (fine[:, :, 0] > 0) & (fine[:, :, 1] > 0) & (fine[:, :, 2] > 0) & (raw[:, :, 9] > 0) & (raw[:, :, 10] > 0) & (raw[:, :, 15] > 0)
+short = okf & (raw[:, :, 15] - 1 <= 1)
+print(f"inside the interpreter segment, steps of <= 1 interpreted cycle ({short.sum()} samples):")
+for name, d in (("stamp 9 -> program patched", fine[:, :, 0] - raw[:, :, 9]), ("-> test vectors of case 0 in registers", fine[:, :, 1] - fine[:, :, 0]),
+                ("-> subleq16_wave_run returned", fine[:, :, 2] - fine[:, :, 1]), ("-> stamp 10 (loop exit)", raw[:, :, 10] - fine[:, :, 2])):
+    seg("   " + name, d[short])
+
+# interpreter work queue: what a better order could buy.  Cost model of one step from the regression above; 8 waves take the environments in
+# queue order (list scheduling), the phase ends with the last wave.
+lib.eaz_diag_qp_its.argtypes = [C.c_void_p]
+its = np.zeros(64 * 64 * 16, np.uint32)
+lib.eaz_diag_qp_its(its.ctypes.data)
+np.save(os.path.join(ROOT, "gpurun_out", "qp_its.npy"), its)
+its = its.reshape(64, 64, 16)
+okq = ((its >> 16) & 1).all(axis=2)
+cost, pcost = (its & 0xFF).astype(np.float64), ((its >> 8) & 0xFF).astype(np.float64)
+fixed, per = 4000.0, 423.0
+
+
+def wall(c, order):
+    t = np.zeros(8)
+    for j in order:
+        k = int(np.argmin(t))
+        t[k] += fixed + per * c[j]
+    return t.max()
+
+
+res = {"fifo": [], "lpt_true": [], "lpt_parent": [], "ideal": []}
+for w in range(64):
+    for sim in range(16, 64):
+        if not okq[w, sim]:
+            continue
+        c, pc = cost[w, sim], pcost[w, sim]
+        res["fifo"].append(wall(c, range(16)))
+        res["lpt_true"].append(wall(c, np.argsort(-c, kind="stable")))
+        res["lpt_parent"].append(wall(c, np.argsort(-pc, kind="stable")))
+        res["ideal"].append(max((16 * fixed + per * c.sum()) / 8, fixed + per * c.max()))
+if res["fifo"]:
+    print("modelled interpreter phase (clocks, simulations 16..63 of the first real step, 64 workgroups): " +
+          "  ".join(f"{k}: mean {np.mean(v):.0f}" for k, v in res.items()))
+    cc = np.corrcoef(cost[okq].reshape(-1), pcost[okq].reshape(-1))[0, 1]
+    print(f"correlation of a step's interpreted cycles with its parent's: {cc:.2f}")
+
