@@ -1288,6 +1288,15 @@ static int flush_expand(eaz_search* s, hipStream_t st) {
     return rc;
 }
 
+extern "C" int eaz_search_launch_info(const eaz_search* s, int* one_launch, int* lds_bytes) {
+    ARG_OK(s != nullptr);
+    const bool ds = s->persist_ok && g_persist;
+    const bool sq = !ds && g_persist == 1 && sqp_eligible(s);
+    if (one_launch) *one_launch = (ds || sq) ? 1 : 0;
+    if (lds_bytes) *lds_bytes = ds ? s->persist_lds : (sq ? s->sqp_lds : 0);
+    return 0;
+}
+
 extern "C" int eaz_search_run(eaz_search* s, void* stream) {
     ARG_OK(s != nullptr);
     if (s->persist_ok && g_persist && s->clear_pending && s->sims_done == 0 && s->pending_expand < 0) {

@@ -377,6 +377,12 @@ class Search:
     def run(self):
         check(_lib.load().eaz_search_run(self.h, _stream()))
 
+    def launch_info(self) -> dict:
+        """one_launch: selfplay() / run() are ONE kernel launch on LDS-resident trees for this search under the current tuning; lds_bytes of it."""
+        one, lds = C.c_int(), C.c_int()
+        check(_lib.load().eaz_search_launch_info(self.h, C.byref(one), C.byref(lds)))
+        return dict(one_launch=bool(one.value), lds_bytes=int(lds.value))
+
     def finish(self):
         act = torch.empty(self.B, dtype=torch.int32, device=self.device)
         aw = torch.empty(self.B, self.A, dtype=torch.float32, device=self.device)

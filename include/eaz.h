@@ -215,6 +215,14 @@ enum {
 /* device pointer + shape ([B,N], [B,N,A], [B,N,state_bytes], [B,A] or [B]; unused dims = 0) + element size */
 EAZ_API int eaz_search_tree_view(eaz_search* s, int field_id, void** d_ptr, int64_t shape[3], int* elem_bytes);
 
+/* Launch structure the library will use for this search under the current tuning (EAZ_TUNE_PERSIST): *one_launch = 1 when eaz_selfplay_run
+ * (the whole call) and eaz_search_run (all simulations) each run as ONE kernel launch on LDS-resident trees -- DeepSea + FC network with two
+ * actions (csrc/search_persist.hpp) or Subleq word_size 16, binary observations, FC network, XXHash novelty over the IO rows
+ * (csrc/search_subleq_persist.hpp), trees small enough for the 160 KiB of LDS -- and 0 when the per-simulation kernels (or, Subleq-16 with
+ * larger trees, csrc/search_subleq.hpp) serve it.  *lds_bytes = dynamic LDS of that launch (0 if none).  No reference counterpart: the
+ * reference's search is one XLA program whatever the sizes; tests and benchmarks use this to know which path they measured. */
+EAZ_API int eaz_search_launch_info(const eaz_search* s, int* one_launch, int* lds_bytes);
+
 /* ---- fused driver: selfplay()  src/selfplay.py:78-149 ------------------------------------------------------ */
 typedef struct {
     int selfplay_steps;               /* T, config.py:37 */
@@ -299,7 +307,7 @@ EAZ_API int eaz_profile_replay(eaz_search* s, int kernel_class, int iters, doubl
 /*   EAZ_TUNE_PERSIST     1 (default) = eaz_search_run runs all simulations in ONE launch, 16 trees per workgroup, where a kernel for it
  *                        exists, and eaz_selfplay_run the WHOLE call (T real steps) in one launch: DeepSea + FC network with two actions
  *                        whose trees fit into LDS (csrc/search_persist.hpp), and Subleq word_size 16 with binary observations + FC network
- *                        with the XXHash novelty over the IO rows (csrc/search_subleq_persist.hpp, trees of <= 81 nodes in LDS, for
+ *                        with the XXHash novelty over the IO rows (csrc/search_subleq_persist.hpp, trees of <= 71 nodes in LDS, for
  *                        both entry points; larger trees: csrc/search_subleq.hpp, eaz_search_run only); 2 = one launch per SEARCH only (Subleq-16: the per-real-step kernels
  *                        around csrc/search_subleq.hpp's kernel; DeepSea: as 1); 0 = tree kernel(s) + one forward per simulation.
  *                        eaz_search_simulate always uses the per-simulation kernels. */
