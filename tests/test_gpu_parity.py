@@ -170,7 +170,7 @@ def test_search_depth_limited_and_qtransform_options(oracle, eaz, torch, max_dep
     (8, 50, 24, 1.0, dict(var_backup=1), False),
     (32, 40, 64, 1.5, dict(bonus_after_rescale=True, var_backup=1, max_depth=9), False),
 ])
-def test_search_run_whole_tree(oracle, eaz, torch, G, B, S, beta_max, opts, masked):
+def test_search_run_whole_tree(oracle, eaz, torch, kernel_variant, G, B, S, beta_max, opts, masked):
     """begin -> run (all S simulations in one call) -> finish: every tree field, the embeddings, action and weights against the
     oracle.  Under the `persist` variant eligible cases are ONE launch of search_persist_kernel (trees in LDS); the other variants
     (and S = 70) loop the per-simulation kernels -- all of them must agree with the oracle."""
@@ -199,9 +199,18 @@ def test_search_run_whole_tree(oracle, eaz, torch, G, B, S, beta_max, opts, mask
                            two_players_game=okw["two_player"], epistemic_bonus_after_rescale=okw["bonus_after_rescale"],
                            epistemic_variance_backup=okw["var_backup"])
     cu = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    info = search.launch_info()
+    # DeepSea: EAZ_TUNE_PERSIST 1 and 2 both mean the one-launch kernel; S = 70: the trees of a workgroup no longer fit into LDS
+    assert info["one_launch"] == (kernel_variant in ("persist", "persist-step") and S <= 64), (info, S)
     for rep in range(2):  # the second search reuses the (dirty) tree buffers of the first
         search.begin(cu(logits), cu(v), cu(u), cu(blobs), cu(beta), cu(invalid), cu(g))
+        search.profile(True)
+        search.profile_read()
         search.run()
+        torch.cuda.synchronize()
+        prof = search.profile_read()
+        search.profile(False)
+        assert (prof["search"]["launches"] == 1 and prof["tree"]["launches"] == 0) == info["one_launch"], (prof, info)
         act, aw = search.finish()
         oact, oaw = otree.finish()
         exact = _compare_tree(search, otree, f"run rep={rep}")
