@@ -619,6 +619,7 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
                                      "bytes_per_simulation": gbytes,
                                      "note": "event pairs around the env-step (+ observation) launches of one simulation; interpreter / "
                                              "launch-latency bound, not bandwidth bound (DESIGN.md 4.4)"}
+    fields["launch_structure"] = search.launch_info()  # one_launch: the whole selfplay() call is ONE kernel launch (include/eaz.h eaz_search_launch_info)
     fields["kernel_ms_instrumented_pass"] = {k: round(v["ms"], 3) for k, v in prof.items()}
     fields["instrumented_pass_env_steps_per_s"] = B * T_instr * n_instr / dt_instr
     return dict(dt=dt, fields=fields)
