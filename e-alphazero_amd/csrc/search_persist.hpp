@@ -9,12 +9,14 @@
 // workgroup evaluates the network for exactly its own 16 leaves, so there is no hand-off between workgroups at all and the tree
 // statistics never leave LDS (north-star: "one wavefront walking one tree in LDS-resident child-index/visit/prior arrays").
 //
-// Workgroup = 320 threads:
+// Workgroup = 512 threads:
 //   waves 0-3  tree phase: 16 lanes per tree (lane j = level j of the recorded root-to-leaf path); forward: each wave owns 64 output
 //              columns of the hidden layers (v_mfma_f32_16x16x4_f32, one accumulation chain per output = the oracle's fmaf chain)
-//   wave 4     helper: W1 row gathers (layer 1) of heads 1 and 2 under layer 2 of the head before, novelty lookup of the 16 leaves, and at the
-//              end ((c0 + c1) + (c2 + c3)) + b and the head activations from the four quarter chains of layer 3, which waves 0-3 run as
-//              MFMA chains over their own hidden columns (a head's chain rides in the first round of the next head's layer 2)
+//   waves 4-7  helpers, one per SIMD: W1 row gathers (layer 1) of heads 1 and 2 under layer 2 of the head before (helper hw: rows 4 hw .. 4 hw + 3
+//              of the H1 tile -- one helper doing all 16 rows cost its SIMD partner 0.9 k cycles per head, which the other three MFMA waves
+//              then waited for at the head's barrier); wave 4 also: novelty lookup of the 16 leaves, and at the end ((c0 + c1) + (c2 + c3)) + b
+//              and the head activations from the four quarter chains of layer 3, which waves 0-3 run as MFMA chains over their own hidden
+//              columns (a head's chain rides in the first round of the next head's layer 2)
 //
 // Per simulation (all in LDS / registers, nothing but the weight stream and 16 W1 rows per head comes from L2):
 //   expand + backward of the previous leaf   lane 0 writes the new node; the path's levels are folded leaf-to-root: every lane computes
@@ -38,7 +40,8 @@
 namespace eaz {
 
 constexpr int kPsTrees = 16;     // trees per workgroup = rows of the forward tile
-constexpr int kPsThreads = 320;  // 4 tree / MFMA waves + 1 helper wave
+constexpr int kPsThreads = 512;  // 4 tree / MFMA waves + 4 helper waves (one per SIMD: the layer-1 work of the next head costs every MFMA wave a quarter
+                                  // instead of wave 0 all of it -- 0.9 k cycles of waiting at each head's barrier, profiles/r03_i_persist_stamps.txt)
 constexpr int kPsA = 2;          // actions (DeepSea)
 #ifndef EAZ_PS_DEPTH
 #define EAZ_PS_DEPTH 16
@@ -243,7 +246,8 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const bool helper = wave == 4;
+    const bool helper = wave >= 4;
+    const int hw = wave - 4;  // helper: rows 4 hw .. 4 hw + 3 of the next head's H1 tile
     const int tree0 = blockIdx.x * kPsTrees;
     // head order rotated per workgroup: at any moment the CUs of an XCD stream three different W2 matrices from L2 instead of all
     // hammering the same lines (the order in which the heads are evaluated does not enter any result)
@@ -314,9 +318,9 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
             EAZ_PSTAMP(0);
             __syncthreads();  // S0
             // W1 rows of the second head: in flight under layer 2 of the first (waves 0-3 issue nothing but their weight stream there)
-            floatx4 gw[16];
+            floatx4 gw[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) gw[i] = *reinterpret_cast<const floatx4*>(W1g[0] + static_cast<long>(M.hot[i]) * kFcH);
+            for (int i = 0; i < 4; ++i) gw[i] = *reinterpret_cast<const floatx4*>(W1g[0] + static_cast<long>(M.hot[4 * hw + i]) * kFcH);
             __syncthreads();  // S1
             EAZ_PSTAMP(4);
 #pragma unroll
@@ -327,19 +331,16 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
                     float* H1n = H1 + ((h + 1) & 1) * kF16HFloats;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
+                        floatx4 o;
 #pragma unroll
-                        for (int i4 = 0; i4 < 4; ++i4) {
-                            floatx4 o;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const float v = __builtin_fmaf(1.0f, gw[4 * i4 + i][c], 0.0f) + hb1[h][c];
-                                o[i] = v > 0.0f ? v : 0.0f;
-                            }
-                            *reinterpret_cast<floatx4*>(H1n + h16_off(4 * lane + c, 4 * i4)) = o;
+                        for (int i = 0; i < 4; ++i) {
+                            const float v = __builtin_fmaf(1.0f, gw[i][c], 0.0f) + hb1[h][c];
+                            o[i] = v > 0.0f ? v : 0.0f;
                         }
+                        *reinterpret_cast<floatx4*>(H1n + h16_off(4 * lane + c, 4 * hw)) = o;
                     }
                 }
-                if (h == 0 && lane < kPsTrees) {
+                if (h == 0 && hw == 0 && lane < kPsTrees) {
                     // novelty lookup of the one-hot observation (hashes.py:23-38,162-229): the hash index of a row that is zero except
                     // obs[hot] = 1 depends on `hot` only and is tabulated once per network (NetDev::hot_index)
                     const uint32_t index = a.net.hot_index[M.hot[lane]];
@@ -350,13 +351,13 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
                 if (h == 0) {
                     // W1 rows of the third head (its H1 tile is the first head's, free from here on)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) gw[i] = *reinterpret_cast<const floatx4*>(W1g[1] + static_cast<long>(M.hot[i]) * kFcH);
+                    for (int i = 0; i < 4; ++i) gw[i] = *reinterpret_cast<const floatx4*>(W1g[1] + static_cast<long>(M.hot[4 * hw + i]) * kFcH);
                 }
             }
             // ---- layer 3, second half + head activation, all three heads at once: lane = (row, output slot) with slot 0 = value, 1 = ube,
             // 2-3 = policy logits; ((c0 + c1) + (c2 + c3)) + b of the four quarter chains that waves 0-3 ran over their own hidden
             // columns (o_linear_parts) ----
-            {
+            if (hw == 0) {
                 const int row = lane & 15, slot = lane >> 4;
                 const int hid = slot < 2 ? slot : a.head[2], o = slot < 2 ? 0 : slot - 2;
                 const int hp = hidv[0] == hid ? 0 : (hidv[1] == hid ? 1 : 2);  // position of that head in this workgroup's order
