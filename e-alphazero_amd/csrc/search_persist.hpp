@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
     __syncthreads();
 
     // Both roles run the same barrier sequence per simulation:
-    //   S0 hot[] ready | S1 H1(head 0) | S2, S4, S6 layer-3 partial sums of head 0, 1, 2 (+ H1 of the next head) | S7 all head outputs
+    //   S1 hot[] + H1(head 0) | S2, S4, S6 layer-3 partial sums of head 0, 1, 2 (+ H1 of the next head) | S7 all head outputs
     if (helper) {
         // =========================================================== helper wave ===========================================================
         // layer-1 bias of the two heads whose W1 rows this wave gathers (lane = 4 columns)
@@ -316,13 +316,12 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
         for (int f = 0; f < n_fwd; ++f) {
             const int sim = fused ? f % (S + 1) - 1 : f;
             EAZ_PSTAMP(0);
-            __syncthreads();  // S0
+            __syncthreads();  // S1
+            EAZ_PSTAMP(4);
             // W1 rows of the second head: in flight under layer 2 of the first (waves 0-3 issue nothing but their weight stream there)
             floatx4 gw[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) gw[i] = *reinterpret_cast<const floatx4*>(W1g[0] + static_cast<long>(M.hot[4 * hw + i]) * kFcH);
-            __syncthreads();  // S1
-            EAZ_PSTAMP(4);
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
                 if (h < 2) {
@@ -387,8 +386,8 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
 #pragma unroll
             for (int c = 0; c < 4; ++c) b2r[h][c] = a.net.b[hidv[h] * 3 + 1][col + c];
         }
-        const float* W1p0 = a.net.w[hidv[0] * 3] + tid;  // first head's row gather: thread = column
-        const float b1r0 = a.net.b[hidv[0] * 3][tid];
+        const float* W1q0 = a.net.w[hidv[0] * 3] + 4 * lane;  // first head's row gather: lane = 4 columns, rows = this wave's trees
+        const floatx4 b1q0 = *reinterpret_cast<const floatx4*>(a.net.b[hidv[0] * 3] + 4 * lane);
         // the W2 stream, kPsDepth k-steps ahead (k-step ks of a head reads rows 4 ks + kq); cyclic over the heads, so the first k-steps of
         // the next simulation are in flight during the tree phase
         floatx4 Bq[kPsDepth];
@@ -584,25 +583,26 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
             }
             }  // sim >= 0
             EAZ_PSTAMP(3);
-            __syncthreads();  // S0: hot[], the leaf's reward / terminated flag
+            ps_wave_sync();  // hot[] of this wave's four trees
             // -------------------------------------------------------- forward of the 16 leaves --------------------------------------------
             {
-                // layer 1 of the first head: relu(W1[hot] + b1), thread = output column
-                float w1n[16];
+                // layer 1 of the first head: relu(W1[hot] + b1) for the rows of THIS wave's trees (4 wave .. 4 wave + 3), lane = 4 columns: no
+                // workgroup barrier between the select and the gather, four 16-byte loads per lane
+                floatx4 w1n[4];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) w1n[i] = W1p0[static_cast<long>(M.hot[i]) * kFcH];
+                for (int k = 0; k < 4; ++k) w1n[k] = *reinterpret_cast<const floatx4*>(W1q0 + static_cast<long>(M.hot[4 * wave + k]) * kFcH);
 #pragma unroll
-                for (int i4 = 0; i4 < 4; ++i4) {
+                for (int c = 0; c < 4; ++c) {
                     floatx4 o;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float v = __builtin_fmaf(1.0f, w1n[4 * i4 + i], 0.0f) + b1r0;
-                        o[i] = v > 0.0f ? v : 0.0f;
+                    for (int k = 0; k < 4; ++k) {
+                        const float v = __builtin_fmaf(1.0f, w1n[k][c], 0.0f) + b1q0[c];
+                        o[k] = v > 0.0f ? v : 0.0f;
                     }
-                    *reinterpret_cast<floatx4*>(H1 + h16_off(tid, 4 * i4)) = o;
+                    *reinterpret_cast<floatx4*>(H1 + h16_off(4 * lane + c, 4 * wave)) = o;
                 }
             }
-            __syncthreads();  // S1: H1 of head 0
+            __syncthreads();  // S1: H1 of head 0; hot[], the leaves' rewards / terminated flags
             EAZ_PSTAMP(4);
 #pragma unroll
             for (int h = 0; h < 3; ++h) {

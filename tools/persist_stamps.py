@@ -52,7 +52,7 @@ print(f"{len(st)} workgroups, simulation {S // 2}; wave 0:")
 seg("expand + backward", w0[:, 0], w0[:, 1])
 seg("re-score (D+1 nodes, one lane each)", w0[:, 1], w0[:, 2])
 seg("select walk + DeepSea step", w0[:, 2], w0[:, 3])
-seg("barrier S0 + W1 row gather + H1 store + barrier S1", w0[:, 3], w0[:, 4])
+seg("W1 row gather of the wave's own trees + H1 store + barrier S1", w0[:, 3], w0[:, 4])
 for h in range(3):
     seg(f"head {h}: layer 2 (256 MFMA per wave) + H2 round trip + quarter chain of layer 3", w0[:, 6 + 3 * h], w0[:, 7 + 3 * h])
     if h < 2:
