@@ -1833,6 +1833,18 @@ extern "C" __attribute__((visibility("default"))) int eaz_diag_qp_its(uint32_t* 
     HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_qp_its), sizeof(uint32_t) * 64 * 64 * 16));
     return 0;
 }
+extern "C" __attribute__((visibility("default"))) int eaz_diag_qp_fwd(unsigned long long* h_out /* [2048*8] */) {
+    ARG_OK(h_out != nullptr);
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_qp_fwd), sizeof(unsigned long long) * 2048 * 8));
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int eaz_diag_qp_rounds(unsigned long long* h_out /* [2048*32] */) {
+    ARG_OK(h_out != nullptr);
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_qp_rounds), sizeof(unsigned long long) * 2048 * 32));
+    return 0;
+}
 extern "C" __attribute__((visibility("default"))) int eaz_diag_qp_ehist(unsigned long long* h_out /* [128] */, int reset) {
     ARG_OK(h_out != nullptr);
     HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_qp_ehist), sizeof(unsigned long long) * 128));

@@ -1,6 +1,6 @@
 // search_subleq.hpp -- subleq16_search_kernel: every simulation of a Subleq-16 search in ONE launch on GLOBAL-MEMORY trees: round 2's C3
 // path.  Since round 3 search_subleq_persist.hpp runs both self-play and eaz_search_run on LDS trees; this kernel remains for trees
-// beyond that kernel's LDS limit (S > 70) and as the EAZ_TUNE_PERSIST = 2 variant the tests compare against.
+// beyond that kernel's LDS limit (S > 68) and as the EAZ_TUNE_PERSIST = 2 variant the tests compare against.
 //
 // Reference: the simulation loop of emctx [EXT] search as called from src/selfplay.py:107-117, with the recurrent fn
 // of src/context.py:117-155 (env.step of src/envs/subleq.py + forward of src/network/fully_connected.py:41-101).

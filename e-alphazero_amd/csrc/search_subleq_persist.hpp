@@ -80,8 +80,9 @@ struct QpMisc {
     float o_value[kQpTrees], o_ube[kQpTrees];
     float b3[20];                       // output biases: value, ube, the 16 policy logits
     float b12[3][2][kFcH];              // hidden-layer biases of the three heads (layer 1, layer 2)
-    unsigned long long xbits[kQpTrees][4];  // the 16 observations as bits: [row][p] bit i = input 64 p + i (subleq.py:88-98); the A operand of lane
-                                            // (row, kq) at k-step 16 p + i is bit 4 i + kq of word p
+    alignas(16) uint8_t obytes[kQpTrees][256];  // the 16 observations as layer-1 A operands: [row][64 kq + ks] = input 4 ks + kq of the row as an FP8 (OCP e4m3)
+                                                // byte, 0x38 = 1.0 or 0 (inputs 240..255: 0) -- lane (row, kq) reads its 64 k-steps as four 16-byte words and
+                                                // one v_cvt_pk_f32_fp8 makes the operands of TWO k-steps (subleq.py:88-98)
     uint8_t words[kQpTrees][48];        // row-words of the 16 observations in flight, 5 observation bits each (subleq.py:88-98)
 };
 constexpr int kQpPartLd = 20;  // quarter sums [4 waves][16 rows][kQpPartLd]: slot 0 value, 1 ube, 2..17 policy logits
@@ -151,6 +152,29 @@ __device__ unsigned long long g_qp_fine[2048 * 8];  // diagnostic build: raw sta
         }                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                             \
     } while (0)
+__device__ unsigned long long g_qp_fwd[2048 * 8];  // diagnostic build: stamps inside the forward of the stamped simulation, [workgroup * 8 + wave][8]: start, then
+                                                   // after layer 1 / layer 2 of head 0, 1, 2, end
+#define EAZ_QWSTAMP(i)                                                                                 \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        if (step == 0 && s == 1 + S / 2 && (tid & 63) == 0 && blockIdx.x < 256) {                      \
+            unsigned long long t_;                                                                     \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+            g_qp_fwd[(blockIdx.x * 8 + (tid >> 6)) * 8 + (i)] = t_;                                    \
+        }                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    } while (0)
+__device__ unsigned long long g_qp_rounds[2048 * 32];  // diagnostic build: stamps after every round of 16 k-steps of the stamped forward, [workgroup * 8 + wave][head * 8 + layer * 4 + round]
+#define EAZ_QRSTAMP(i)                                                                                 \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        if (step == 0 && s == 1 + S / 2 && (tid & 63) == 0 && blockIdx.x < 256) {                      \
+            unsigned long long t_;                                                                     \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+            g_qp_rounds[(blockIdx.x * 8 + (tid >> 6)) * 32 + (i)] = t_;                                \
+        }                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    } while (0)
 __device__ uint32_t g_qp_its[64 * 64 * 16];  // diagnostic build, first real step of workgroups 0..63: [workgroup][simulation][environment] = cost of the step | parent's cost << 8 | written << 16
 __device__ unsigned long long g_qp_ehist[128];  // diagnostic build: interpreter steps of workgroups 0..63 -- [0..3] by test cases run, [4..35] by interpreted cycles / 4 of
                                                  // the whole step, [36..67] of test case 0 alone, [68..99] of the steps that ran more than one case; [100] sum of cycles
@@ -159,6 +183,8 @@ __device__ unsigned long long g_qp_dhist[72];  // diagnostic build: histogram of
 #define EAZ_QPSTAMP(i)
 #define EAZ_QESTAMP(sp, i)
 #define EAZ_QFSTAMP(sp, i)
+#define EAZ_QWSTAMP(i)
+#define EAZ_QRSTAMP(i)
 #endif
 
 __device__ __forceinline__ unsigned long long qp_u64(uint32_t lo, uint32_t hi) { return static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32); }
@@ -199,9 +225,9 @@ __device__ __forceinline__ uint8_t qp_code(uint32_t v) { return static_cast<uint
 
 // The observation of a state, twice: the 48 row-words (memory | example_input | input_after | example_output | output_after,
 // subleq.py:679-707) as 5-bit codes for the novelty hash, and the 240 observation bits themselves (bit 5 w + j = bit j of row-word w's
-// code, subleq.py:88-98; inputs 240..255 zero) as four 64-bit words for layer 1.  Lane w < 48 computes the code of row-word w; bit k of
-// the observation is fetched from the lane that holds its word (ds_bpermute) and the 64 lanes' bits become a word by one ballot.
-__device__ __forceinline__ void qp_emit_obs(uint8_t* words, unsigned long long* xb, unsigned long long mem, unsigned long long exin, unsigned long long inaf,
+// code, subleq.py:88-98; inputs 240..255 zero) as FP8 bytes in layer 1's operand order (QpMisc::obytes).  Lane w < 48 computes the code of
+// row-word w; bit k of the observation is fetched from the lane that holds its word (ds_bpermute) and stored as its byte.
+__device__ __forceinline__ void qp_emit_obs(uint8_t* words, uint8_t* ob, unsigned long long mem, unsigned long long exin, unsigned long long inaf,
                                             unsigned long long exout, unsigned long long outaf, int lane) {
     uint32_t code = 0u;
     if (lane < 16) {
@@ -217,8 +243,7 @@ __device__ __forceinline__ void qp_emit_obs(uint8_t* words, unsigned long long* 
         const int k = 64 * p + lane;
         const int w = (k * 52429) >> 18, j = k - 5 * w;  // k / 5 for k < 2^14
         const uint32_t c = static_cast<uint32_t>(__shfl(static_cast<int>(code), w < 48 ? w : 0));
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(w < 48 && ((c >> j) & 1u) != 0);
-        if (lane == 0) xb[p] = m;
+        ob[64 * (k & 3) + (k >> 2)] = (w < 48 && ((c >> j) & 1u) != 0) ? static_cast<uint8_t>(0x38) : static_cast<uint8_t>(0);
     }
 }
 
@@ -226,10 +251,20 @@ __device__ __forceinline__ void qp_emit_obs(uint8_t* words, unsigned long long* 
 // every k-step followed by the refill of its registers.  ABITS: layer 1, A operand = a bit of `abits` as a float; otherwise layer 2,
 // A operands from the H1 tile kPsARing k-steps ahead.  CHAIN: the round also carries the 16 dependent MFMAs of the previous head's
 // layer-3 quarter chain (A from the H2 columns this wave wrote, B = `w3` in registers).
+// layer 1: the A operands of a round's 16 k-steps are the 16 FP8 bytes of one uint4 of QpMisc::obytes; one v_cvt_pk_f32_fp8 converts two of
+// them.  Every VALU instruction between the MFMAs of this loop costs ~18 clocks (it waits for the matrix pipe's passes): with a v_bfe + v_cvt
+// pair per k-step on the observation's bits a layer-1 round took 2 650 clocks against 2 176 for a layer-2 round, whose operand is a ds_read.
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ floatx2 qp_abytes2(const uint4& w, const int i /* even k-step of the round */) {
+    const uint32_t d = (i >> 2) == 0 ? w.x : ((i >> 2) == 1 ? w.y : ((i >> 2) == 2 ? w.z : w.w));
+    return (i & 2) ? __builtin_amdgcn_cvt_pk_f32_fp8(static_cast<int>(d), true) : __builtin_amdgcn_cvt_pk_f32_fp8(static_cast<int>(d), false);
+}
+constexpr int kQpAAhead = 2;  // layer 1: a pair of A operands is converted this many k-steps before the MFMAs that read them (ring av[])
 template <bool CHAIN, bool ABITS>
-__device__ __forceinline__ void qp_round(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDepth], float (&av)[kPsARing], const float* apn, const unsigned long long abits,
-                                         __amdgpu_buffer_rsrc_t rs, int voff, int sbase, floatx4& a3, const float* hpA, const float (&w3)[16]) {
-    static_assert(kPsDepth == 16, "a round is 16 k-steps");
+__device__ __forceinline__ void qp_round(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDepth], float (&av)[kPsARing], const float* apn, const uint4 abits,
+                                         const uint4 abits_next, __amdgpu_buffer_rsrc_t rs, int voff, int sbase, floatx4& a3, const float* hpA,
+                                         const float (&w3)[16]) {
+    static_assert(kPsDepth == 16 && kPsDepth % kPsARing == 0 && kQpAAhead < kPsARing, "a round is 16 k-steps; the operand ring runs on across rounds");
     float cha[kChRing];
     if constexpr (CHAIN) {
 #pragma unroll
@@ -237,8 +272,8 @@ __device__ __forceinline__ void qp_round(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDep
     }
 #pragma unroll
     for (int i = 0; i < kPsDepth; ++i) {
-        // layer 1: `abits` = the round's observation word >> kq, the A operand of k-step i is its bit 4 i
-        const float aop = ABITS ? static_cast<float>(((i < 8 ? static_cast<uint32_t>(abits) : static_cast<uint32_t>(abits >> 32)) >> (4 * (i & 7))) & 1u) : av[i % kPsARing];
+        // layer 1: av[] holds the operands of k-steps i .. i + kQpAAhead - 1 on entry (of this round; the last k-steps fill in the next round's)
+        const float aop = av[i % kPsARing];
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, Bq[i][c], acc[c], 0, 0, 0);
         if constexpr (CHAIN) {
@@ -246,7 +281,15 @@ __device__ __forceinline__ void qp_round(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDep
             if (i + kChRing < 16) cha[i % kChRing] = hpA[68 * (i + kChRing)];
         }
         Bq[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sbase + i * 4096, 0));
-        if constexpr (!ABITS) av[i % kPsARing] = apn[i * 68];
+        if constexpr (ABITS) {
+            if ((i & 1) == 0) {
+                const floatx2 f = i + kQpAAhead < kPsDepth ? qp_abytes2(abits, i + kQpAAhead) : qp_abytes2(abits_next, i + kQpAAhead - kPsDepth);
+                av[(i + kQpAAhead) % kPsARing] = f[0];
+                av[(i + kQpAAhead + 1) % kPsARing] = f[1];
+            }
+        } else {
+            av[i % kPsARing] = apn[i * 68];
+        }
         __builtin_amdgcn_sched_barrier(0);  // keep every refill right behind the k-step that freed its registers
     }
 }
@@ -255,7 +298,7 @@ __device__ __forceinline__ void qp_round(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDep
 // wavefront-uniform.  mode 0: plain step (search), 1: auto_reset(env.step, env.init) (selfplay.py:26-75), as subleq16_wave_body.
 // blob: also the 336-byte state of include/eaz.h (real steps); words: the observation's row-words.  Returns the reward / terminated flag.
 __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src, uint32_t* dst, const uint32_t* root_ex, uint8_t* words,
-                                            unsigned long long* xb, const int action, const int mode, const Key envkey, const int b, const int lane, char* blob0,
+                                            uint8_t* xb, const int action, const int mode, const Key envkey, const int b, const int lane, char* blob0,
                                             char* blob1, float& reward_out, int& term_out, int16_t* tree_task, unsigned long long* dstamp = nullptr) {
     EAZ_QESTAMP(dstamp, 8);
     uint32_t s[QS_WORDS];
@@ -542,7 +585,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             M.root_ex[j][0] = static_cast<uint32_t>(exin); M.root_ex[j][1] = static_cast<uint32_t>(exin >> 32);
             M.root_ex[j][2] = static_cast<uint32_t>(exout); M.root_ex[j][3] = static_cast<uint32_t>(exout >> 32);
         }
-        qp_emit_obs(M.words[j], M.xbits[j], mem, exin, inaf, exout, outaf, lane);
+        qp_emit_obs(M.words[j], M.obytes[j], mem, exin, inaf, exout, outaf, lane);
     }
     {
         // per-tree scalars of the whole launch; search only: the root the caller prepared (eaz_search_begin -> tree_root_kernel: masked prior
@@ -940,7 +983,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
 #else
                         unsigned long long* dsp = nullptr;
 #endif
-                        qp_env_step(a.e, SJ + node * QS_WORDS, SJ + dstn * QS_WORDS, M.root_ex[j], M.words[j], M.xbits[j], action, 0, env_key, bj, lane,
+                        qp_env_step(a.e, SJ + node * QS_WORDS, SJ + dstn * QS_WORDS, M.root_ex[j], M.words[j], M.obytes[j], action, 0, env_key, bj, lane,
                                     nullptr, nullptr, rew, term, &M.task[j], dsp);
                         EAZ_QESTAMP(dsp, 14);
 #ifdef EAZ_FC_STAMPS
@@ -957,7 +1000,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                         const long o = static_cast<long>(step - 1) * B + bj;
                         char* blob0 = (jlive && a.sp.out_states) ? a.sp.out_states + o * sizeof(eaz_subleq_state) : nullptr;
                         char* blob1 = (jlive && step == n_steps) ? a.sp.states + static_cast<long>(bj) * sizeof(eaz_subleq_state) : nullptr;
-                        qp_env_step(a.e, M.root_state[j], M.root_state[j], M.root_ex[j], M.words[j], M.xbits[j], action, 1, env_key, bj, lane, blob0, blob1,
+                        qp_env_step(a.e, M.root_state[j], M.root_state[j], M.root_ex[j], M.words[j], M.obytes[j], action, 1, env_key, bj, lane, blob0, blob1,
                                     rew, term, &M.task[j]);
                     }
                     j = env_at(claim());
@@ -998,9 +1041,10 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
 #pragma unroll
                 for (int qq = 0; qq < 16; ++qq) { const float wv = pwv[4 * qq]; w3v[qq] = fr < 2 ? wv : 0.0f; }
             }
-            const unsigned long long* xrow = M.xbits[fr];  // this lane's layer-1 A operands: bit 4 i + kq of word p = input 64 p + 4 i + kq of row r
+            const uint4* xrow = reinterpret_cast<const uint4*>(&M.obytes[fr][64 * fkq]);  // this lane's layer-1 A operands: four rounds of 16 FP8 bytes
             const float* hpA = H2 + h16_off(fn0 + fkq, fr);  // quarter chain: H2[h16_off(n0 + 4 q + kq, r)] = hpA[68 q]
             float av[kPsARing];
+            EAZ_QWSTAMP(0);
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
                 floatx4 acc[4];
@@ -1009,8 +1053,14 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 floatx4 a3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
                 // ---- layer 1: [16 x 256] x [256 x 256], inputs 240..255 zero on both sides (exact); the first round carries the quarter chain
                 // of the head before ----
-                if (h > 0) qp_round<true, true>(acc, Bq, av, nullptr, xrow[0] >> fkq, W1r[h], fvoff, 4096 * kPsDepth, a3, hpA, w3v);
-                else qp_round<false, true>(acc, Bq, av, nullptr, xrow[0] >> fkq, W1r[h], fvoff, 4096 * kPsDepth, a3, hpA, w3v);
+                uint4 xcur = xrow[0], xnext = xrow[1];
+                {
+                    const floatx2 f = qp_abytes2(xcur, 0);
+                    av[0] = f[0]; av[1] = f[1];
+                }
+                if (h > 0) qp_round<true, true>(acc, Bq, av, nullptr, xcur, xnext, W1r[h], fvoff, 4096 * kPsDepth, a3, hpA, w3v);
+                else qp_round<false, true>(acc, Bq, av, nullptr, xcur, xnext, W1r[h], fvoff, 4096 * kPsDepth, a3, hpA, w3v);
+                EAZ_QRSTAMP(h * 8);
                 if (h > 0 && fr == h - 1) {  // head 0 = value: output column 0, head 1 = ube: column 1 (shared W3 registers)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) part[(fw * 16 + 4 * fkq + reg) * kQpPartLd + fr] = a3[reg];
@@ -1023,9 +1073,13 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
 #pragma unroll 1
                 for (int rd = 1; rd < 4; ++rd) {
                     const bool same = rd < 3;  // the refills of the last round are the first k-steps of layer 2
-                    qp_round<false, true>(acc, Bq, av, nullptr, xrow[rd] >> fkq, same ? W1r[h] : W2r[h], fvoff,
+                    xcur = xnext;
+                    xnext = xrow[same ? rd + 1 : 3];  // (the last round converts nothing of it that is used: layer 2 refills the ring)
+                    qp_round<false, true>(acc, Bq, av, nullptr, xcur, xnext, same ? W1r[h] : W2r[h], fvoff,
                                           same ? 4096 * kPsDepth * (rd + 1) : 0, a3, hpA, w3v);
+                    EAZ_QRSTAMP(h * 8 + rd);
                 }
+                EAZ_QWSTAMP(1 + 2 * h);
                 {
                     float* Ht = H1 + (h & 1) * kF16HFloats;
                     const floatx4 bb1 = *reinterpret_cast<const floatx4*>(&M.b12[h][0][fcol]);
@@ -1052,9 +1106,11 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 for (int rd = 0; rd < 4; ++rd) {
                     const bool same = rd < 3;
                     // reads past k-step 63 land in the next tile and are never used
-                    qp_round<false, false>(acc2, Bq, av, Ap + (rd * kPsDepth + kPsARing) * 68, 0ull, same ? W2r[h] : W1r[h == 2 ? 0 : h + 1], fvoff,
+                    qp_round<false, false>(acc2, Bq, av, Ap + (rd * kPsDepth + kPsARing) * 68, uint4{}, uint4{}, same ? W2r[h] : W1r[h == 2 ? 0 : h + 1], fvoff,
                                            same ? 4096 * kPsDepth * (rd + 1) : 0, a3, hpA, w3v);
+                    EAZ_QRSTAMP(h * 8 + 4 + rd);
                 }
+                EAZ_QWSTAMP(2 + 2 * h);
                 const floatx4 bb2 = *reinterpret_cast<const floatx4*>(&M.b12[h][1][fcol]);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {

@@ -307,7 +307,7 @@ EAZ_API int eaz_profile_replay(eaz_search* s, int kernel_class, int iters, doubl
 /*   EAZ_TUNE_PERSIST     1 (default) = eaz_search_run runs all simulations in ONE launch, 16 trees per workgroup, where a kernel for it
  *                        exists, and eaz_selfplay_run the WHOLE call (T real steps) in one launch: DeepSea + FC network with two actions
  *                        whose trees fit into LDS (csrc/search_persist.hpp), and Subleq word_size 16 with binary observations + FC network
- *                        with the XXHash novelty over the IO rows (csrc/search_subleq_persist.hpp, trees of <= 71 nodes in LDS, for
+ *                        with the XXHash novelty over the IO rows (csrc/search_subleq_persist.hpp, trees of <= 69 nodes in LDS, for
  *                        both entry points; larger trees: csrc/search_subleq.hpp, eaz_search_run only); 2 = one launch per SEARCH only (Subleq-16: the per-real-step kernels
  *                        around csrc/search_subleq.hpp's kernel; DeepSea: as 1); 0 = tree kernel(s) + one forward per simulation.
  *                        eaz_search_simulate always uses the per-simulation kernels. */

@@ -235,8 +235,8 @@ def test_subleq_word_sizes_that_are_not_multiples_of_four(oracle, eaz, torch, W,
 
 @pytest.mark.parametrize("case", [
     dict(B=1, S=8, T=3),                                                        # a single environment: 15 of the workgroup's trees mirror it
-    dict(B=17, S=70, T=2),                                                      # the largest trees whose workgroup set fits into LDS (71 nodes)
-    dict(B=17, S=71, T=2),                                                      # one more: the call falls back to the per-search kernels
+    dict(B=17, S=68, T=2),                                                      # the largest trees whose workgroup set fits into LDS (69 nodes)
+    dict(B=17, S=69, T=2),                                                      # one more: the call falls back to the per-search kernels
     dict(B=33, S=16, T=15, rescale=False, gumbel_scale=0.5, max_considered=4),  # qtransform / root-selection options
     dict(B=20, S=12, T=14, two_player=True),                                    # negated discount (context.py:143) in the node records
     dict(B=24, S=16, T=15, reward_fn="lowest_bytes", explicit_gumbel=True, tasks=(1, 5)),
@@ -262,7 +262,7 @@ def test_subleq16_one_launch_selfplay_edges(oracle, eaz, torch, case, kernel_var
     search = engine.Search(env, net, B, S, discount=0.97, two_players_game=c.get("two_player", False), rescale_values=c.get("rescale", True),
                            gumbel_scale=c.get("gumbel_scale", 1.0), max_num_considered_actions=c.get("max_considered", 16))
     if kernel_variant == "persist":
-        assert search.launch_info()["one_launch"] == (S <= 70), (search.launch_info(), S)  # the LDS limit is where the docs say it is
+        assert search.launch_info()["one_launch"] == (S <= 68), (search.launch_info(), S)  # the LDS limit is where the docs say it is
     st = env.init(B, key=19)
     ost = oenv.init(B, key=(19, 0))
     gum = oracle.gumbel((8, 1), T * B * W).reshape(T, B, W) if explicit else None

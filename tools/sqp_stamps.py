@@ -63,6 +63,36 @@ seg("E: interpreters of one wave (work queue)", diff(4, 5))
 seg("E: slowest wave of the workgroup", (st[:, :, 5] - st[:, :, 4]).max(axis=1))
 seg("E -> F barrier (wait for the slowest wave)", diff(5, 6))
 seg("F: observation tile + three heads in turn", diff(6, 7))
+# F by XCD (workgroup b runs on XCD b % 8 when the grid is 256 workgroups on 256 CUs) and by position inside the XCD: is the spread a property of
+# the place (L2 slice, clocks) or of the moment?
+if len(st) == 256:
+    print("   F by wave (median of stamp 6 -> 7): " + "  ".join(f"w{w}: {np.median(st[:, w, 7] - st[:, w, 6]):.0f}" for w in range(8)))
+    print("   arrival at stamp 7 relative to the workgroup's first wave there (median): " +
+          "  ".join(f"w{w}: {np.median(st[:, w, 7] - st[:, :, 7].min(axis=1)):.0f}" for w in range(8)))
+    fw0 = (st[:, 0, 7] - st[:, 0, 6])
+    print("   F of wave 0 by XCD (median): " + "  ".join(f"{x}: {np.median(fw0[x::8]):.0f}" for x in range(8)))
+    starts = st[:, 0, 6] - st[:, 0, 6].min()
+    print(f"   start of F relative to the earliest workgroup: median {np.median(starts):.0f}, p90 {np.percentile(starts, 90):.0f}; "
+          f"correlation of F's duration with its start {np.corrcoef(starts, fw0)[0, 1]:.2f}")
+lib.eaz_diag_qp_fwd.argtypes = [C.c_void_p]
+fwb = np.zeros(2048 * 8, np.uint64)
+lib.eaz_diag_qp_fwd(fwb.ctypes.data)
+fw = fwb.reshape(256, 8, 8).astype(np.int64)[:, 0, :]
+if (fw[:, :7] > 0).all():
+    print("   inside F, wave 0 (median): " + "  ".join(
+        f"head {h}: layer 1 {np.median(fw[:, 1 + 2 * h] - (fw[:, 2 * h] if h == 0 else fw[:, 2 * h])):.0f}, layer 2 (+ H1 tile, barrier) {np.median(fw[:, 2 + 2 * h] - fw[:, 1 + 2 * h]):.0f};"
+        for h in range(3)) + f"  after the last layer 2 -> stamp 7: {np.median(st[:, 0, 7] - fw[:, 6]):.0f}")
+lib.eaz_diag_qp_rounds.argtypes = [C.c_void_p]
+rb = np.zeros(2048 * 32, np.uint64)
+lib.eaz_diag_qp_rounds(rb.ctypes.data)
+rr = rb.reshape(256, 8, 32).astype(np.int64)[:, 0, :]
+if (rr[:, :24] > 0).all() and (fw[:, :7] > 0).all():
+    for h in range(3):
+        prev = fw[:, 2 * h]  # F start / end of layer 2 of the head before
+        l1 = [np.median(rr[:, h * 8] - prev)] + [np.median(rr[:, h * 8 + r] - rr[:, h * 8 + r - 1]) for r in range(1, 4)]
+        l2 = [np.median(rr[:, h * 8 + 4] - fw[:, 1 + 2 * h])] + [np.median(rr[:, h * 8 + 4 + r] - rr[:, h * 8 + 3 + r]) for r in range(1, 4)]
+        print(f"   head {h}, wave 0, clocks per round of 16 k-steps (floor 2048): layer 1 " + " ".join(f"{x:.0f}" for x in l1) +
+              "   | H1 tile + barrier + layer 2 " + " ".join(f"{x:.0f}" for x in l2))
 t0 = st[:, :, 0].min(axis=1)
 seg("T (first wave in -> last wave at the T/E barrier)", st[:, :, 4].max(axis=1) - t0)
 seg("E (barrier to barrier)", st[:, :, 6].max(axis=1) - st[:, :, 4].max(axis=1))
