@@ -114,9 +114,14 @@ __device__ __forceinline__ void rn_conv(floatx4 (&acc)[kRnMT][4], const ResNetDe
 __device__ __forceinline__ void rn_conv64(floatx4 (&acc)[kRnMT][4], const ResNetDev& n, const float* U, const float* Wc, const RnLane& L, int lane) {
     const int r = lane & 15, kq = lane >> 4, col = 4 * r;
     BGroup b0, b1;
+    // weights through a buffer resource: the lane's part of the address (row kq, columns col .. col + 3) never changes and the k-step goes into
+    // the scalar offset -- a global_load needs three 64-bit VALU instructions per refill, and every VALU instruction between the MFMAs of this
+    // loop costs the matrix pipe ~18 clocks
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wc), 0, 9 * kRnC * kRnC * 4, 0x00020000);
+    const int wvoff = (kq * kRnC + col) * 4;
     auto load_b = [&](BGroup& b, int ks0) {
 #pragma unroll
-        for (int i = 0; i < kFcG; ++i) b.v[i] = *reinterpret_cast<const floatx4*>(Wc + static_cast<long>(4 * (ks0 + i) + kq) * kRnC + col);
+        for (int i = 0; i < kFcG; ++i) b.v[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff, (ks0 + i) * (4 * kRnC * 4), 0));
     };
     auto compute = [&](const BGroup& b, const float* const (&src)[kRnMT], int half) {
 #pragma unroll

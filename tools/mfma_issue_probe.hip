@@ -16,9 +16,9 @@ typedef int intx4 __attribute__((ext_vector_type(4)));
 
 constexpr int kDepth = 16;
 
-template <int WAVES>
+template <int WAVES, int VAR>
 __global__ void __launch_bounds__(64 * WAVES) probe(const float* W, float* out, int heads, unsigned long long* clocks) {
-    __shared__ float At[64 * 68 + 64];
+    __shared__ __attribute__((aligned(16))) float At[64 * 68 + 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 64 * 68 + 64; i += blockDim.x) At[i] = 0.001f * static_cast<float>((i * 37) & 255);
     __syncthreads();
@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(64 * WAVES) probe(const float* W, float* out, 
     for (int c = 0; c < NT; ++c) acc[c] = floatx4{0, 0, 0, 0};
     const float* ap = At + lane;
     unsigned long long t0 = 0, t1 = 0;
-    if constexpr (WAVES == 4) {
+    if constexpr (WAVES == 4 && VAR == 0) {
         floatx4 Bq[kDepth];
         for (int i = 0; i < kDepth; ++i) Bq[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, i * 4096, 0));
         float av[4];
@@ -47,6 +47,32 @@ __global__ void __launch_bounds__(64 * WAVES) probe(const float* W, float* out, 
                     for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i % 4], Bq[i][c], acc[c], 0, 0, 0);
                     Bq[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sbase + i * 4096, 0));
                     av[i % 4] = apn[(i % 12) * 68];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    } else if constexpr (WAVES == 4 && VAR != 0) {
+        // VAR 1: A operands as one ds_read_b128 per FOUR k-steps; VAR 2: no A operand reads (register constant); VAR 3: no weight refills
+        floatx4 Bq[kDepth];
+        for (int i = 0; i < kDepth; ++i) Bq[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, i * 4096, 0));
+        const floatx4* ap4 = reinterpret_cast<const floatx4*>(At) + lane;
+        floatx4 a4[2] = {ap4[0], ap4[64]};
+        float a1 = At[lane];
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+        for (int h = 0; h < heads; ++h) {
+            const int hb = (h % 3) * 262144;
+#pragma unroll 1
+            for (int r = 0; r < 4; ++r) {
+                const int sbase = hb + ((r + 1) & 3) * 65536;
+#pragma unroll
+                for (int i = 0; i < kDepth; ++i) {
+                    const float aop = VAR == 1 ? a4[(i >> 2) & 1][i & 3] : a1;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, Bq[i][c], acc[c], 0, 0, 0);
+                    if (VAR != 3) Bq[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sbase + i * 4096, 0));
+                    if (VAR == 1 && (i & 3) == 3) a4[(i >> 2) & 1] = ap4[64 * (((i >> 2) + 2 + 4 * r) & 15)];
+                    if (VAR == 3) a1 = At[lane + 68 * (i & 7)];
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -94,13 +120,16 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < hw.size(); ++i) hw[i] = 1e-3f * static_cast<float>((i * 2654435761u) >> 24);
     HIP_OK(hipMemcpy(W, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
     std::vector<unsigned long long> hc(grid * 8);
-    for (int variant : {4, 8, 4, 8}) {
+    for (int variant : {4, 8, 41, 42, 43, 4, 41}) {
         HIP_OK(hipMemset(clk, 0, grid * 8 * 8));
         hipEvent_t e0, e1;
         HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
         HIP_OK(hipEventRecord(e0));
-        if (variant == 4) probe<4><<<grid, 256>>>(W, out, heads, clk);
-        else probe<8><<<grid, 512>>>(W, out, heads, clk);
+        if (variant == 4) probe<4, 0><<<grid, 256>>>(W, out, heads, clk);
+        else if (variant == 41) probe<4, 1><<<grid, 256>>>(W, out, heads, clk);
+        else if (variant == 42) probe<4, 2><<<grid, 256>>>(W, out, heads, clk);
+        else if (variant == 43) probe<4, 3><<<grid, 256>>>(W, out, heads, clk);
+        else probe<8, 0><<<grid, 512>>>(W, out, heads, clk);
         HIP_OK(hipEventRecord(e1));
         HIP_OK(hipDeviceSynchronize());
         float ms = 0;
@@ -109,8 +138,8 @@ int main(int argc, char** argv) {
         std::vector<double> per;
         for (int i = 0; i < grid * 8; ++i) if (hc[i]) per.push_back(static_cast<double>(hc[i]) / heads);
         std::sort(per.begin(), per.end());
-        printf("%d waves per workgroup: %8.0f shader-clock ticks (s_memtime, 100 MHz) per head median, i.e. %.1f us per head; launch %.3f ms = %.2f us per head; floor 8192 MFMA cycles\n",
-               variant, per[per.size() / 2], 0.01 * per[per.size() / 2], ms, 1e3 * ms / heads);
+        printf("variant %2d (4 / 8 = waves per workgroup; 41 = A operands by ds_read_b128 per four k-steps, 42 = no A reads, 43 = no weight refills): %6.0f clocks per head (median), launch %.3f ms = %.2f us per head; floor 8192\n",
+               variant, per[per.size() / 2], ms, 1e3 * ms / heads);
     }
     return 0;
 }
