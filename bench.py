@@ -602,7 +602,7 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
             "status": "retired for this configuration",
             "why": "Subleq-16: the search kernel keeps every node's state in LDS (32 bytes: the program as sixteen 4-bit words, input_after / "
                    "output_after, a header), steps the chosen edge with its all-scalar interpreter LDS to LDS, and hands the forward the observation "
-                   "as 240 bits per row -- no gather launch, no state or observation traffic to HBM in the timed path (DESIGN.md 4.4)"}
+                   "as 256 operand bytes per row in LDS -- no gather launch, no state or observation traffic to HBM in the timed path (DESIGN.md 4.4)"}
     elif prof["gather"]["launches"] == 0:
         fields["leaf_gather"] = {
             "status": "retired for this configuration",

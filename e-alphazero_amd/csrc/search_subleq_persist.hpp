@@ -25,9 +25,9 @@
 //   F  the forward of the three heads self-play reads for the 16 new observations, heads in turn on waves 0-3 (wave w owns 64 hidden
 //      columns) with the weight stream of search_persist.hpp: ONE continuous buffer-load stream W1(h) | W2(h) | W1(h+1) ... 16 k-steps
 //      ahead in registers, cyclic over the heads, so the first k-steps of the next simulation are in flight during T and E.  The
-//      observation never becomes a tile: a Subleq observation is 240 bits, the interpreter's wave leaves them as four 64-bit masks per
-//      row (mask kq, bit ks = input 4 ks + kq: exactly the A operands lane (row, kq) feeds to k-step ks), and layer 1's A operand is
-//      `(float)((mask >> ks) & 1)` -- no LDS traffic in layer 1 at all.  Layer 3 = quarter chains whose operands W3 stay in registers
+//      observation never becomes an f32 tile: a Subleq observation is 240 bits, the interpreter's wave leaves them as 256 FP8 bytes per
+//      row (0x38 = 1.0) in the operand order of the MFMA lanes (QpMisc::obytes), a lane reads the 16 k-steps of a round as one 16-byte
+//      word and one v_cvt_pk_f32_fp8 makes the A operands of two k-steps.  Layer 3 = quarter chains whose operands W3 stay in registers
 //      for the whole launch; a head's chain rides in a round of the next head (ps_round).  The heads' outputs are never
 //      materialised: expand / root preparation read the four quarter sums and apply ((c0 + c1) + (c2 + c3)) + b themselves.
 // Same float operations in the same order as tree_step_kernel<16,1> / fc16p_forward_kernel (the 16-slot butterfly sum is
