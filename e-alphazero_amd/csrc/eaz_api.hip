@@ -280,6 +280,7 @@ extern "C" int eaz_env_info(const eaz_env* env, int* kind, int* num_actions, int
 
 // mode: 0 step, 1 auto-reset step, 2 init.  src/dst: plain [B] batches.
 // mover_reward (optional): rewards[b, current_player before the step] of the new states
+static int g_subleq_wave = [] { const char* e = std::getenv("EAZ_SUBLEQ_WAVE"); return e ? std::atoi(e) : 1; }();  // word sizes other than 16: wavefront per environment (1) or lane per environment (0)
 // environments per one-wavefront workgroup of subleq_step_kernel: spread until the launch has a workgroup per CU
 static int subleq_envs_per_wg(int B) {
     int epw = 64;
@@ -307,10 +308,15 @@ static int env_step_launch(eaz_env* env, int B, const void* in, const int32_t* a
             subleq16_wave_kernel<<<B, 64, 0, st>>>(env->dev, src, dst, action, B, mode, key, d_key, static_cast<char*>(out_copy), mover_reward,
                                                    nullptr, nullptr, 256, nullptr, NoveltyFuse{nullptr, nullptr, 0, 0.0f});
         } else {
-            const int epw = subleq_envs_per_wg(B);
-            subleq_step_kernel<<<cdiv(B, epw), 64, subleq_lds_bytes(env->dev.W), st>>>(env->dev, src, dst, action, B, mode, key, d_key,
-                                                                                      static_cast<char*>(out_copy), mover_reward, nullptr, nullptr,
-                                                                                      epw, 256);
+            if (g_subleq_wave) {  // one wavefront per environment (default)
+                subleq_wave_kernel<<<B, 64, 0, st>>>(env->dev, src, dst, action, B, mode, key, d_key, static_cast<char*>(out_copy), mover_reward, nullptr,
+                                                     nullptr);
+            } else {
+                const int epw = subleq_envs_per_wg(B);
+                subleq_step_kernel<<<cdiv(B, epw), 64, subleq_lds_bytes(env->dev.W), st>>>(env->dev, src, dst, action, B, mode, key, d_key,
+                                                                                          static_cast<char*>(out_copy), mover_reward, nullptr, nullptr,
+                                                                                          epw, 256);
+            }
         }
         LAUNCH_OK();
     } else {
@@ -1223,6 +1229,9 @@ static int recurrent_launch(eaz_search* s, hipStream_t st) {
                 subleq16_wave_kernel<<<B, 64, 0, st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0}, nullptr, nullptr, s->d_next_reward,
                                                        s->d_next_term, s->d_next_legal, 16, fused_obs ? s->d_obs : nullptr,
                                                        NoveltyFuse{nd.bitset, novelty_done ? s->d_novelty : nullptr, nd.hash_bits, nd.nov_scale});
+            else if (g_subleq_wave)
+                subleq_wave_kernel<<<B, 64, 0, st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0}, nullptr, nullptr, s->d_next_reward,
+                                                     s->d_next_term, s->d_next_legal);
             else
                 subleq_step_kernel<<<cdiv(B, epw), 64, subleq_lds_bytes(env->dev.W), st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0},
                                                                                           nullptr, nullptr, s->d_next_reward, s->d_next_term,

@@ -623,6 +623,227 @@ __global__ void __launch_bounds__(64) subleq16_wave_kernel(EnvDev e, StateRef sr
                        out_copy, next_reward, next_term, next_legal, mem_copy, obs_out, nf);
 }
 
+// ---- Subleq, any word size: one wavefront per environment -----------------------------------------------------------------
+// The per-lane kernel above (subleq_step_kernel) spends ~1.1 k clocks per interpreted cycle at word_size 256 (a branch-free VALU body of
+// ~200 dependent instructions), and a launch lasts as long as its slowest environment: a 200-cycle counting loop = 95 us.  Here the machine
+// state of ONE environment is wavefront-uniform: the program memory lives in the lanes of one VGPR (lane l = bytes 4 l .. 4 l + 3, 256 bytes),
+// an operand fetch is a v_readlane with a scalar index + a scalar byte extract, the write-back a compare + select on the lane id; cursor, counters, IO buffers
+// (eight 16-bit words as two 64-bit scalars each) and every branch are scalar.  The periodicity test compares the memory VGPR with its
+// snapshot in one v_cmp when the cursor equals the snapshot's.  subleq.py:297-398 `simulate`.
+__device__ __forceinline__ bool subleqw_wave_run(const int W, const int lane, uint32_t mv, const Pack8 sin, const Pack8 stout, Pack8& in_after, Pack8& out_after,
+                                                 int& bytes_used) {
+    // Structure of subleq16_wave_run (above), with byte operands in the lanes of `mv` and 16-bit IO words: the inner loop runs the cycles that
+    // touch memory words only; the input is not rolled but indexed by a cursor (position 8 reads as W); halting (:341) is folded into `inc`;
+    // an IO event invalidates the Brent snapshot (the input cursor and the output only move forward).
+    const int AMAX = W - 4, AIN = W - 3, AOUT = W - 2, kStop = 1000;
+    const unsigned long long w4 = 0x0001000100010001ull * static_cast<unsigned long long>(W);
+    Pack8 sout{w4, w4};
+    uint32_t ssnap = 0u;
+    int cur = 0, cycles = 0, in_cur = 0, out_cursor = 0, top_cur = -3;
+    int s_cur = -1, s_cycle = 0, it = 0, next_snap = 1;
+    int error = 0;
+    int inc = pack8_eq(sout, stout) ? kStop : 1;
+    auto dword = [&](int i) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mv), i)); };
+    auto get16 = [](const Pack8& p, int i) { return static_cast<int>(((i < 4 ? p.lo : p.hi) >> (16 * (i & 3))) & 0xFFFFull); };
+    auto diffmod = [&](int ra, int rb) {  // (ra - rb) mod W, :322: words are < W, so one conditional add; the general form only for hand-made bytes >= W
+        int v = ra - rb;
+        v += v < 0 ? W : 0;
+        if (v < 0 || v >= W) v = pymod(ra - rb, W);
+        return v;
+    };
+    auto cycle_end = [&]() {
+        cycles += inc;
+        it += 1;
+        if (cur == s_cur) {
+            if (cycles < 200 && __builtin_amdgcn_ballot_w64(mv != ssnap) == 0ull) {
+                const int p = cycles - s_cycle;
+                cycles += ((200 - cycles) / p) * p;
+            }
+        }
+        if (it == next_snap) {
+            ssnap = mv; s_cur = cur; s_cycle = cycles;
+            next_snap *= 2;
+        }
+    };
+    for (;;) {
+        int a = 0, b = 0, c = 0;
+        uint32_t da = 0u;
+        bool oob;
+        for (;;) {
+            oob = cur + 2 >= W;  // :364-370
+            if (oob) break;
+            top_cur = top_cur > cur ? top_cur : cur;
+            const int cl = cur >> 2;
+            const unsigned long long two = static_cast<unsigned long long>(dword(cl)) | (static_cast<unsigned long long>(dword(cl < 63 ? cl + 1 : 63)) << 32);
+            const uint32_t abc = static_cast<uint32_t>(two >> (8 * (cur & 3)));
+            a = abc & 0xFF; b = (abc >> 8) & 0xFF; c = (abc >> 16) & 0xFF;
+            if ((a > b ? a : b) > AMAX) break;
+            da = dword(a >> 2);
+            const int sha = 8 * (a & 3);
+            const int v = diffmod(static_cast<int>((da >> sha) & 0xFFu), static_cast<int>((dword(b >> 2) >> (8 * (b & 3))) & 0xFFu));
+            const uint32_t nd = (da & ~(0xFFu << sha)) | (static_cast<uint32_t>(v) << sha);
+            mv = lane == (a >> 2) ? nd : mv;
+            cur = (v == 0 || 2 * v >= W) ? c : cur + 3;  // :329-330
+            cycle_end();
+            if (cycles >= 200) break;
+        }
+        if (cycles >= 200) break;
+        if (oob) { error = 1; break; }  // nothing else changes
+        // ---- a cycle that names IN, OUT or a word beyond ADDRESS_MAX: read_memory :187-232 (both reads see the pre-advance input state)
+        const int in0 = in_cur < 8 ? get16(sin, in_cur) : W;
+        const bool in_ok = in0 < W;
+        int ra = 0, rb = 0;
+        if (a <= AMAX) { da = dword(a >> 2); ra = static_cast<int>((da >> (8 * (a & 3))) & 0xFFu); } else if (a == AIN && in_ok) ra = in0;
+        if (b <= AMAX) rb = static_cast<int>((dword(b >> 2) >> (8 * (b & 3))) & 0xFFu); else if (b == AIN && in_ok) rb = in0;
+        const int v = diffmod(ra, rb);
+        if (a == AIN || b == AIN) {
+            if (in_ok) { in_cur += 1; s_cur = -1; }
+            else error = 1;
+        }
+        // write_memory :243-295
+        if (a == AOUT) {
+            if (out_cursor >= 8) error = 1;
+            else {
+                const int sh = 16 * (out_cursor & 3);
+                const unsigned long long clr = ~(0xFFFFull << sh), ins = static_cast<unsigned long long>(v) << sh;
+                if (out_cursor < 4) sout.lo = (sout.lo & clr) | ins; else sout.hi = (sout.hi & clr) | ins;
+                if (v != get16(stout, out_cursor)) error = 1;  // :346-350
+                out_cursor += 1;
+                s_cur = -1;
+                if (pack8_eq(sout, stout)) inc = kStop;
+            }
+        } else if (a <= AMAX) {
+            const int sha = 8 * (a & 3);
+            const uint32_t nd = (da & ~(0xFFu << sha)) | (static_cast<uint32_t>(v) << sha);
+            mv = lane == (a >> 2) ? nd : mv;
+        }
+        cur = (v == 0 || 2 * v >= W) ? c : cur + 3;
+        if (error) break;
+        cycle_end();
+        if (cycles >= 200) break;
+    }
+    // the rolled input (:333-338): words in_cur .. 7 move down, W comes in at the top
+    Pack8 ia = sin;
+    for (int k = 0; k < in_cur; ++k) {
+        ia.lo = (ia.lo >> 16) | (ia.hi << 48);
+        ia.hi = (ia.hi >> 16) | (static_cast<unsigned long long>(W) << 48);
+    }
+    in_after = ia;
+    out_after = sout;
+    bytes_used = top_cur + 3;
+    return error == 0 && pack8_eq(sout, stout);
+}
+
+// Same contract as subleq_step_kernel; grid = B workgroups of one wavefront.  Lane l carries bytes 4 l .. 4 l + 3 of the state's 256-byte
+// memory field (all of it: the bytes beyond word_size are zero and travel with the copy), lane 0 the header and the four IO rows.
+__global__ void __launch_bounds__(64) subleq_wave_kernel(EnvDev e, StateRef src, StateRef dst, const int32_t* action, int B, int mode, Key key_arg,
+                                                         const Key* key_ptr, char* out_copy, float* next_reward, uint8_t* next_term,
+                                                         uint8_t* next_legal) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int W = e.W;
+    const char* sp = state_ptr(src, b, e.state_bytes);
+    char* dp = state_ptr(dst, b, e.state_bytes);
+    const eaz_subleq_state* ss = reinterpret_cast<const eaz_subleq_state*>(sp);
+    int h_step = 0, h_task = 0, h_flags = 0;
+    uint32_t md = 0u;
+    if (mode != 2) {
+        const int4 hv = *reinterpret_cast<const int4*>(sp);
+        h_step = __builtin_amdgcn_readfirstlane(hv.x);
+        h_task = __builtin_amdgcn_readfirstlane(hv.y);
+        h_flags = __builtin_amdgcn_readfirstlane(hv.w);
+        md = reinterpret_cast<const uint32_t*>(sp + 80)[lane];
+    }
+    const int s_term = h_flags & 0xFF, s_trunc = (h_flags >> 8) & 0xFF, s_solved = (h_flags >> 16) & 0xFF;
+    // ---- decide what this environment does (pgx wrapper A.1, auto_reset selfplay.py:66-71, _step subleq.py:671-677)
+    bool do_init = false, finish = false, run = false;
+    int step_count = 0, task = 0, act = 0;
+    {
+        const bool done = mode != 2 && (s_term | s_trunc) != 0;
+        do_init = mode == 2 || (mode == 1 && done);
+        if (do_init) {
+            const Key key = key_ptr ? *key_ptr : key_arg;
+            const Key kb = fold(key, static_cast<uint32_t>(b));
+            const Key ki = mode == 2 ? kb : fold(kb, 1u);
+            const int idx = e.n_tasks > 1 ? static_cast<int>(rbits(ki, 0) % static_cast<uint32_t>(e.n_tasks)) : 0;  // subleq.py:624
+            task = e.tasks[idx];
+            step_count = 0;
+            run = true;
+            md = 0u;
+        } else if (done) {
+            task = h_task; step_count = h_step;  // same state, zero rewards
+        } else {
+            task = h_task;
+            step_count = h_step + 1;
+            act = __builtin_amdgcn_readfirstlane(action[b]);
+            if (step_count >= W - 3 || s_solved) finish = true;  // subleq.py:671-673
+            else run = true;
+        }
+    }
+    task = __builtin_amdgcn_readfirstlane(task);
+    Pack8 ex_in{0ull, 0ull}, ex_out{0ull, 0ull}, in_after{0ull, 0ull}, out_after{0ull, 0ull};
+    bool all_correct = false;
+    int bytes_used = 0;
+    if (run) {
+        const int idx = step_count - 1;  // the action is word step_count - 1 (subleq.py:654)
+        if (!do_init && idx >= 0 && idx < W && lane == (idx >> 2)) md = (md & ~(0xFFu << (8 * (idx & 3)))) | ((static_cast<uint32_t>(act) & 0xFFu) << (8 * (idx & 3)));
+        all_correct = true;
+        for (int c = 0; c < 3 && all_correct; ++c) {  // subleq.py:511 vmap; `solved` is the AND (:525), only case 0 feeds the state
+            uint16_t tin[8], tout[8];
+            subleq_test_case(task, c, W, tin, tout);
+            const Pack8 pin = pack8(tin), pout = pack8(tout);
+            Pack8 ia, oa;
+            int bytes_c = 0;
+            const bool correct = subleqw_wave_run(W, lane, md, pin, pout, ia, oa, bytes_c);
+            bytes_used = bytes_c > bytes_used ? bytes_c : bytes_used;  // :530
+            if (c == 0) { ex_in = pin; ex_out = pout; in_after = ia; out_after = oa; }
+            all_correct = correct;
+        }
+    }
+    // ---- assemble the new state --------------------------------------------------------------------------------
+    const bool copy_mem = reinterpret_cast<const void*>(sp) != reinterpret_cast<const void*>(dp);
+    float reward;
+    int terminated, solved;
+    if (run) {
+        solved = all_correct ? 1 : 0;                           // subleq.py:525
+        reward = solved ? subleq_reward(e, bytes_used) : 0.0f;  // :535-537 / :540-542
+        terminated = do_init ? 0 : s_term;                      // _step never sets terminated on this branch (:661-669)
+    } else {
+        solved = s_solved;
+        reward = 0.0f;                                          // terminal no-op (A.1) or subleq.py:673
+        terminated = finish ? 1 : s_term;
+    }
+    const int truncated = do_init ? 0 : s_trunc;
+    const uint4 header = make_uint4(static_cast<uint32_t>(step_count), static_cast<uint32_t>(task), __builtin_bit_cast(uint32_t, reward),
+                                    static_cast<uint32_t>(terminated) | (static_cast<uint32_t>(truncated) << 8) | (static_cast<uint32_t>(solved) << 16));
+    uint4 rows[4];
+    if (run) {
+        auto r4 = [](const Pack8& p) { return make_uint4(static_cast<uint32_t>(p.lo), static_cast<uint32_t>(p.lo >> 32), static_cast<uint32_t>(p.hi), static_cast<uint32_t>(p.hi >> 32)); };
+        rows[0] = r4(ex_in); rows[1] = r4(in_after); rows[2] = r4(ex_out); rows[3] = r4(out_after);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rows[i] = *reinterpret_cast<const uint4*>(sp + 16 + 16 * i);
+    }
+    (void)ss;
+    auto emit = [&](char* base, bool everything) {
+        if (lane == 0) {
+            *reinterpret_cast<uint4*>(base) = header;
+            if (everything || run) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(base + 16 + 16 * i) = rows[i];
+            }
+        }
+        if (everything || run) reinterpret_cast<uint32_t*>(base + 80)[lane] = md;
+    };
+    emit(dp, copy_mem);
+    if (out_copy) emit(out_copy + static_cast<long>(b) * sizeof(eaz_subleq_state), true);
+    if (lane == 0) {
+        if (next_reward) next_reward[b] = reward;
+        if (next_term) next_term[b] = static_cast<uint8_t>(terminated);
+    }
+    if (next_legal)
+        for (int a = lane; a < e.A; a += 64) next_legal[static_cast<long>(b) * e.A + a] = 1;  // all legal (subleq.py:626)
+}
+
 // ---- connect_four -------------------------------------------------------------------------------------------------
 // One thread per environment.  mode as deepsea_step_kernel.  mover_reward[b] = rewards[b, current_player BEFORE the step]
 // (context.py:125,139 / evaluate.py:48-50).
