@@ -310,7 +310,7 @@ static int env_step_launch(eaz_env* env, int B, const void* in, const int32_t* a
         } else {
             if (g_subleq_wave) {  // one wavefront per environment (default)
                 subleq_wave_kernel<<<B, 64, 0, st>>>(env->dev, src, dst, action, B, mode, key, d_key, static_cast<char*>(out_copy), mover_reward, nullptr,
-                                                     nullptr);
+                                                     nullptr, nullptr);
             } else {
                 const int epw = subleq_envs_per_wg(B);
                 subleq_step_kernel<<<cdiv(B, epw), 64, subleq_lds_bytes(env->dev.W), st>>>(env->dev, src, dst, action, B, mode, key, d_key,
@@ -1221,7 +1221,7 @@ static int recurrent_launch(eaz_search* s, hipStream_t st) {
             // embedding slots 1.. are only ever written here and the allocation starts zeroed: bytes >= W of `memory` stay zero
             const int epw = subleq_envs_per_wg(B);
             // word_size 16 + binary encoding: the step kernel also writes the observation row (no obs_emit launch)
-            const bool fused_obs = g_fused_leaf && env->dev.W == 16 && env->dev.binary && env->dev.obs_dim == 240;
+            const bool fused_obs = g_fused_leaf && env->dev.binary && ((env->dev.W == 16 && env->dev.obs_dim == 240) || (env->dev.W != 16 && g_subleq_wave));
             // ... and, for the XXHash variant over the IO rows (the FCNet default, fully_connected.py:85-87), the novelty lookup
             const NetDev& nd = s->net->dev;
             novelty_done = fused_obs && !nd.sim_matrix && nd.hash_off == 80 && nd.hash_len == 160 && nd.in_dim == 240;
@@ -1231,7 +1231,7 @@ static int recurrent_launch(eaz_search* s, hipStream_t st) {
                                                        NoveltyFuse{nd.bitset, novelty_done ? s->d_novelty : nullptr, nd.hash_bits, nd.nov_scale});
             else if (g_subleq_wave)
                 subleq_wave_kernel<<<B, 64, 0, st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0}, nullptr, nullptr, s->d_next_reward,
-                                                     s->d_next_term, s->d_next_legal);
+                                                     s->d_next_term, s->d_next_legal, fused_obs ? s->d_obs : nullptr);
             else
                 subleq_step_kernel<<<cdiv(B, epw), 64, subleq_lds_bytes(env->dev.W), st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0},
                                                                                           nullptr, nullptr, s->d_next_reward, s->d_next_term,

@@ -738,7 +738,7 @@ __device__ __forceinline__ bool subleqw_wave_run(const int W, const int lane, ui
 // memory field (all of it: the bytes beyond word_size are zero and travel with the copy), lane 0 the header and the four IO rows.
 __global__ void __launch_bounds__(64) subleq_wave_kernel(EnvDev e, StateRef src, StateRef dst, const int32_t* action, int B, int mode, Key key_arg,
                                                          const Key* key_ptr, char* out_copy, float* next_reward, uint8_t* next_term,
-                                                         uint8_t* next_legal) {
+                                                         uint8_t* next_legal, uint8_t* obs_out) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int W = e.W;
     const char* sp = state_ptr(src, b, e.state_bytes);
@@ -842,6 +842,29 @@ __global__ void __launch_bounds__(64) subleq_wave_kernel(EnvDev e, StateRef src,
     }
     if (next_legal)
         for (int a = lane; a < e.A; a += 64) next_legal[static_cast<long>(b) * e.A + a] = 1;  // all legal (subleq.py:626)
+    if (obs_out) {
+        // binary encoding only (the caller checks): the observation row of the new state (subleq.py:679-707 rows = memory | example_input |
+        // input_after | example_output | output_after; :88-98 columns = little-endian bits of v mod W, then v == W) -- no obs_emit launch
+        uint8_t* o = obs_out + static_cast<long>(b) * e.obs_dim;
+        const int cols = e.obs_cols;
+        for (int i = lane; i < ((W + 32 + 63) & ~63); i += 64) {
+            const uint32_t mdw = static_cast<uint32_t>(__shfl(static_cast<int>(md), (i < W ? i : 0) >> 2));
+            int v;
+            if (i < W) v = static_cast<int>((mdw >> (8 * (i & 3))) & 0xFFu);
+            else {
+                const int r = (i - W) >> 3, k = (i - W) & 7;
+                const uint4 rw = r == 0 ? rows[0] : (r == 1 ? rows[1] : (r == 2 ? rows[2] : rows[3]));
+                const uint32_t pair = (k >> 1) == 0 ? rw.x : ((k >> 1) == 1 ? rw.y : ((k >> 1) == 2 ? rw.z : rw.w));
+                v = static_cast<int>((pair >> (16 * (k & 1))) & 0xFFFFu);
+            }
+            if (i < W + 32) {
+                const unsigned m = static_cast<unsigned>(pymod(v, W)) & 0xFFu;  // :90
+                uint8_t* ow = o + i * cols;
+                for (int j = 0; j < cols - 1; ++j) ow[j] = j < 8 ? static_cast<uint8_t>((m >> j) & 1u) : static_cast<uint8_t>(0);  // :91
+                ow[cols - 1] = static_cast<uint8_t>(v == W);                                                                       // :96
+            }
+        }
+    }
 }
 
 // ---- connect_four -------------------------------------------------------------------------------------------------
