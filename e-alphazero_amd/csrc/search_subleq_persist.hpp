@@ -72,7 +72,7 @@ struct QpMisc {
     int real_action[kQpTrees];
     int env_next;
     int pad[3];
-    uint8_t qkey[kQpTrees];             // expected cost of the environment's next interpreter step (queue order)
+    alignas(16) uint8_t qkey[kQpTrees]; // expected cost of the environment's next interpreter step (queue order)
     int16_t task[kQpTrees];             // the environments' tasks: constant between two resets (subleq.py:624), so not stored per node
     float beta[kQpTrees];               // selfplay.py:105 beta * linspace(0, 1, B)[b]; search only: the caller's per-tree beta
     int nc[kQpTrees];                   // min(valid root actions, max_num_considered_actions): row of the considered-visit table
@@ -330,11 +330,9 @@ __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src
         else run = true;
     }
     const int branch = task - 1 < 0 ? 0 : (task - 1 > 5 ? 5 : task - 1);  // get_test_cases: lax.switch clamps the branch index
-    // the packed test vectors of the three cases, requested together (one scalar-cache round trip instead of one per case)
-    unsigned long long tv[3][2];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { tv[c][0] = kSq16Cases.v[branch][c][0]; tv[c][1] = kSq16Cases.v[branch][c][1]; }
-    const unsigned long long t_in = tv[0][0], t_out = tv[0][1];
+    // the packed test vectors of case 0 (99.9 % of the steps run nothing else; the other two are fetched when case 0 has passed: twelve scalar
+    // registers held across the interpreter were part of what the compiler spilled into VGPR lanes around it)
+    const unsigned long long t_in = kSq16Cases.v[branch][0][0], t_out = kSq16Cases.v[branch][0][1];
     unsigned long long exin = exroot ? qp_u64(root_ex[0], root_ex[1]) : t_in, exout = exroot ? qp_u64(root_ex[2], root_ex[3]) : t_out;
     bool all_correct = false;
     int bytes_used = 0;
@@ -363,7 +361,7 @@ __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src
             asm volatile("" : "+v"(tmask));  // lives in a VGPR: subleq16_wave_run accumulates it on the vector port
 #pragma unroll 1
             for (int c = 0; c < 3 && all_correct; ++c) {  // subleq.py:511 vmap; `solved` is the AND (:525), only case 0 feeds the state
-                const unsigned long long sin = c == 0 ? tv[0][0] : (c == 1 ? tv[1][0] : tv[2][0]), stout = c == 0 ? tv[0][1] : (c == 1 ? tv[1][1] : tv[2][1]);
+                const unsigned long long sin = c == 0 ? t_in : kSq16Cases.v[branch][c][0], stout = c == 0 ? t_out : kSq16Cases.v[branch][c][1];
                 unsigned long long s_after, s_out;
                 int bytes_c;
                 int it_c = 0;
@@ -949,12 +947,15 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 // queue position -> environment: by descending key, ties by index (every wave ranks the 16 keys itself: lanes 0..15)
                 int rank = 0;
                 if (env_mode == 0) {
+                    // unique keys (key, then the lower index first): rank = number of larger ones -- one compare per other environment
                     const int me = lane & 15;
-                    const int kme = M.qkey[me];
+                    const int kme = 16 * static_cast<int>(M.qkey[me]) + (15 - me);
+                    const uint4 kq = *reinterpret_cast<const uint4*>(&M.qkey[0]);
 #pragma unroll
                     for (int o = 0; o < kQpTrees; ++o) {
-                        const int ko = M.qkey[o];
-                        rank += (ko > kme || (ko == kme && o < me)) ? 1 : 0;
+                        const uint32_t d = __builtin_amdgcn_readfirstlane((o >> 2) == 0 ? kq.x : ((o >> 2) == 1 ? kq.y : ((o >> 2) == 2 ? kq.z : kq.w)));
+                        const int ko = 16 * static_cast<int>((d >> (8 * (o & 3))) & 0xFFu) + (15 - o);
+                        rank += ko > kme ? 1 : 0;
                     }
                 } else {
                     rank = lane & 15;
