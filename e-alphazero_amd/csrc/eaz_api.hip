@@ -441,7 +441,7 @@ static int net_create_fc_impl(eaz_net* n, int in_dim, int hidden, int num_action
         HIP_OK(hipMemcpy(n->d_hot_index, hi.data(), hi.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         n->dev.hot_index = n->d_hot_index;
     }
-    if (fp_eligible(in_dim, num_actions))
+    if (hidden == kFcH && fp_eligible(in_dim, num_actions))
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc16p_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, fp_lds_bytes(kFpMaxK, kFcW3Cols)));
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_forward_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFcLdsBytes));
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_forward_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFcLdsBytes));
@@ -457,7 +457,9 @@ extern "C" int eaz_net_create_fc(eaz_ctx* ctx, int in_dim, int hidden, int num_a
                                  const float* const* h_b, float max_ube, float max_reward_variance, int hash_off,
                                  int hash_len, int hash_bits, eaz_net** out) {
     ARG_OK(ctx && out && h_w && h_b && in_dim > 0 && num_actions > 0 && num_actions <= 256);
-    if (hidden != kFcH) return fail("the gfx950 FC kernel is specialised for linear_layer_size = %d (config.py:24), got %d", kFcH, hidden);
+    // linear_layer_size 256 (config.py:24, the only value the reference's configurations use) runs the MFMA kernels; any other size the plain
+    // kernel of net_fc.hpp (fc_generic_forward_kernel): same results contract, per-simulation path only, not tuned
+    if (hidden < 1 || hidden > 1024) return fail("linear_layer_size %d outside 1..1024", hidden);
     if (hash_len <= 0 || hash_len % 4 != 0 || hash_off < 0 || hash_off + hash_len > in_dim)
         return fail("hash slice [%d, %d) invalid: length must be a positive multiple of 4 (hashes.py:210) inside the observation", hash_off, hash_off + hash_len);
     ARG_OK(hash_bits >= 4 && hash_bits <= 32);
@@ -695,6 +697,11 @@ static int fc_launch(eaz_net* n, int B, const uint8_t* obs, const NetOut& o, con
     if (B <= 0 || heads.n <= 0) return 0;
     if (n->kind == 1) {  // residual tower: six samples per workgroup, all heads in one launch
         resnet_forward_kernel<<<cdiv(B, kRnSamples), 256, kRnLdsBytes, st>>>(n->rdev, obs, B, o);
+        LAUNCH_OK();
+        return 0;
+    }
+    if (n->dev.H != kFcH) {  // any other linear_layer_size: plain fmaf chains
+        fc_generic_forward_kernel<<<dim3(cdiv(B, kFgRows), heads.n), 256, fg_lds_bytes(n->dev.H), st>>>(n->dev, obs, B, o, heads);
         LAUNCH_OK();
         return 0;
     }
@@ -965,7 +972,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     DALLOC(s->d_leaf_hot, B);
     t.fenv = env->dev; t.fuse_reward = s->d_next_reward; t.fuse_term = s->d_next_term; t.leaf_hot = s->d_leaf_hot;
     t.fuse_env = 0;
-    s->fuse_leaf = g_fused_leaf && env->dev.kind == EAZ_ENV_DEEPSEA && net->kind == 0 && net->dev.ztab != nullptr;
+    s->fuse_leaf = g_fused_leaf && env->dev.kind == EAZ_ENV_DEEPSEA && net->kind == 0 && net->dev.ztab != nullptr && net->dev.H == kFcH;
     if (s->fuse_leaf) HIP_OK(hipMemset(s->d_next_legal, 1, static_cast<size_t>(B) * A));  // legal_action_mask all true (deep_sea.py:19)
     {
         // persistent search: DeepSea + FC net, two actions, node ids / grid coordinates inside the packed LDS fields, and the 16 trees of a
@@ -978,7 +985,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(search_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
         if (s->persist_ok) DALLOC(s->d_replay_states, static_cast<size_t>(B) * env->dev.state_bytes);
         // Subleq-16 one-launch search (search_subleq.hpp): two forward tile sets = 76 KB of dynamic LDS (eligibility is re-checked per run)
-        if (env->dev.kind == EAZ_ENV_SUBLEQ && env->dev.W == 16 && net->kind == 0 && fp_eligible(net->dev.in_dim, net->dev.A)) {
+        if (env->dev.kind == EAZ_ENV_SUBLEQ && env->dev.W == 16 && net->kind == 0 && net->dev.H == kFcH && fp_eligible(net->dev.in_dim, net->dev.A)) {
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(subleq16_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        sq16_lds_bytes(net->dev.in_dim, net->dev.A, kSqHeadGroups)));
             // ... and the whole selfplay() call in one launch while the 16 trees + states of a workgroup fit beside the forward tiles
@@ -1100,7 +1107,7 @@ static bool sq16_persist_eligible(const eaz_search* s) {
     const EnvDev& ed = s->env->dev;
     if (!(ed.kind == EAZ_ENV_SUBLEQ && ed.W == 16 && ed.binary && ed.obs_dim == 240 && s->lpt == 16 && s->apl == 1 && s->net->kind == 0)) return false;
     const NetDev& nd = s->net->dev;
-    return fp_eligible(nd.in_dim, nd.A) && nd.in_dim == 240 && !nd.sim_matrix && nd.hash_off == 80 && nd.hash_len == 160;
+    return nd.H == kFcH && fp_eligible(nd.in_dim, nd.A) && nd.in_dim == 240 && !nd.sim_matrix && nd.hash_off == 80 && nd.hash_len == 160;
 }
 static int sq16_persist_launch(eaz_search* s, int sim0, int n_sims, bool expand_first, bool expand_last, hipStream_t st) {
     Sq16SearchArgs a;

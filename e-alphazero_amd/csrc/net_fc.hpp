@@ -943,4 +943,75 @@ __global__ void __launch_bounds__(256, 3) fc16_forward_kernel(NetDev net, FcIn i
     if (kstep_counter && lane == 0 && wave == 0 && executed) atomicAdd(kstep_counter, executed);
 }
 
+// ---- any linear_layer_size other than 256 (config.py:24): plain fmaf chains, not tuned -----------------------------------------------------
+// The MFMA kernels above are specialised for H = 256 (tile shapes, LDS layouts, the four 64-column quarters of layer 3).  This kernel is the
+// numerics contract written out: thread = output column, acc = +0; acc = fmaf(x[k], w[k][j], acc) for k ascending; + b; relu -- and the
+// third layer as four contiguous quarter chains added ((c0 + c1) + (c2 + c3)) when H % 4 == 0, one chain otherwise (oracle o_linear_parts).
+// One workgroup = kFgRows rows of one head; hidden activations in LDS ([rows][H] twice).
+constexpr int kFgRows = 4;
+__host__ __device__ inline int fg_lds_bytes(int H) { return 2 * kFgRows * H * static_cast<int>(sizeof(float)); }
+__global__ void __launch_bounds__(256) fc_generic_forward_kernel(NetDev net, const uint8_t* __restrict__ obs, int B, NetOut out, HeadList heads) {
+    extern __shared__ __attribute__((aligned(16))) float fg_sm[];
+    const int H = net.H, K1 = net.in_dim, tid = threadIdx.x;
+    const int head = heads.id[blockIdx.y];
+    const int row0 = blockIdx.x * kFgRows;
+    float* h1 = fg_sm;
+    float* h2 = fg_sm + kFgRows * H;
+    const float* W1 = net.w[head * 3], *W2 = net.w[head * 3 + 1], *W3 = net.w[head * 3 + 2];
+    const float* b1 = net.b[head * 3], *b2 = net.b[head * 3 + 1], *b3 = net.b[head * 3 + 2];
+    for (int j = tid; j < H; j += 256) {  // layer 1 (fully_connected.py:45-47: observation bytes as float32)
+        float acc[kFgRows];
+#pragma unroll
+        for (int r = 0; r < kFgRows; ++r) acc[r] = 0.0f;
+        for (int k = 0; k < K1; ++k) {
+            const float w = W1[static_cast<long>(k) * H + j];
+#pragma unroll
+            for (int r = 0; r < kFgRows; ++r) {
+                const int row = row0 + r < B ? row0 + r : B - 1;
+                acc[r] = __builtin_fmaf(static_cast<float>(obs[static_cast<long>(row) * K1 + k]), w, acc[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kFgRows; ++r) { const float v = acc[r] + b1[j]; h1[r * H + j] = v > 0.0f ? v : 0.0f; }
+    }
+    __syncthreads();
+    for (int j = tid; j < H; j += 256) {  // layer 2
+        float acc[kFgRows];
+#pragma unroll
+        for (int r = 0; r < kFgRows; ++r) acc[r] = 0.0f;
+        for (int k = 0; k < H; ++k) {
+            const float w = W2[static_cast<long>(k) * H + j];
+#pragma unroll
+            for (int r = 0; r < kFgRows; ++r) acc[r] = __builtin_fmaf(h1[r * H + k], w, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < kFgRows; ++r) { const float v = acc[r] + b2[j]; h2[r * H + j] = v > 0.0f ? v : 0.0f; }
+    }
+    __syncthreads();
+    const int No = head < 2 ? 1 : net.A;
+    const int parts = (H % 4 == 0) ? 4 : 1, Kp = H / parts;
+    for (int idx = tid; idx < kFgRows * No; idx += 256) {  // layer 3 + the head's output (fully_connected.py:55,64,68-81,93)
+        const int r = idx / No, o = idx - r * No;
+        float c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int q = 0; q < parts; ++q) {
+            float z = 0.0f;
+            for (int k = q * Kp; k < (q + 1) * Kp; ++k) z = __builtin_fmaf(h2[r * H + k], W3[static_cast<long>(k) * No + o], z);
+            c[q] = z;
+        }
+        float z = parts == 4 ? (c[0] + c[1]) + (c[2] + c[3]) : c[0];
+        z = z + b3[o];
+        if (row0 + r >= B) continue;
+        const long gi = row0 + r;
+        if (head == 0) { if (out.value) out.value[gi] = det_tanh(z); }
+        else if (head == 1) {
+            float u = 0.5f * (det_tanh(z) + 1.0f);
+            u = u * net.max_u;  // :93 (:95-96 joined in ube_combine())
+            if (out.ube) out.ube[gi] = u;
+        } else {
+            float* dst = head == 2 ? out.exploit : out.explore;
+            if (dst) dst[gi * net.A + o] = z;
+        }
+    }
+}
+
 }  // namespace eaz

@@ -120,7 +120,9 @@ EAZ_API int eaz_env_num_players(const eaz_env* env);
 /* ---- (ii) network: forward.apply(params, state, obs, is_training=False) ------------------------------------ */
 /* EpistemicFullyConnectedAZNet fully_connected.py:14-39.  h_w[i] is [in,out] row-major, h_b[i] is [out], i in haiku
  * creation order: value 0-2, ube 3-5, exploitation 6-8, exploration 9-11 (fully_connected.py:50-81).
- * hash_off/hash_len select the flattened slice that is hashed (hash_io: rows word_size.. , fully_connected.py:85-87). */
+ * hash_off/hash_len select the flattened slice that is hashed (hash_io: rows word_size.. , fully_connected.py:85-87).
+ * hidden = config.linear_layer_size (config.py:24): 256 runs the MFMA kernels and the one-launch self-play; 1..1024 otherwise: a plain kernel on
+ * the per-simulation path (same results contract, not tuned). */
 EAZ_API int eaz_net_create_fc(eaz_ctx* ctx, int in_dim, int hidden, int num_actions, const float* const* h_w, const float* const* h_b,
                       float max_ube, float max_reward_variance, int hash_off, int hash_len, int hash_bits, eaz_net** out);
 /* EpistemicResidualAZNet(num_actions, num_channels=64, num_blocks) resnet.py:42-66 on [H,W,Cin] observations.  h_arrays: the

@@ -716,7 +716,7 @@ static void o_linear_parts(int B, int K, int N, const float* x, const float* w, 
     const int Kp = K / parts;
 #pragma omp parallel for schedule(static)
     for (int r0 = 0; r0 < B; r0 += 4) {
-        float acc[4][4][O_MAX_A > 256 ? O_MAX_A : 256];
+        float acc[4][4][O_MAX_A > 1024 ? O_MAX_A : 1024];  /* N = linear_layer_size (<= 1024) or the number of actions */
         const int rb = B - r0 < 4 ? B - r0 : 4;
         for (int q = 0; q < parts; ++q) {
             for (int r = 0; r < rb; ++r)
@@ -750,7 +750,7 @@ EXPORT void eazo_net_forward(const ONet* n, int B, const uint8_t* obs, float* ex
                              float* u, float* nov) {
     if (n->resnet) { o_resnet_forward(n, B, obs, exploit, explore, v, u, nov); return; }
     const int K = n->in_dim, H = n->H, A = n->A;
-    if (H > 256 || A > O_MAX_A) { fprintf(stderr, "eazo_net_forward: H/A too large\n"); abort(); }
+    if (H > 1024 || A > O_MAX_A) { fprintf(stderr, "eazo_net_forward: H/A too large\n"); abort(); }
     float* x = (float*)malloc((size_t)B * K * sizeof(float));
     float* h1 = (float*)malloc((size_t)B * H * sizeof(float));
     float* h2 = (float*)malloc((size_t)B * H * sizeof(float));

@@ -660,14 +660,60 @@ def test_simhash_lookup_update_and_selfplay_match_oracle(oracle, eaz, torch, kin
     assert np.array_equal(got["binary_set"], expect) and np.array_equal(got["random_matrix"], st["random_matrix"])
 
 
+@pytest.mark.parametrize("kind,H", [("deepsea", 128), ("deepsea", 30), ("subleq", 64), ("subleq", 512)])
+def test_other_linear_layer_sizes(oracle, eaz, torch, kind, H):
+    """config.linear_layer_size other than 256 (config.py:24): the forward of all four heads and a self-play call against the oracle.  H = 30:
+    not a multiple of 4, i.e. the third layer is ONE chain (oracle o_linear_parts).  These sizes run fc_generic_forward_kernel on the
+    per-simulation path (the one-launch kernels are specialised for 256)."""
+    from e_alphazero_amd import engine
+
+    if kind == "deepsea":
+        G, A = 8, 2
+        am, _, state = deepsea_setup(eaz, G, seed=5, fill=0.4)
+        in_dim = G * G
+        params = eaz.params.init_fc_params(in_dim, H, A, seed=H)
+        env = engine.EnvHandle.deepsea(G, am, device=0)
+        net = engine.FCNet(env.ctx, in_dim, H, A, params, state)
+        oenv = oracle.OracleEnv.deepsea(G, am)
+        onet = oracle.OracleNet(in_dim, H, A, eaz.params.fc_weight_list(params), bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+        disc, kw = 0.997, {}
+    else:
+        W = 16
+        dims, _, state = subleq_setup(eaz, W, seed=3, fill=0.4)
+        in_dim, A = dims["in_dim"], W
+        params = eaz.params.init_fc_params(in_dim, H, A, seed=H)
+        env = engine.EnvHandle.subleq(W, (1,), True, device=0)
+        net = engine.FCNet(env.ctx, in_dim, H, A, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
+        oenv = oracle.OracleEnv.subleq(W, (1,), True)
+        onet = oracle.OracleNet(in_dim, H, A, eaz.params.fc_weight_list(params), hash_off=dims["hash_off"], hash_len=dims["hash_len"],
+                                bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+        disc, kw = 0.97, {}
+    B, S, T = 37, 12, 4
+    st = env.init(B, key=2)
+    ost = oenv.init(B, key=(2, 0)) if kind == "subleq" else oenv.init(B)
+    obs = oenv.observe(ost)
+    obs[::3] = (np.random.default_rng(H).random(obs[::3].shape) < 0.3).astype(np.uint8)  # dense rows as well
+    for a_, b_, name in zip(net.forward(torch.from_numpy(obs).cuda()), onet.forward(obs), ("exploit", "explore", "value", "ube", "novelty")):
+        np.testing.assert_allclose(a_.cpu().numpy(), b_, rtol=0, atol=ATOL, err_msg=name)
+    search = engine.Search(env, net, B, S, discount=disc)
+    assert not search.launch_info()["one_launch"]
+    out = search.selfplay(st, T, key=91, **kw)
+    ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(91, 0), discount=disc)
+    assert np.array_equal(out["action"].cpu().numpy(), ref["action"])
+    conv = (lambda a: subleq_device_to_oracle(a, 16)) if kind == "subleq" else (lambda a: a)
+    assert np.array_equal(conv(out["state"].cpu().numpy()), ref["state"])
+    for k in ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction", "q_values_epistemic_variance"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
+
+
 def test_unsupported_shapes_fail_loudly(eaz, torch):
-    """The device path is specialised for linear_layer_size = 256 (config.py:24, every reference configuration); Subleq word sizes are
+    """linear_layer_size is 1..1024 (256, config.py:24, runs the MFMA kernels; any other size the plain kernel); Subleq word sizes are
     16..256 (subleq.py:606): anything else must be refused with a message, never computed on some fallback."""
     from e_alphazero_amd import engine
 
     env = engine.EnvHandle.deepsea(8, np.zeros((8, 8), np.uint8), device=0)
-    with pytest.raises(eaz.EazError, match="linear_layer_size = 256"):
-        engine.FCNet(env.ctx, 64, 128, 2, eaz.params.init_fc_params(64, 128, 2, seed=0))
+    with pytest.raises(eaz.EazError, match="linear_layer_size"):
+        engine.FCNet(env.ctx, 64, 2048, 2, eaz.params.init_fc_params(64, 2048, 2, seed=0))
     with pytest.raises(eaz.EazError, match=r"\[16, 256\]"):
         engine.EnvHandle.subleq(8, (1,), True, device=0)
     with pytest.raises(eaz.EazError, match="multiple of 4"):
