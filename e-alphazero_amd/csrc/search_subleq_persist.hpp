@@ -227,6 +227,9 @@ __device__ __forceinline__ uint8_t qp_code(uint32_t v) { return static_cast<uint
 // subleq.py:679-707) as 5-bit codes for the novelty hash, and the 240 observation bits themselves (bit 5 w + j = bit j of row-word w's
 // code, subleq.py:88-98; inputs 240..255 zero) as FP8 bytes in layer 1's operand order (QpMisc::obytes).  Lane w < 48 computes the code of
 // row-word w; bit k of the observation is fetched from the lane that holds its word (ds_bpermute) and stored as its byte.
+// The 16-byte words of a row of QpMisc::obytes are stored at position (word ^ swz(row)): the rows are 256 bytes = 64 banks apart, so the forward's
+// ds_read_b128 of word c from all 16 rows would hit the same four banks 16 times; swz = bits 8..11 of the row's LDS address (one more per row).
+__device__ __forceinline__ int qp_ob_swz(const uint8_t* row) { return static_cast<int>((reinterpret_cast<uintptr_t>(row) >> 8) & 15u); }
 __device__ __forceinline__ void qp_emit_obs(uint8_t* words, uint8_t* ob, unsigned long long mem, unsigned long long exin, unsigned long long inaf,
                                             unsigned long long exout, unsigned long long outaf, int lane) {
     uint32_t code = 0u;
@@ -238,12 +241,14 @@ __device__ __forceinline__ void qp_emit_obs(uint8_t* words, uint8_t* ob, unsigne
         code = qp_code(static_cast<uint32_t>(src >> sh) & 0xFFu);
     }
     if (lane < 48) words[lane] = static_cast<uint8_t>(code);
+    const int swz = qp_ob_swz(ob);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int k = 64 * p + lane;
         const int w = (k * 52429) >> 18, j = k - 5 * w;  // k / 5 for k < 2^14
         const uint32_t c = static_cast<uint32_t>(__shfl(static_cast<int>(code), w < 48 ? w : 0));
-        ob[64 * (k & 3) + (k >> 2)] = (w < 48 && ((c >> j) & 1u) != 0) ? static_cast<uint8_t>(0x38) : static_cast<uint8_t>(0);
+        const int idx = 64 * (k & 3) + (k >> 2);
+        ob[(((idx >> 4) ^ swz) << 4) | (idx & 15)] = (w < 48 && ((c >> j) & 1u) != 0) ? static_cast<uint8_t>(0x38) : static_cast<uint8_t>(0);
     }
 }
 
@@ -1042,7 +1047,9 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
 #pragma unroll
                 for (int qq = 0; qq < 16; ++qq) { const float wv = pwv[4 * qq]; w3v[qq] = fr < 2 ? wv : 0.0f; }
             }
-            const uint4* xrow = reinterpret_cast<const uint4*>(&M.obytes[fr][64 * fkq]);  // this lane's layer-1 A operands: four rounds of 16 FP8 bytes
+            const uint4* xrow_base = reinterpret_cast<const uint4*>(&M.obytes[fr][0]);  // this lane's layer-1 A operands: four rounds of 16 FP8 bytes,
+            const int xswz = qp_ob_swz(&M.obytes[fr][0]);                              // words 4 kq .. 4 kq + 3 of the row (swizzled, qp_ob_swz)
+            auto xrow = [&](int rd) { return xrow_base[(4 * fkq + rd) ^ xswz]; };
             const float* hpA = H2 + h16_off(fn0 + fkq, fr);  // quarter chain: H2[h16_off(n0 + 4 q + kq, r)] = hpA[68 q]
             float av[kPsARing];
             EAZ_QWSTAMP(0);
@@ -1054,7 +1061,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 floatx4 a3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
                 // ---- layer 1: [16 x 256] x [256 x 256], inputs 240..255 zero on both sides (exact); the first round carries the quarter chain
                 // of the head before ----
-                uint4 xcur = xrow[0], xnext = xrow[1];
+                uint4 xcur = xrow(0), xnext = xrow(1);
                 {
                     const floatx2 f = qp_abytes2(xcur, 0);
                     av[0] = f[0]; av[1] = f[1];
@@ -1075,7 +1082,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 for (int rd = 1; rd < 4; ++rd) {
                     const bool same = rd < 3;  // the refills of the last round are the first k-steps of layer 2
                     xcur = xnext;
-                    xnext = xrow[same ? rd + 1 : 3];  // (the last round converts nothing of it that is used: layer 2 refills the ring)
+                    xnext = xrow(same ? rd + 1 : 3);  // (the last round converts nothing of it that is used: layer 2 refills the ring)
                     qp_round<false, true>(acc, Bq, av, nullptr, xcur, xnext, same ? W1r[h] : W2r[h], fvoff,
                                           same ? 4096 * kPsDepth * (rd + 1) : 0, a3, hpA, w3v);
                     EAZ_QRSTAMP(h * 8 + rd);
