@@ -82,6 +82,27 @@ def test_reference_call_sites_match_fused_selfplay(eaz, torch, directed):
     assert out.state.terminated.any() and (out.state._step_count == 0).any()
 
 
+def test_config_linear_layer_size_through_the_facade(eaz, torch):
+    """config.linear_layer_size (config.py:24) other than 256: get_forward_fn builds the FC net at that size, selfplay() runs the per-simulation
+    kernels, and the reference-style step loop over the facade's own pieces reproduces it."""
+    from e_alphazero_amd import api
+
+    G, B, S, T = 8, 24, 8, 4
+    env = api.DeepSea(size_of_grid=G, action_map_key=api.random.PRNGKey(2))
+    config, forward, model, context = _setup(api, env, B, S, T, linear_layer_size=64)
+    assert tuple(np.asarray(model[0]["fc_az_net/linear"]["w"]).shape) == (G * G, 64)  # the value head's first layer: [in, linear_layer_size]
+    states = api.vmap(env.init)(api.random.split(api.random.PRNGKey(6), B))
+    g = torch.randn(T, B, 2, device="cuda")
+    last, out = api.selfplay(model, config, context, states, api.random.PRNGKey(12), gumbel=g)
+    s = states
+    for t in range(T):
+        s, o = _reference_style_step(api, torch, model, config, context, s, g[t], api.random.fold_in(0, t))
+        assert torch.equal(s.data, out.state.data[t]), f"state t={t}"
+        for k in ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction", "q_values_epistemic_variance"):
+            assert torch.equal(o[k], getattr(out, k)[t]), f"{k} t={t}"
+    assert torch.equal(s.data, last.data)
+
+
 def test_generic_recurrent_fn_path_matches_fused(eaz, torch):
     from e_alphazero_amd import api
 
