@@ -48,7 +48,7 @@ def count(body, mnemonic):
 
 # kernel stem -> VGPR budget of the occupancy it is designed for (MI355X_MICROARCH.md register table: 512 / waves per SIMD, granule 8)
 BUDGET = {
-    "search_persist_kernel": 256,      # 320 threads: five waves on four SIMDs, one SIMD carries two
+    "search_persist_kernel": 256,      # 512 threads (4 MFMA + 4 helper waves): two waves per SIMD
     "subleq16_search_kernel": 256,     # 512 threads: two waves per SIMD
     "subleq16_selfplay_kernel": 256,   # 512 threads: two waves per SIMD
     "fc16p_forward_kernel": 168,       # three 256-thread workgroups per CU: three waves per SIMD
@@ -66,7 +66,7 @@ def test_no_scratch_and_register_budget(asm, stem):
     assert count(body, "v_mfma_f32_16x16x4_f32") > 0, f"{stem} has lost its f32 MFMA stream"
 
 
-@pytest.mark.parametrize("stem", ["search_persist_kernel", "subleq16_search_kernel", "subleq16_selfplay_kernel", "fc16p_forward_kernel"])
+@pytest.mark.parametrize("stem", ["search_persist_kernel", "subleq16_search_kernel", "subleq16_selfplay_kernel", "fc16p_forward_kernel", "resnet_forward_kernel"])
 def test_weight_stream_is_buffer_loads(asm, stem):
     body, _ = kernel(asm, stem)
     assert count(body, "buffer_load_dwordx4") >= 16, "the weight stream (16 k-steps of 16-byte buffer loads in flight) is gone"
@@ -118,3 +118,17 @@ def test_selfplay_kernel_roles_issue_the_same_number_of_barriers():
     # the MFMA branch's barrier sits inside `for (int h = 0; h < 3; ++h)`
     assert mfma.count("__syncthreads();") == 1 and "for (int h = 0; h < 3; ++h)" in mfma
     assert helper.count("__syncthreads();") == 3
+
+
+def test_layer_loops_carry_no_avoidable_vector_alu_work(asm):
+    """A VALU instruction of the same wavefront between the MFMAs of a layer loop costs the matrix pipe ~18 clocks: the Subleq
+    forward converts its layer-1 operands two at a time from FP8 bytes (one v_cvt_pk_f32_fp8 per two k-steps, none of the v_cvt_f32_ubyte
+    that a bit / byte extraction per k-step compiles to), the ResNet's 3x3 convolutions fetch their weights without 64-bit address arithmetic
+    (no global_load_dwordx4 left beside the MFMAs of the tower: what remains are the first convolution's and the heads' loads), and the
+    DeepSea kernel is a 512-thread workgroup (one helper wavefront per SIMD)."""
+    body, _ = kernel(asm, "subleq16_selfplay_kernel")
+    assert count(body, "v_cvt_pk_f32_fp8_e32") + count(body, "v_cvt_pk_f32_fp8_sdwa") + count(body, "v_cvt_pk_f32_fp8") >= 24
+    body, _ = kernel(asm, "resnet_forward_kernel")
+    assert count(body, "buffer_load_dwordx4") >= 24 and count(body, "global_load_dwordx4") <= 48
+    _, meta = kernel(asm, "search_persist_kernel")
+    assert meta.get("max_flat_workgroup_size", 512) == 512
