@@ -593,6 +593,15 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
             roof["traffic"] = 1024.0 * (2.0 * k.get("FETCH_SIZE_KB_per_launch", 0.0) + k.get("WRITE_SIZE_KB_per_launch", 0.0))
             roof["traffic_source"] = (f"profiles/{cand} (2 x FETCH_SIZE [gfx950 16-B/lane correction] + WRITE_SIZE, bytes per launch; recorded by "
                                       "rocprofv3 --pmc passes over this workload, not inside this process)")
+            # tie the attached counters to the code that is being timed: the profile carries the source hash it was recorded on
+            # (tools/pmc_summary.py), the library the hash it was built from (eaz_build_hash)
+            from e_alphazero_amd import _lib
+            rec, built = pmc.get("source_hash"), _lib.build_hash()
+            roof["traffic_source_hash"] = rec
+            roof["library_hash"] = built
+            roof["traffic_source_status"] = "current" if rec == built else \
+                (f"stale: recorded on sources {rec}, the library being timed was built from {built}" if rec else
+                 f"stale: recorded before profiles carried a source hash (library: {built})")
             break
     fields["roofline"] = roof
     # ---- leaf gather (north-star: >= 40 % of the HBM roof on the leaf-gather kernel) ----

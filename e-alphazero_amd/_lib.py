@@ -113,12 +113,35 @@ def load():
         L = C.CDLL(LIB_PATH)
         L.eaz_last_error.restype = C.c_char_p
         L.eaz_last_error.argtypes = []
+        L.eaz_build_hash.restype = C.c_char_p
+        L.eaz_build_hash.argtypes = []
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = C.c_int
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def source_hash() -> str:
+    """First 12 hex digits of the SHA-256 over csrc/*.hip, csrc/*.hpp (sorted by name) and include/eaz.h of this tree -- what
+    csrc/Makefile bakes into the library as eaz_build_hash().  No GPU, no library needed."""
+    import glob
+    import hashlib
+
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")), key=os.path.basename)
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "eaz.h"))
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
+def build_hash() -> str:
+    """The source hash the loaded libeaz.so was built from (eaz_build_hash)."""
+    return load().eaz_build_hash().decode()
 
 
 def check(rc: int) -> None:

@@ -49,6 +49,10 @@ static int fail(const char* fmt, ...) {
 
 extern "C" const char* eaz_last_error(void) { return g_err.c_str(); }
 extern "C" int eaz_version(void) { return 100; }
+#ifndef EAZ_SRC_HASH
+#define EAZ_SRC_HASH "unknown"
+#endif
+extern "C" const char* eaz_build_hash(void) { return EAZ_SRC_HASH; }
 
 static inline int cdiv(long a, long b) { return static_cast<int>((a + b - 1) / b); }
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -81,6 +85,9 @@ struct eaz_net {
     float* d_sim_matrix;                  // NetDev::sim_matrix storage (SimHash)
     unsigned long long* d_kstep_counter;  // executed layer-1 k-steps (profiling only; nullptr = off)
     unsigned long long* d_kstep_storage;
+    float* d_w1q[4];        // NetDev::w1q storage (built on the first Subleq-16 one-launch call, sq16_pack_w1)
+    uint64_t w_stamp;       // counts weight uploads (create, eaz_net_set_weights)
+    uint64_t w1q_stamp;     // the upload d_w1q was packed from
 };
 
 struct ProfSpan {
@@ -448,6 +455,8 @@ static int net_create_fc_impl(eaz_net* n, int in_dim, int hidden, int num_action
     HIP_OK(hipMalloc(&n->d_kstep_storage, 8 * sizeof(unsigned long long)));
     HIP_OK(hipMemset(n->d_kstep_storage, 0, 8 * sizeof(unsigned long long)));
     n->d_kstep_counter = nullptr;
+    n->dev.l1q_mode = -1;
+    n->w_stamp = 1;
     return 0;
 }
 
@@ -566,6 +575,7 @@ extern "C" int eaz_net_destroy(eaz_net* n) {
     if (n->d_hot_index) (void)hipFree(n->d_hot_index);
     if (n->d_sim_matrix) (void)hipFree(n->d_sim_matrix);
     if (n->d_kstep_storage) (void)hipFree(n->d_kstep_storage);
+    for (int h = 0; h < 4; ++h) if (n->d_w1q[h]) (void)hipFree(n->d_w1q[h]);
     delete n;
     return 0;
 }
@@ -579,6 +589,7 @@ extern "C" int eaz_net_set_weights(eaz_net* n, const float* const* h_w, const fl
         HIP_OK(hipMemcpyAsync(n->d_w[l], h_w[l], sizeof(float) * k * m, hipMemcpyHostToDevice, S(stream)));
         HIP_OK(hipMemcpyAsync(n->d_b[l], h_b[l], sizeof(float) * m, hipMemcpyHostToDevice, S(stream)));
     }
+    n->w_stamp += 1;  // derived device copies (d_w1q) are rebuilt by their next user
     return 0;
 }
 
@@ -669,6 +680,11 @@ extern "C" int eaz_tune_set(int knob, int value) {
     if (knob == EAZ_TUNE_SHARDS) {
         ARG_OK(value == 0 || value == 1 || value == 2 || value == 4);  // 8 / 16 streams measured 328 k / 192 k env-steps/s at C3 (4: 559 k)
         g_shards = value;
+        return 0;
+    }
+    if (knob == EAZ_TUNE_SUBLEQ_WAVE) {
+        ARG_OK(value == 0 || value == 1);
+        g_subleq_wave = value;
         return 0;
     }
     if (knob == EAZ_TUNE_FC_TILE) {
@@ -1135,7 +1151,21 @@ static bool sqp_eligible(const eaz_search* s) {
         if (s->env->dev.tasks[i] < -32768 || s->env->dev.tasks[i] > 32767) return false;
     return true;
 }
+// layer-1 weights in the one-launch kernel's packed input order (sq16_l1_src), rebuilt on the launch stream after every weight upload
+static int sq16_pack_w1(eaz_net* n, int mode, hipStream_t st) {
+    if (n->dev.l1q_mode == mode && n->w1q_stamp == n->w_stamp) return 0;
+    const int rows = 32 * sq16_l1_halves(0);  // the larger of the two modes
+    for (int h = 0; h < 4; ++h)
+        if (!n->d_w1q[h]) { HIP_OK(hipMalloc(&n->d_w1q[h], sizeof(float) * rows * kFcH)); n->dev.w1q[h] = n->d_w1q[h]; }
+    sq16_pack_w1_kernel<<<dim3(32 * sq16_l1_halves(mode), 4), 256, 0, st>>>(n->dev, mode, n->d_w1q[0], n->d_w1q[1], n->d_w1q[2], n->d_w1q[3]);
+    LAUNCH_OK();
+    n->dev.l1q_mode = mode; n->dev.l1q_halves = sq16_l1_halves(mode);
+    n->w1q_stamp = n->w_stamp;
+    return 0;
+}
 static int sqp_launch(eaz_search* s, const PersistSelfplay& sp, hipStream_t st) {
+    const int rc = sq16_pack_w1(s->net, 0, st);
+    if (rc) return rc;
     Sq16SelfplayArgs a;
     a.sp = sp;
     a.t = s->tree;
@@ -1855,10 +1885,10 @@ extern "C" __attribute__((visibility("default"))) int eaz_diag_qp_fwd(unsigned l
     HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_qp_fwd), sizeof(unsigned long long) * 2048 * 8));
     return 0;
 }
-extern "C" __attribute__((visibility("default"))) int eaz_diag_qp_rounds(unsigned long long* h_out /* [2048*32] */) {
+extern "C" __attribute__((visibility("default"))) int eaz_diag_qp_rounds(unsigned long long* h_out /* [2048*64] */) {
     ARG_OK(h_out != nullptr);
     HIP_OK(hipDeviceSynchronize());
-    HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_qp_rounds), sizeof(unsigned long long) * 2048 * 32));
+    HIP_OK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_qp_rounds), sizeof(unsigned long long) * 2048 * 64));
     return 0;
 }
 extern "C" __attribute__((visibility("default"))) int eaz_diag_qp_ehist(unsigned long long* h_out /* [128] */, int reset) {

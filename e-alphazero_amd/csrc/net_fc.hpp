@@ -40,6 +40,10 @@ struct NetDev {
     const uint32_t* ztab;  // device [4][hash_len/4 + 1]: accumulator of hash lane i after n all-zero stripes (one-hot fast path)
     const uint32_t* hot_index;  // device [in_dim]: get_indices() of the row that is zero except obs[h] = 1 (hashes.py:162-229 / :124-139)
     const float* sim_matrix;    // non-null: hash_class = SimHash, random matrix [hash_len, hash_bits] (hashes.py:124-139)
+    // Subleq-16 one-launch kernel (search_subleq_persist.hpp): layer-1 weights of the four heads in its packed input order (sq16_l1_src),
+    // [32 l1q_halves][256] each; l1q_mode -1: not built
+    const float* w1q[4];
+    int l1q_mode, l1q_halves;
 };
 
 struct NetOut {

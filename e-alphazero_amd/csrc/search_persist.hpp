@@ -143,6 +143,21 @@ __device__ __forceinline__ eaz_deepsea_state ps_unpack(uint32_t w) {
 
 // LDS traffic between the lanes of one wavefront: DS operations of a wave execute in issue order, so only the compiler has to be
 // kept from reordering them
+// Work-queue claim of the one-launch Subleq kernels: `counter` (an LDS address) += 1 by ONE lane, returns the value before the add to the
+// whole wavefront.  Written as the instructions themselves: `atomicAdd` goes through the compiler's atomic optimizer, which turned the
+// lane-0 form into a loop that never ended in the release build and the all-lane form into a 64-iteration scan behind vmcnt(0) (DESIGN.md
+// 4.4).  exec is narrowed to lane 0 around the ds_add_rtn_u32, so the claim does not depend on how the LDS orders the 64 same-address adds
+// of one wavefront against another wavefront's (rounds 2-3 issued it from all 64 lanes and divided by 64).  Call with all lanes active.
+__device__ __forceinline__ int lds_claim_one(const uint32_t counter_lds_addr) {
+    int got;
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, %1"
+                 : "=&v"(got), "=&s"(saved)
+                 : "v"(counter_lds_addr), "v"(1)
+                 : "memory");
+    return __builtin_amdgcn_readfirstlane(got);
+}
+
 __device__ __forceinline__ void ps_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -166,10 +166,7 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
                 }
                 taken += 1;
                 EAZ_ESTAMP(taken < 3 ? taken : 3);
-                // one ds_add_rtn by all 64 lanes (lane 0 reads the counter before this wave's 64 increments: the counter runs in units of 64)
-                int got;
-                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(env_next_off), "v"(1) : "memory");
-                j = kSqWaves + (__builtin_amdgcn_readfirstlane(got) >> 6);
+                j = kSqWaves + lds_claim_one(env_next_off);  // one lane, one ds_add_rtn_u32 (search_persist.hpp)
             }
         }
         EAZ_QSTAMP(3);

@@ -164,14 +164,14 @@ __device__ unsigned long long g_qp_fwd[2048 * 8];  // diagnostic build: stamps i
         }                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                             \
     } while (0)
-__device__ unsigned long long g_qp_rounds[2048 * 32];  // diagnostic build: stamps after every round of 16 k-steps of the stamped forward, [workgroup * 8 + wave][head * 8 + layer * 4 + round]
+__device__ unsigned long long g_qp_rounds[2048 * 64];  // diagnostic build: stamps after every half-round of 8 k-steps of the stamped forward, [workgroup * 8 + wave][head * 16 + layer * 8 + half-round]
 #define EAZ_QRSTAMP(i)                                                                                 \
     do {                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                             \
         if (step == 0 && s == 1 + S / 2 && (tid & 63) == 0 && blockIdx.x < 256) {                      \
             unsigned long long t_;                                                                     \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
-            g_qp_rounds[(blockIdx.x * 8 + (tid >> 6)) * 32 + (i)] = t_;                                \
+            g_qp_rounds[(blockIdx.x * 8 + (tid >> 6)) * 64 + (i)] = t_;                                \
         }                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                             \
     } while (0)
@@ -223,15 +223,38 @@ __device__ __forceinline__ uint32_t qp_hdr(int step, int term, int trunc, int so
 // observation code of a row-word: bits 0..3 = v mod 16, bit 4 = (v == 16)  (subleq.py:88-98)
 __device__ __forceinline__ uint8_t qp_code(uint32_t v) { return static_cast<uint8_t>((v & 15u) | (v == 16u ? 16u : 0u)); }
 
+// Layer 1's packed input order (Sq16 one-launch kernel only; sq16_pack_w1_kernel builds the device copy of W1 in the same order).  An input that is
+// structurally zero contributes fmaf(0, w, acc) = acc, bit for bit, so it is left out of the chain; the others keep their ascending order:
+//   mode 0: 224 inputs -- the four value bits of the 16 memory words (a memory word is < 16 here, so its pad flag, subleq.py:88-98, is always
+//           0: 16 of the 240 inputs never fire), then the four IO rows as they are (observation inputs 80..239);
+//   mode 1: 144 inputs -- memory bits, then input_after and output_after; the example_input / example_output rows are constants of the tree
+//           and start the chain as a per-tree partial sum (the network's "constant inputs first" input order, NetDev::order).
+// Returns the observation index of packed input kp, or -1 for a zero row of the device copy.
+__host__ __device__ inline int sq16_l1_src(int mode, int kp) {
+    if (kp < 64) return 5 * (kp >> 2) + (kp & 3);
+    const int q = kp - 64;
+    if (mode == 0) return q < 160 ? 80 + q : -1;
+    return q < 40 ? 120 + q : (q < 80 ? 160 + q : -1);
+}
+__host__ __device__ inline int sq16_l1_halves(int mode) { return mode == 0 ? 7 : 5; }  // half-rounds of 8 k-steps (32 inputs) of layer 1
+// device copy of a head's layer-1 weights in the packed order: out[kp][c] = W1[sq16_l1_src(kp)][c], zero rows where the source is -1;
+// grid = (32 x half-rounds, 4 heads), 256 threads = the hidden columns
+__global__ void __launch_bounds__(256) sq16_pack_w1_kernel(NetDev net, int mode, float* o0, float* o1, float* o2, float* o3) {
+    const int kp = blockIdx.x, head = blockIdx.y, c = threadIdx.x;
+    float* out = head == 0 ? o0 : (head == 1 ? o1 : (head == 2 ? o2 : o3));
+    const int src = sq16_l1_src(mode, kp);
+    out[kp * kFcH + c] = src >= 0 ? net.w[head * 3][src * kFcH + c] : 0.0f;
+}
+
 // The observation of a state, twice: the 48 row-words (memory | example_input | input_after | example_output | output_after,
-// subleq.py:679-707) as 5-bit codes for the novelty hash, and the 240 observation bits themselves (bit 5 w + j = bit j of row-word w's
-// code, subleq.py:88-98; inputs 240..255 zero) as FP8 bytes in layer 1's operand order (QpMisc::obytes).  Lane w < 48 computes the code of
-// row-word w; bit k of the observation is fetched from the lane that holds its word (ds_bpermute) and stored as its byte.
+// subleq.py:679-707) as 5-bit codes for the novelty hash, and the observation bits themselves (bit 5 w + j = bit j of row-word w's
+// code, subleq.py:88-98) in layer 1's packed input order (sq16_l1_src) as FP8 bytes in the operand order of the MFMA lanes (QpMisc::obytes).
+// Lane w < 48 computes the code of row-word w; a packed input is fetched from the lane that holds its word (ds_bpermute) and stored as its byte.
 // The 16-byte words of a row of QpMisc::obytes are stored at position (word ^ swz(row)): the rows are 256 bytes = 64 banks apart, so the forward's
-// ds_read_b128 of word c from all 16 rows would hit the same four banks 16 times; swz = bits 8..11 of the row's LDS address (one more per row).
+// reads of one word from all 16 rows would hit the same banks 16 times; swz = bits 8..11 of the row's LDS address (one more per row).
 __device__ __forceinline__ int qp_ob_swz(const uint8_t* row) { return static_cast<int>((reinterpret_cast<uintptr_t>(row) >> 8) & 15u); }
 __device__ __forceinline__ void qp_emit_obs(uint8_t* words, uint8_t* ob, unsigned long long mem, unsigned long long exin, unsigned long long inaf,
-                                            unsigned long long exout, unsigned long long outaf, int lane) {
+                                            unsigned long long exout, unsigned long long outaf, int lane, const int l1_mode) {
     uint32_t code = 0u;
     if (lane < 16) {
         code = static_cast<uint32_t>(mem >> (4 * lane)) & 15u;
@@ -242,61 +265,86 @@ __device__ __forceinline__ void qp_emit_obs(uint8_t* words, uint8_t* ob, unsigne
     }
     if (lane < 48) words[lane] = static_cast<uint8_t>(code);
     const int swz = qp_ob_swz(ob);
+    const int np = l1_mode == 0 ? 4 : 3;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const int k = 64 * p + lane;
-        const int w = (k * 52429) >> 18, j = k - 5 * w;  // k / 5 for k < 2^14
-        const uint32_t c = static_cast<uint32_t>(__shfl(static_cast<int>(code), w < 48 ? w : 0));
-        const int idx = 64 * (k & 3) + (k >> 2);
-        ob[(((idx >> 4) ^ swz) << 4) | (idx & 15)] = (w < 48 && ((c >> j) & 1u) != 0) ? static_cast<uint8_t>(0x38) : static_cast<uint8_t>(0);
+        if (p >= np) break;
+        const int kp = 64 * p + lane;  // packed input: byte 64 (kp & 3) + (kp >> 2) of the row
+        int w = 0, j = 0;
+        bool valid = true;
+        if (p == 0) {
+            w = lane >> 2; j = lane & 3;
+        } else {
+            const int q = kp - 64;
+            const int wq = (q * 52429) >> 18;  // q / 5 for q < 2^14
+            j = q - 5 * wq;
+            if (l1_mode == 0) { w = 16 + wq; valid = q < 160; }
+            else { w = 24 + wq + (wq >= 8 ? 8 : 0); valid = q < 80; }
+        }
+        const uint32_t c = static_cast<uint32_t>(__shfl(static_cast<int>(code), valid ? w : 0));
+        const int idx = 64 * (kp & 3) + (kp >> 2);
+        ob[(((idx >> 4) ^ swz) << 4) | (idx & 15)] = (valid && ((c >> j) & 1u) != 0) ? static_cast<uint8_t>(0x38) : static_cast<uint8_t>(0);
     }
 }
 
-// One round of the forward's weight stream (search_persist.hpp ps_round): 16 k-steps of four MFMAs each on the prefetched weights Bq,
-// every k-step followed by the refill of its registers.  ABITS: layer 1, A operand = a bit of `abits` as a float; otherwise layer 2,
-// A operands from the H1 tile kPsARing k-steps ahead.  CHAIN: the round also carries the 16 dependent MFMAs of the previous head's
-// layer-3 quarter chain (A from the H2 columns this wave wrote, B = `w3` in registers).
-// layer 1: the A operands of a round's 16 k-steps are the 16 FP8 bytes of one uint4 of QpMisc::obytes; one v_cvt_pk_f32_fp8 converts two of
-// them.  Every VALU instruction between the MFMAs of this loop costs ~18 clocks (it waits for the matrix pipe's passes): with a v_bfe + v_cvt
-// pair per k-step on the observation's bits a layer-1 round took 2 650 clocks against 2 176 for a layer-2 round, whose operand is a ds_read.
+// One half-round of the forward's weight stream (search_persist.hpp ps_round, in halves): 8 k-steps of four MFMAs each on the prefetched weights
+// Bq[8 PH .. 8 PH + 7], every k-step followed by the refill of its registers with the k-step the same registers serve next -- the next half-round
+// of the same phase PH, 16 k-steps ahead in the stream (`rs`, `sbase`).  The stream W1(h) | W2(h) | W1(h + 1) ... is 7 (or 5) + 8 half-rounds per
+// head, an odd number, so the phases alternate from head to head (static: the head loop is unrolled) and after the third head one phase is
+// skipped (its registers were refilled half a round early; nothing is issued for it), which makes every forward start in phase 0.
+// ABITS: layer 1, the A operands of the 8 k-steps are the 8 FP8 bytes of one uint2 of QpMisc::obytes, one v_cvt_pk_f32_fp8 converts two of
+// them (every VALU instruction between the MFMAs of this loop costs ~18 clocks: with a v_bfe + v_cvt pair per k-step on the observation's
+// bits a layer-1 round of 16 k-steps took 2 650 clocks against 2 176 for a layer-2 round, whose operand is a ds_read); otherwise layer 2, A
+// operands from the H1 tile kPsARing k-steps ahead.  CHAIN 1 / 2: the half-round also carries dependent MFMAs 0..7 / 8..15 of the previous
+// head's layer-3 quarter chain (A from the H2 columns this wave wrote, B = `w3` in registers).
 typedef float floatx2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ floatx2 qp_abytes2(const uint4& w, const int i /* even k-step of the round */) {
-    const uint32_t d = (i >> 2) == 0 ? w.x : ((i >> 2) == 1 ? w.y : ((i >> 2) == 2 ? w.z : w.w));
+__device__ __forceinline__ floatx2 qp_abytes2(const uint2& w, const int i /* even k-step of the half-round */) {
+    const uint32_t d = (i >> 2) == 0 ? w.x : w.y;
     return (i & 2) ? __builtin_amdgcn_cvt_pk_f32_fp8(static_cast<int>(d), true) : __builtin_amdgcn_cvt_pk_f32_fp8(static_cast<int>(d), false);
 }
 constexpr int kQpAAhead = 2;  // layer 1: a pair of A operands is converted this many k-steps before the MFMAs that read them (ring av[])
-template <bool CHAIN, bool ABITS>
-__device__ __forceinline__ void qp_round(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDepth], float (&av)[kPsARing], const float* apn, const uint4 abits,
-                                         const uint4 abits_next, __amdgpu_buffer_rsrc_t rs, int voff, int sbase, floatx4& a3, const float* hpA,
-                                         const float (&w3)[16]) {
-    static_assert(kPsDepth == 16 && kPsDepth % kPsARing == 0 && kQpAAhead < kPsARing, "a round is 16 k-steps; the operand ring runs on across rounds");
+constexpr int kQpHalf = 8;    // k-steps of a half-round
+template <int CHAIN, bool ABITS, int PH>
+__device__ __forceinline__ void qp_half(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDepth], float (&av)[kPsARing], const float* apn, const uint2 abits,
+                                        const uint2 abits_next, __amdgpu_buffer_rsrc_t rs, int voff, int sbase, floatx4& a3, const float* hpA,
+                                        const float (&w3)[16]) {
+    static_assert(kPsDepth == 2 * kQpHalf && kPsARing == kQpHalf && kQpAAhead < kPsARing && kChRing <= kQpHalf, "two half-rounds fill the weight ring; the operand ring is one half-round");
+    constexpr int C0 = CHAIN == 2 ? 8 : 0;
     float cha[kChRing];
-    if constexpr (CHAIN) {
+    if constexpr (CHAIN != 0) {
 #pragma unroll
-        for (int qq = 0; qq < kChRing; ++qq) cha[qq] = hpA[68 * qq];
+        for (int qq = 0; qq < kChRing; ++qq) cha[qq] = hpA[68 * (C0 + qq)];
     }
 #pragma unroll
-    for (int i = 0; i < kPsDepth; ++i) {
-        // layer 1: av[] holds the operands of k-steps i .. i + kQpAAhead - 1 on entry (of this round; the last k-steps fill in the next round's)
-        const float aop = av[i % kPsARing];
+    for (int i = 0; i < kQpHalf; ++i) {
+        // layer 1: av[] holds the operands of k-steps i .. i + kQpAAhead - 1 on entry (of this half-round; the last k-steps fill in the next one's)
+        const float aop = av[i];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, Bq[i][c], acc[c], 0, 0, 0);
-        if constexpr (CHAIN) {
-            a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(cha[i % kChRing], w3[i], a3, 0, 0, 0);
-            if (i + kChRing < 16) cha[i % kChRing] = hpA[68 * (i + kChRing)];
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, Bq[kQpHalf * PH + i][c], acc[c], 0, 0, 0);
+        if constexpr (CHAIN != 0) {
+            a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(cha[i % kChRing], w3[C0 + i], a3, 0, 0, 0);
+            if (i + kChRing < kQpHalf) cha[i % kChRing] = hpA[68 * (C0 + i + kChRing)];
         }
-        Bq[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sbase + i * 4096, 0));
+        Bq[kQpHalf * PH + i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sbase + i * 4096, 0));
         if constexpr (ABITS) {
             if ((i & 1) == 0) {
-                const floatx2 f = i + kQpAAhead < kPsDepth ? qp_abytes2(abits, i + kQpAAhead) : qp_abytes2(abits_next, i + kQpAAhead - kPsDepth);
+                const floatx2 f = i + kQpAAhead < kQpHalf ? qp_abytes2(abits, i + kQpAAhead) : qp_abytes2(abits_next, i + kQpAAhead - kQpHalf);
                 av[(i + kQpAAhead) % kPsARing] = f[0];
                 av[(i + kQpAAhead + 1) % kPsARing] = f[1];
             }
         } else {
-            av[i % kPsARing] = apn[i * 68];
+            av[i] = apn[i * 68];
         }
         __builtin_amdgcn_sched_barrier(0);  // keep every refill right behind the k-step that freed its registers
     }
+}
+// the same with the phase as an argument (a constant once the head loop is unrolled)
+template <int CHAIN, bool ABITS>
+__device__ __forceinline__ void qp_half_ph(const int ph, floatx4 (&acc)[4], floatx4 (&Bq)[kPsDepth], float (&av)[kPsARing], const float* apn, const uint2 abits,
+                                           const uint2 abits_next, __amdgpu_buffer_rsrc_t rs, int voff, int sbase, floatx4& a3, const float* hpA,
+                                           const float (&w3)[16]) {
+    if (ph == 0) qp_half<CHAIN, ABITS, 0>(acc, Bq, av, apn, abits, abits_next, rs, voff, sbase, a3, hpA, w3);
+    else qp_half<CHAIN, ABITS, 1>(acc, Bq, av, apn, abits, abits_next, rs, voff, sbase, a3, hpA, w3);
 }
 
 // pgx.Env.step (A.1) around subleq.py:648-677 for ONE environment on one wavefront, compact state `src` (LDS) -> `dst` (LDS), everything
@@ -304,7 +352,8 @@ __device__ __forceinline__ void qp_round(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDep
 // blob: also the 336-byte state of include/eaz.h (real steps); words: the observation's row-words.  Returns the reward / terminated flag.
 __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src, uint32_t* dst, const uint32_t* root_ex, uint8_t* words,
                                             uint8_t* xb, const int action, const int mode, const Key envkey, const int b, const int lane, char* blob0,
-                                            char* blob1, float& reward_out, int& term_out, int16_t* tree_task, unsigned long long* dstamp = nullptr) {
+                                            char* blob1, float& reward_out, int& term_out, int16_t* tree_task, const int l1_mode,
+                                            unsigned long long* dstamp = nullptr) {
     EAZ_QESTAMP(dstamp, 8);
     uint32_t s[QS_WORDS];
 #pragma unroll
@@ -419,7 +468,7 @@ __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src
                            __builtin_bit_cast(uint32_t, reward));
     }
     EAZ_QESTAMP(dstamp, 11);
-    qp_emit_obs(words, xb, mem, exin, inaf, exout, outaf, lane);
+    qp_emit_obs(words, xb, mem, exin, inaf, exout, outaf, lane, l1_mode);
     EAZ_QESTAMP(dstamp, 12);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -556,7 +605,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             M.b12[h][l][c] = a.net.b[a.heads.id[h] * 3 + l][c];
         }
         if (tid < 18) M.b3[tid] = tid < 2 ? a.net.b[a.heads.id[tid] * 3 + 2][0] : a.net.b[a.heads.id[2] * 3 + 2][tid - 2];
-        const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.net.w[a.heads.id[0] * 3]), 0, fp_kpad(240) * kFcH * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.net.w1q[a.heads.id[0]]), 0, a.net.l1q_halves * kQpHalf * 4096, 0x00020000);
         if (wave < 4) {
 #pragma unroll
             for (int i = 0; i < kPsDepth; ++i) Bq[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs0, fvoff, i * 4096, 0));
@@ -588,7 +637,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             M.root_ex[j][0] = static_cast<uint32_t>(exin); M.root_ex[j][1] = static_cast<uint32_t>(exin >> 32);
             M.root_ex[j][2] = static_cast<uint32_t>(exout); M.root_ex[j][3] = static_cast<uint32_t>(exout >> 32);
         }
-        qp_emit_obs(M.words[j], M.obytes[j], mem, exin, inaf, exout, outaf, lane);
+        qp_emit_obs(M.words[j], M.obytes[j], mem, exin, inaf, exout, outaf, lane, a.net.l1q_mode);
     }
     {
         // per-tree scalars of the whole launch; search only: the root the caller prepared (eaz_search_begin -> tree_root_kernel: masked prior
@@ -942,13 +991,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 const uint32_t env_next_off = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) int*)(&M.env_next)));
                 // every wave starts on its own environment, then takes what is left, one at a time: the runs are heavy-tailed
                 const int n_static = 8;
-                auto claim = [&]() {
-                    // one ds_add_rtn by all 64 lanes (lane 0 reads the counter before this wave's 64 increments: the counter runs in units of 64),
-                    // written as the instruction itself: `atomicAdd` goes through the compiler's atomic optimizer (a lane scan behind vmcnt(0))
-                    int got;
-                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(env_next_off), "v"(1) : "memory");
-                    return n_static + (__builtin_amdgcn_readfirstlane(got) >> 6);
-                };
+                auto claim = [&]() { return n_static + lds_claim_one(env_next_off); };  // one lane, one ds_add_rtn_u32 (search_persist.hpp)
                 // queue position -> environment: by descending key, ties by index (every wave ranks the 16 keys itself: lanes 0..15)
                 int rank = 0;
                 if (env_mode == 0) {
@@ -990,7 +1033,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                         unsigned long long* dsp = nullptr;
 #endif
                         qp_env_step(a.e, SJ + node * QS_WORDS, SJ + dstn * QS_WORDS, M.root_ex[j], M.words[j], M.obytes[j], action, 0, env_key, bj, lane,
-                                    nullptr, nullptr, rew, term, &M.task[j], dsp);
+                                    nullptr, nullptr, rew, term, &M.task[j], a.net.l1q_mode, dsp);
                         EAZ_QESTAMP(dsp, 14);
 #ifdef EAZ_FC_STAMPS
                         if (step == 0 && blockIdx.x < 64 && s <= 64) {
@@ -1007,7 +1050,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                         char* blob0 = (jlive && a.sp.out_states) ? a.sp.out_states + o * sizeof(eaz_subleq_state) : nullptr;
                         char* blob1 = (jlive && step == n_steps) ? a.sp.states + static_cast<long>(bj) * sizeof(eaz_subleq_state) : nullptr;
                         qp_env_step(a.e, M.root_state[j], M.root_state[j], M.root_ex[j], M.words[j], M.obytes[j], action, 1, env_key, bj, lane, blob0, blob1,
-                                    rew, term, &M.task[j]);
+                                    rew, term, &M.task[j], a.net.l1q_mode);
                     }
                     j = env_at(claim());
                 }
@@ -1031,44 +1074,53 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             // ================= waves 0-3: layers 1-3 of the three heads for the 16 rows; barriers: H1 of head 0, 1, 2 | quarter sums =================
             EAZ_QP_ARGS;
             EAZ_QP_FWD_LANES;
+            const int n1 = a.net.l1q_halves;  // half-rounds of layer 1: 7 (224 packed inputs) or 5 (144 + 16 zero rows), sq16_l1_halves
             __amdgpu_buffer_rsrc_t W1r[3], W2r[3];
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
-                W1r[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.net.w[a.heads.id[h] * 3]), 0, fp_kpad(240) * kFcH * 4, 0x00020000);
+                W1r[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.net.w1q[a.heads.id[h]]), 0, n1 * kQpHalf * 4096, 0x00020000);
                 W2r[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.net.w[a.heads.id[h] * 3 + 1]), 0, kFcH * kFcH * 4, 0x00020000);
             }
             // layer-3 weights of this wave's quarter of k as MFMA B operands (W3[64 w + 4 q + kq][r]): ONE set of 16 registers, requested
             // ~10 k cycles before the chain that consumes it.  First the two one-output heads together: B column 0 = W3 of the value head,
             // column 1 = W3 of the ube head (a chain then also produces the other head's column from the wrong hidden tile, which nobody
-            // reads); once the ube head's chain has run (first round of the third head) the policy head's weights take their place.
+            // reads); once the ube head's chain has run (first half-rounds of the third head) the policy head's weights take their place.
             float w3v[16];
             {
                 const float* pwv = a.net.w[a.heads.id[fr == 1 ? 1 : 0] * 3 + 2] + (fn0 + fkq);
 #pragma unroll
                 for (int qq = 0; qq < 16; ++qq) { const float wv = pwv[4 * qq]; w3v[qq] = fr < 2 ? wv : 0.0f; }
             }
-            const uint4* xrow_base = reinterpret_cast<const uint4*>(&M.obytes[fr][0]);  // this lane's layer-1 A operands: four rounds of 16 FP8 bytes,
-            const int xswz = qp_ob_swz(&M.obytes[fr][0]);                              // words 4 kq .. 4 kq + 3 of the row (swizzled, qp_ob_swz)
-            auto xrow = [&](int rd) { return xrow_base[(4 * fkq + rd) ^ xswz]; };
+            // this lane's layer-1 A operands: half-round j = the 8 FP8 bytes 64 kq + 8 j .. + 7 of the row (16-byte words swizzled, qp_ob_swz)
+            const uint8_t* xrow_base = &M.obytes[fr][0];
+            const int xswz = qp_ob_swz(xrow_base);
+            auto xrow = [&](int j) { return *reinterpret_cast<const uint2*>(xrow_base + ((((4 * fkq + (j >> 1)) ^ xswz) << 4) | ((j & 1) << 3))); };
             const float* hpA = H2 + h16_off(fn0 + fkq, fr);  // quarter chain: H2[h16_off(n0 + 4 q + kq, r)] = hpA[68 q]
             float av[kPsARing];
+            constexpr int kHalfBytes = kQpHalf * 4096;  // one half-round of the weight stream
             EAZ_QWSTAMP(0);
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
+                const int P = h & 1;               // phase of this head's first half-round (qp_half)
+                const int hn = h == 2 ? 0 : h + 1;  // the head whose layer 1 follows in the stream
                 floatx4 acc[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
                 floatx4 a3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-                // ---- layer 1: [16 x 256] x [256 x 256], inputs 240..255 zero on both sides (exact); the first round carries the quarter chain
-                // of the head before ----
-                uint4 xcur = xrow(0), xnext = xrow(1);
+                // ---- layer 1: [16 x 32 n1] x [32 n1 x 256] on the packed inputs (sq16_l1_src); half-round e refills its registers for half-round
+                // e + 2 of the head's sequence L1_0 .. L1_(n1-1), L2_0 .. L2_7; the first two carry the quarter chain of the head before ----
+                uint2 xcur = xrow(0), xnext = xrow(1);
                 {
                     const floatx2 f = qp_abytes2(xcur, 0);
                     av[0] = f[0]; av[1] = f[1];
                 }
-                if (h > 0) qp_round<true, true>(acc, Bq, av, nullptr, xcur, xnext, W1r[h], fvoff, 4096 * kPsDepth, a3, hpA, w3v);
-                else qp_round<false, true>(acc, Bq, av, nullptr, xcur, xnext, W1r[h], fvoff, 4096 * kPsDepth, a3, hpA, w3v);
-                EAZ_QRSTAMP(h * 8);
+                if (h > 0) qp_half_ph<1, true>(P, acc, Bq, av, nullptr, xcur, xnext, W1r[h], fvoff, 2 * kHalfBytes, a3, hpA, w3v);
+                else qp_half_ph<0, true>(P, acc, Bq, av, nullptr, xcur, xnext, W1r[h], fvoff, 2 * kHalfBytes, a3, hpA, w3v);
+                EAZ_QRSTAMP(h * 16);
+                xcur = xnext; xnext = xrow(2);
+                if (h > 0) qp_half_ph<2, true>(P ^ 1, acc, Bq, av, nullptr, xcur, xnext, W1r[h], fvoff, 3 * kHalfBytes, a3, hpA, w3v);
+                else qp_half_ph<0, true>(P ^ 1, acc, Bq, av, nullptr, xcur, xnext, W1r[h], fvoff, 3 * kHalfBytes, a3, hpA, w3v);
+                EAZ_QRSTAMP(h * 16 + 1);
                 if (h > 0 && fr == h - 1) {  // head 0 = value: output column 0, head 1 = ube: column 1 (shared W3 registers)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) part[(fw * 16 + 4 * fkq + reg) * kQpPartLd + fr] = a3[reg];
@@ -1079,14 +1131,18 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                     for (int qq = 0; qq < 16; ++qq) w3v[qq] = pwp[4 * qq * kQpA];
                 }
 #pragma unroll 1
-                for (int rd = 1; rd < 4; ++rd) {
-                    const bool same = rd < 3;  // the refills of the last round are the first k-steps of layer 2
-                    xcur = xnext;
-                    xnext = xrow(same ? rd + 1 : 3);  // (the last round converts nothing of it that is used: layer 2 refills the ring)
-                    qp_round<false, true>(acc, Bq, av, nullptr, xcur, xnext, same ? W1r[h] : W2r[h], fvoff,
-                                          same ? 4096 * kPsDepth * (rd + 1) : 0, a3, hpA, w3v);
-                    EAZ_QRSTAMP(h * 8 + rd);
+                for (int j = 2; j + 1 < n1; j += 2) {  // n1 is odd: pairs (2, 3), (4, 5), ... then the single half-round n1 - 1
+                    xcur = xnext; xnext = xrow(j + 1);
+                    qp_half_ph<0, true>(P, acc, Bq, av, nullptr, xcur, xnext, W1r[h], fvoff, (j + 2) * kHalfBytes, a3, hpA, w3v);
+                    EAZ_QRSTAMP(h * 16 + j);
+                    xcur = xnext; xnext = xrow(j + 2);
+                    const bool same = j + 3 < n1;  // otherwise: the first half-round of layer 2
+                    qp_half_ph<0, true>(P ^ 1, acc, Bq, av, nullptr, xcur, xnext, same ? W1r[h] : W2r[h], fvoff, same ? (j + 3) * kHalfBytes : 0, a3, hpA, w3v);
+                    EAZ_QRSTAMP(h * 16 + j + 1);
                 }
+                xcur = xnext;  // (the last half-round converts nothing of `abits_next` that is used: layer 2 refills the ring)
+                qp_half_ph<0, true>(P, acc, Bq, av, nullptr, xcur, xcur, W2r[h], fvoff, kHalfBytes, a3, hpA, w3v);
+                EAZ_QRSTAMP(h * 16 + n1 - 1);
                 EAZ_QWSTAMP(1 + 2 * h);
                 {
                     float* Ht = H1 + (h & 1) * kF16HFloats;
@@ -1103,7 +1159,8 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                     }
                 }
                 __syncthreads();  // H1 of head h
-                // ---- layer 2: [16 x 256] x [256 x 256]; the refills of the last round are the first k-steps of the next head (next simulation) ----
+                // ---- layer 2: [16 x 256] x [256 x 256], half-rounds in phases P ^ 1, P, ...; the refills of the last two are the first two
+                // half-rounds of the next head (third head: of the next forward, whose first phase is 0 again -- the skipped phase) ----
                 floatx4 acc2[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc2[c] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -1111,12 +1168,15 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
 #pragma unroll
                 for (int i = 0; i < kPsARing; ++i) av[i] = Ap[i * 68];
 #pragma unroll 1
-                for (int rd = 0; rd < 4; ++rd) {
-                    const bool same = rd < 3;
+                for (int j = 0; j < 8; j += 2) {
+                    const bool same = j + 2 < 8;
                     // reads past k-step 63 land in the next tile and are never used
-                    qp_round<false, false>(acc2, Bq, av, Ap + (rd * kPsDepth + kPsARing) * 68, uint4{}, uint4{}, same ? W2r[h] : W1r[h == 2 ? 0 : h + 1], fvoff,
-                                           same ? 4096 * kPsDepth * (rd + 1) : 0, a3, hpA, w3v);
-                    EAZ_QRSTAMP(h * 8 + 4 + rd);
+                    qp_half_ph<0, false>(P ^ 1, acc2, Bq, av, Ap + (j * kQpHalf + kPsARing) * 68, uint2{}, uint2{}, same ? W2r[h] : W1r[hn], fvoff,
+                                         same ? (j + 2) * kHalfBytes : (h == 2 ? kHalfBytes : 0), a3, hpA, w3v);
+                    EAZ_QRSTAMP(h * 16 + 8 + j);
+                    qp_half_ph<0, false>(P, acc2, Bq, av, Ap + ((j + 1) * kQpHalf + kPsARing) * 68, uint2{}, uint2{}, same ? W2r[h] : W1r[hn], fvoff,
+                                         same ? (j + 3) * kHalfBytes : (h == 2 ? 0 : kHalfBytes), a3, hpA, w3v);
+                    EAZ_QRSTAMP(h * 16 + 9 + j);
                 }
                 EAZ_QWSTAMP(2 + 2 * h);
                 const floatx4 bb2 = *reinterpret_cast<const floatx4*>(&M.b12[h][1][fcol]);

@@ -73,9 +73,10 @@ def fingerprint(arrays) -> bytes:
 
 
 def tune(fc_tile: Optional[int] = None, fused_leaf: Optional[int] = None, tree_block: Optional[int] = None,
-         tree_spread: Optional[int] = None, persist: Optional[int] = None, shards: Optional[int] = None) -> None:
+         tree_spread: Optional[int] = None, persist: Optional[int] = None, shards: Optional[int] = None,
+         subleq_wave: Optional[int] = None) -> None:
     """Kernel-selection knobs (include/eaz.h eaz_tune_set); results are identical for every setting."""
-    for knob, v in ((0, fc_tile), (1, fused_leaf), (2, tree_block), (3, tree_spread), (4, persist), (5, shards)):
+    for knob, v in ((0, fc_tile), (1, fused_leaf), (2, tree_block), (3, tree_spread), (4, persist), (5, shards), (6, subleq_wave)):
         if v is not None:
             check(_lib.load().eaz_tune_set(knob, int(v)))
 

@@ -95,7 +95,10 @@ _STATE_LEAVES = ("binary_set", "random_matrix")
 
 def load_npz(path: str):
     """-> (params, state) haiku-style dicts.  Loaded with allow_pickle=False: nothing in the file is executed.  Files without the
-    "params/" / "state/" prefixes (round-1/2 layout) are split by leaf name: hash-module leaves and "/~/" (EMA) modules are state."""
+    "params/" / "state/" prefixes (LEGACY round-1/2 layout only; save_npz and the INTEGRATION.md recipe always write the prefixes) are split by
+    a heuristic: hash-module leaves and "/~/" (EMA) modules are state.  That is right for the reference's networks, whose parameter-holding
+    modules are all created in __call__; a haiku module created inside another module's __init__ would also carry "/~/" in its PARAMETER
+    path, so a legacy file in which a "/~/" module holds a `w` or `b` leaf is ambiguous and refused."""
     z = np.load(path, allow_pickle=False)
     params, state = {}, {}
     for key in z.files:
@@ -105,6 +108,9 @@ def load_npz(path: str):
             (params if head == "params" else state).setdefault(mod, {})[name] = z[key]
         else:
             mod, name = key.rsplit("/", 1)
+            if "/~/" in mod and name in ("w", "b"):
+                raise ValueError(f"{path}: legacy (prefix-less) checkpoint key {key!r} is a weight leaf under a '/~/' module -- cannot tell "
+                                 "parameters from state; re-export with the 'params/' / 'state/' prefixes (INTEGRATION.md, Checkpoints)")
             is_state = name in _STATE_LEAVES or "/~/" in mod
             (state if is_state else params).setdefault(mod, {})[name] = z[key]
     return params, state

@@ -72,10 +72,14 @@ class TrajectoryPooler:
     and returns its [world, T, B, R] landing buffer, valid until two more submits.  `flush()` waits for everything in flight."""
 
     class Pending:
-        def __init__(self, work, gathered):
-            self.work, self.gathered = work, gathered
+        def __init__(self, work, gathered, pooler=None, index=0):
+            self.work, self.gathered, self.pooler, self.index = work, gathered, pooler, index
 
         def wait(self) -> torch.Tensor:
+            # the landing buffer belongs to submit number `index`; the submit two steps later reuses it (double buffering)
+            if self.pooler is not None and self.pooler.n - self.index > 2:
+                raise RuntimeError(f"TrajectoryPooler: the landing buffer of submit {self.index} was overwritten by submit {self.index + 2} "
+                                   f"({self.pooler.n} submits so far): wait() within two submits, or clone the result")
             if self.work is not None:
                 self.work.wait()
                 self.work = None
@@ -92,9 +96,10 @@ class TrajectoryPooler:
         import torch.distributed as dist
 
         slot = self.n & 1
-        self.n += 1
+        index = self.n
         if self.pending[slot] is not None:
             self.pending[slot].wait()  # the collective that read this slot's block two steps ago
+        self.n += 1
         block = pack(out)
         if self.to_host:               # rehearsal on fewer GPUs than ranks: gloo through host memory
             block = block.cpu()
@@ -105,7 +110,7 @@ class TrajectoryPooler:
         self.blocks[slot].copy_(block)
         T, B, R = block.shape
         work = dist.all_gather_into_tensor(self.landing[slot].view(-1, B, R), self.blocks[slot], group=self.group, async_op=True)
-        self.pending[slot] = TrajectoryPooler.Pending(work, self.landing[slot])
+        self.pending[slot] = TrajectoryPooler.Pending(work, self.landing[slot], self, index)
         return self.pending[slot]
 
     def flush(self) -> None:

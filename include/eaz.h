@@ -77,6 +77,9 @@ typedef struct {
 /* ---- context ------------------------------------------------------------------------------------------------ */
 EAZ_API const char* eaz_last_error(void);
 EAZ_API int eaz_version(void);
+/* first 12 hex digits of the SHA-256 over the .hip and .hpp files of csrc (sorted by name) and include/eaz.h this library was built from
+   ("unknown" for a build outside csrc/Makefile): measurement files under profiles/ carry it, bench.py compares (no reference counterpart) */
+EAZ_API const char* eaz_build_hash(void);
 EAZ_API int eaz_ctx_create(int device, eaz_ctx** out);
 EAZ_API int eaz_ctx_destroy(eaz_ctx* ctx);
 /* child key = fold(key, tag) of the engine's Threefry-2x32 key derivation (csrc/rng.hpp); the counterpart of
@@ -318,6 +321,10 @@ EAZ_API int eaz_profile_replay(eaz_search* s, int kernel_class, int iters, doubl
  *                        sub-batches on as many streams (one sub-batch's env-step launch overlaps another's forward), 1 = off,
  *                        0 (default) = 4 for Subleq batches of >= 2048 environments, 2 from 1024, else 1 (not used by the one-launch searches) */
 #define EAZ_TUNE_SHARDS 5
+/*   EAZ_TUNE_SUBLEQ_WAVE Subleq word sizes other than 16 on the per-simulation path: 1 (default) = one wavefront per environment
+ *                        (subleq_wave_kernel, program in the lanes of one VGPR), 0 = one lane per environment (subleq_step_kernel, program in LDS);
+ *                        initial value from the environment variable EAZ_SUBLEQ_WAVE */
+#define EAZ_TUNE_SUBLEQ_WAVE 6
 EAZ_API int eaz_tune_set(int knob, int value);
 
 #ifdef __cplusplus

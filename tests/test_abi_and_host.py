@@ -28,8 +28,17 @@ def test_library_exports_every_declared_symbol(eaz):
 
 
 def test_ctypes_binding_matches_header(eaz):
-    assert sorted(list(eaz.SIGNATURES) + ["eaz_last_error"]) == _declared()
+    assert sorted(list(eaz.SIGNATURES) + ["eaz_last_error", "eaz_build_hash"]) == _declared()
     assert eaz.load_library().eaz_version() >= 100
+
+
+def test_library_carries_the_hash_of_the_sources_it_was_built_from():
+    """csrc/Makefile bakes the SHA-256 prefix of csrc/*.hip, *.hpp and include/eaz.h into the library; profiles/ files and bench.py's
+    `traffic_source_status` compare against it, so a stale library (or a stale profile) is visible instead of silently attached."""
+    from e_alphazero_amd import _lib
+
+    assert re.fullmatch(r"[0-9a-f]{12}", _lib.source_hash())
+    assert _lib.build_hash() == _lib.source_hash(), "libeaz.so was not rebuilt after the last source change (run __graft_entry__.build())"
 
 
 def test_state_struct_sizes_match_header():
@@ -96,6 +105,16 @@ def test_params_layout_and_npz_roundtrip(eaz, tmp_path):
     p2, s2 = eaz.params.load_npz(path)
     assert all(np.array_equal(p[k]["w"], p2[k]["w"]) and np.array_equal(p[k]["b"], p2[k]["b"]) for k in p)
     assert np.array_equal(s2["fc_az_net/xxhash32"]["binary_set"], bs)
+    # legacy (prefix-less) files: split by the documented heuristic; a weight leaf under a "/~/" module is ambiguous and refused
+    legacy = str(tmp_path / "legacy.npz")
+    np.savez(legacy, **{"fc_az_net/linear/w": p["fc_az_net/linear"]["w"], "fc_az_net/xxhash32/binary_set": bs,
+                        "az_resnet/batch_norm/~/mean_ema/average": np.zeros(4, np.float32)})
+    p3, s3 = eaz.params.load_npz(legacy)
+    assert list(p3) == ["fc_az_net/linear"] and set(s3) == {"fc_az_net/xxhash32", "az_resnet/batch_norm/~/mean_ema"}
+    bad = str(tmp_path / "bad.npz")
+    np.savez(bad, **{"outer/~/inner/w": np.zeros((2, 2), np.float32)})
+    with pytest.raises(ValueError, match="cannot tell"):
+        eaz.params.load_npz(bad)
 
 
 def test_subleq16_test_vector_table_matches_the_oracle_generator(eaz, oracle):

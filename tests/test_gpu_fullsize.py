@@ -129,16 +129,21 @@ def test_c3_selfplay_subset_matches_oracle(oracle, eaz, torch, flags):
     _check_subset(out, ref, idx, state_cmp=lambda s: subleq_device_to_oracle(s, W))
     assert np.array_equal(subleq_device_to_oracle(st[idx].cpu().numpy(), W), ost)
     sc = ref["state"].view(np.uint8)[..., 0:4].copy().view(np.int32)[..., 0]
-    assert (np.diff(sc.astype(np.int64), axis=0) < 0).all(axis=0).any() or (np.diff(sc.astype(np.int64), axis=0) < 0).any(), "no episode ended inside the window"
+    # EVERY environment of the subset crosses an episode boundary inside the window (a terminated-root search, then the auto-reset)
+    assert (np.diff(sc.astype(np.int64), axis=0) < 0).any(axis=0).all(), "an environment never restarted inside the window"
 
 
-def test_subleq256_selfplay_subset_matches_oracle(oracle, eaz, torch):
-    """The reference's code-default word size (main.py:159: word_size = 256 -> 256 actions, 2592 observation bytes, 532 KB of tree statistics per
+@pytest.mark.parametrize("wave", [1, 0], ids=["wave-per-env", "lane-per-env"])
+def test_subleq256_selfplay_subset_matches_oracle(oracle, eaz, torch, wave):
+    """Both Subleq step kernels of the per-simulation path (EAZ_TUNE_SUBLEQ_WAVE: subleq_wave_kernel, the default, and subleq_step_kernel).
+    The reference's code-default word size (main.py:159: word_size = 256 -> 256 actions, 2592 observation bytes, 532 KB of tree statistics per
     environment) at C3's batch and simulation count, on the per-simulation kernels (tree_step_kernel<64, 4>, subleq_step_kernel, the 16- /
     64-row forward) with sub-batches on their own streams: a random subset of the batch against the oracle over 3 real steps."""
     from e_alphazero_amd import engine
 
     W, B, S, T, NSUB = 256, 4096, 64, 3, 6
+    engine.tune(subleq_wave=wave)
+    request_restore = lambda: engine.tune(subleq_wave=1)  # noqa: E731
     dims, params, state = subleq_setup(eaz, W, seed=1, fill=0.5)
     env = engine.EnvHandle.subleq(W, (1,), True, device=0)
     net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
@@ -152,7 +157,11 @@ def test_subleq256_selfplay_subset_matches_oracle(oracle, eaz, torch):
     gum = np.random.default_rng(5).gumbel(size=(T, B, W)).astype(np.float32)
     gum[:, idx] = oracle.gumbel((6, 7), T * NSUB * W).reshape(T, NSUB, W)
     st = env.init(B, key=0)
-    out = search.selfplay(st, T, key=31, gumbel=torch.from_numpy(gum).cuda())
+    try:
+        out = search.selfplay(st, T, key=31, gumbel=torch.from_numpy(gum).cuda())
+        torch.cuda.synchronize()
+    finally:
+        request_restore()
     ost = oenv.init(NSUB)
     ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(31, 0), gumbel=np.ascontiguousarray(gum[:, idx]), discount=0.97)
     _check_subset(out, ref, idx, state_cmp=lambda s: subleq_device_to_oracle(s, W))

@@ -205,8 +205,8 @@ def test_subleq_word_sizes_that_are_not_multiples_of_four(oracle, eaz, torch, W,
     multiple of 4 (hashes.py:210).  Environment steps on random programs, then self-play across an auto-reset, against the oracle."""
     from e_alphazero_amd import engine
 
-    if kernel_variant not in ("persist", "tile16-unfused"):
-        pytest.skip("one fused and one unfused variant cover the per-lane Subleq kernel")
+    if kernel_variant not in ("persist", "tile16-unfused", "perlane-unfused"):
+        pytest.skip("one fused and one unfused variant of the wavefront-per-environment kernel, and the lane-per-environment kernel (perlane-unfused)")
     B, S, T = 21, 10, 3
     dims, params, state = subleq_setup(eaz, W, binary=binary, seed=W, fill=0.3)
     assert dims["hash_len"] % 4 == 0 and W % 4 != 0

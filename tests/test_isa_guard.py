@@ -83,6 +83,12 @@ def test_work_queue_claim_is_one_lds_atomic(asm, stem):
     window = "\n".join(lines[max(0, sites[0] - 40):sites[0] + 8])
     assert "s_ff1_i32_b64" not in window and "v_readlane_b32" not in window.split("ds_add_rtn_u32")[1], \
         "a lane-scan (atomic optimizer) loop surrounds the work-queue claim"
+    # issued by ONE lane: exec is narrowed to lane 0 right in front of the atomic and restored behind it (lds_claim_one), so the claim does
+    # not rely on the LDS keeping one wavefront's 64 same-address adds together
+    before = [ln.strip() for ln in lines[sites[0] - 2:sites[0]]]
+    after = [ln.strip() for ln in lines[sites[0] + 1:sites[0] + 4]]
+    assert re.match(r"s_mov_b64 exec, 1\b", before[-1]) and re.match(r"s_mov_b64 s\[\d+:\d+\], exec", before[-2]), before
+    assert any(re.match(r"s_mov_b64 exec, s\[\d+:\d+\]", ln) for ln in after), after
 
 
 @pytest.mark.parametrize("stem,size_of", [("subleq16_search_kernel", None), ("subleq16_selfplay_kernel", None)])

@@ -65,6 +65,11 @@ def _worker(rank, world, port, T, B, SB, A, q):
         for k, v in _fake_output(r, T, B, SB, A, 2).items():
             ok &= bool(torch.equal(got[k][r * B:(r + 1) * B], v.transpose(0, 1)))
     ok &= pend[0].gathered.data_ptr() == pend[2].gathered.data_ptr() != pend[1].gathered.data_ptr()  # two landing buffers, alternating
+    try:  # ... so the handle of step 0 is stale once step 2 has been submitted, and says so instead of returning step 2's data
+        pend[0].wait()
+        ok = False
+    except RuntimeError as e:
+        ok &= "overwritten" in str(e)
     q.put((rank, ok, tuple(pooled["state"].shape)))
     dist.barrier()
     dist.destroy_process_group()

@@ -83,15 +83,16 @@ if (fw[:, :7] > 0).all():
         f"head {h}: layer 1 {np.median(fw[:, 1 + 2 * h] - (fw[:, 2 * h] if h == 0 else fw[:, 2 * h])):.0f}, layer 2 (+ H1 tile, barrier) {np.median(fw[:, 2 + 2 * h] - fw[:, 1 + 2 * h]):.0f};"
         for h in range(3)) + f"  after the last layer 2 -> stamp 7: {np.median(st[:, 0, 7] - fw[:, 6]):.0f}")
 lib.eaz_diag_qp_rounds.argtypes = [C.c_void_p]
-rb = np.zeros(2048 * 32, np.uint64)
+rb = np.zeros(2048 * 64, np.uint64)
 lib.eaz_diag_qp_rounds(rb.ctypes.data)
-rr = rb.reshape(256, 8, 32).astype(np.int64)[:, 0, :]
-if (rr[:, :24] > 0).all() and (fw[:, :7] > 0).all():
+rr = rb.reshape(256, 8, 64).astype(np.int64)[:, 0, :]
+N1 = int(os.environ.get("N1", 7))  # half-rounds of layer 1 (sq16_l1_halves): slots head * 16 + 0 .. N1 - 1; layer 2: head * 16 + 8 .. 15
+if (fw[:, :7] > 0).all():
     for h in range(3):
         prev = fw[:, 2 * h]  # F start / end of layer 2 of the head before
-        l1 = [np.median(rr[:, h * 8] - prev)] + [np.median(rr[:, h * 8 + r] - rr[:, h * 8 + r - 1]) for r in range(1, 4)]
-        l2 = [np.median(rr[:, h * 8 + 4] - fw[:, 1 + 2 * h])] + [np.median(rr[:, h * 8 + 4 + r] - rr[:, h * 8 + 3 + r]) for r in range(1, 4)]
-        print(f"   head {h}, wave 0, clocks per round of 16 k-steps (floor 2048): layer 1 " + " ".join(f"{x:.0f}" for x in l1) +
+        l1 = [np.median(rr[:, h * 16] - prev)] + [np.median(rr[:, h * 16 + r] - rr[:, h * 16 + r - 1]) for r in range(1, N1)]
+        l2 = [np.median(rr[:, h * 16 + 8] - fw[:, 1 + 2 * h])] + [np.median(rr[:, h * 16 + 8 + r] - rr[:, h * 16 + 7 + r]) for r in range(1, 8)]
+        print(f"   head {h}, wave 0, clocks per half-round of 8 k-steps (floor 1024): layer 1 " + " ".join(f"{x:.0f}" for x in l1) +
               "   | H1 tile + barrier + layer 2 " + " ".join(f"{x:.0f}" for x in l2))
 t0 = st[:, :, 0].min(axis=1)
 seg("T (first wave in -> last wave at the T/E barrier)", st[:, :, 4].max(axis=1) - t0)
