@@ -135,11 +135,19 @@ def build_workload(name, args, device, rank, beta=0.0):
         params = eaz.params.init_fc_params(in_dim, H, W, seed=0)
         hstate = eaz.params.init_hash_state(fill=args.hash_fill, seed=0)
         env = engine.EnvHandle.subleq(W, (1,), True, device=device)     # task NEGATION_POSITIVE (config.py:18)
-        net = engine.FCNet(env.ctx, in_dim, H, W, params, hstate, hash_off=hash_off, hash_len=in_dim - hash_off)
+        # layer-1 input order: a switch of the engine's numerics contract (include/eaz.h eaz_net_set_input_order) that the oracle follows
+        # (parity gate, cpu_baseline).  "constants-first" (the default at word_size 16, where the one-launch kernel profits): the chain of
+        # layer 1 sums example_input / example_output -- constants of an episode -- first; "ascending": the plain k-ascending chain.
+        cfirst = args.l1_order == "constants-first" or (args.l1_order == "auto" and W == 16)
+        order = eaz.params.subleq_constants_first(W, True) if cfirst else None
+        net = engine.FCNet(env.ctx, in_dim, H, W, params, hstate, hash_off=hash_off, hash_len=in_dim - hash_off, input_order=order)
         search = engine.Search(env, net, B, S, discount=0.97, exploration=explore)
         A = W
         desc = (f"Subleq word_size={W} task=1 binary obs, batch={B}/GPU, {S} sims, {T} real steps per selfplay() call, FC H={H} "
-                + ("(BASELINE.json configs[2])" if W == 16 else "(configs[2] at another word size: the per-simulation kernels)"))
+                + ("(BASELINE.json configs[2])" if W == 16 else "(configs[2] at another word size: the per-simulation kernels)")
+                + (", layer-1 input order: constants first (numerics switch eaz_net_set_input_order; the oracle follows it)" if cfirst else
+                   ", layer-1 input order: ascending (default contract)"))
+        w["l1_exec_inputs"] = (144 if cfirst else 224) if W == 16 else in_dim   # inputs the one-launch kernel's layer 1 chains per forward
         data = "synthetic (random-init FC net, half-filled novelty set)"
         # dense rows: narrow heads run the pipelined 16-row kernel, wide heads (W > 16) the 64-row tiles
         net_kernel, net_flops = "fc16p_forward_kernel" if W == 16 else "fc16_forward_kernel | fc_forward_kernel (by sub-batch size)", fc_flops_per_eval(in_dim, A, (0, 1, 2)) * B
@@ -152,6 +160,7 @@ def build_workload(name, args, device, rank, beta=0.0):
             oenv = O.OracleEnv.subleq(W, (1,), True)
             onet = O.OracleNet(in_dim, H, W, eaz.params.fc_weight_list(params), hash_off=hash_off, hash_len=in_dim - hash_off,
                                bitset=hstate[eaz.params.HASH_MODULE]["binary_set"])
+            onet.set_input_order(order)
             return oenv, onet, dict(discount=0.97), f"Subleq-{W}"
     else:
         nb, A = 5, 7
@@ -244,6 +253,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--word-size", type=int, default=16, help="c3: Subleq word size (16 = configs[2]; the reference's code default is 256, main.py:159)")
+    ap.add_argument("--l1-order", choices=("auto", "ascending", "constants-first"), default="auto",
+                    help="c3: layer-1 input order of the FC network (numerics switch, include/eaz.h eaz_net_set_input_order); auto = constants-first at word_size 16")
     ap.add_argument("--grid", type=int, default=32, help="DeepSea size (c2)")
     ap.add_argument("--batch", type=int, default=0, help="environments per GPU (default: the workload's)")
     ap.add_argument("--sims", type=int, default=0)
@@ -384,9 +395,12 @@ def run_rank(args):
         result["extra"] = {}
         #                tag              workload (steps, warmup, T)  beta  hash fill
         for tag, name, (xs, xw, xt), xbeta, xfill in (("c3", "c3", (3, 1, 0), 0.0, None), ("c3_beta1", "c3", (3, 1, 0), 1.0, None),
+                                                      ("c3_ascending", "c3", (3, 1, 0), 0.0, None),
                                                       ("c2_empty_set", "c2", (3, 1, 0), 0.0, 0.0), ("c4", "c4", (1, 1, 2), 0.0, None)):
             xargs = argparse.Namespace(**vars(args))
             xargs.workload, xargs.selfplay_steps = name, xt
+            if tag == "c3_ascending":   # the default numerics contract (k-ascending layer-1 chain): extra.c3 runs the constants-first switch
+                xargs.l1_order = "ascending"
             if xfill is not None:
                 xargs.hash_fill = xfill
             wl = meas = None
@@ -526,15 +540,20 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
     dense_flops = wl["net_flops"]
     if persistent and name == "c3" and prof["search"]["launches"] == n_instr:
         # subleq16_selfplay_kernel: ONE launch per selfplay() call = T real steps x (root inference + S simulations): tree phase on LDS node
-        # records, all-scalar interpreter, dense forward of 3 heads per simulation (16 trees per workgroup).  FLOPs: the (S + 1) forwards per
-        # real step, dense (the kernel runs layer 1 as whole rounds of 16 k-steps: the 4 zero-padded k-steps are not counted).
+        # records, all-scalar interpreter, forward of 3 heads per simulation (16 trees per workgroup).  EXECUTED FLOPs: the (S + 1) forwards per
+        # real step with layer 1 over the inputs the kernel chains -- 224 of the 240 (the pad flags of the memory words are structurally zero and
+        # dropped, exact) or, under the constants-first input order, 144 (the 80 example-row inputs enter as one precomputed partial sum per
+        # tree); the zero-padded k-steps of the last half-round are not counted.  `dense` prices the same forwards at all 240 inputs.
         kname = "subleq16_selfplay_kernel"
         n_launch = prof["search"]["launches"]
         k_ms = search.profile_replay("search", 3)
         pair_us = 1e3 * prof["search"]["ms"] / n_launch
-        flops = dense = T_instr * (S + 1) * dense_flops
-        algo = (f"{T_instr} real steps x ({S} simulations + root) x {B} rows x dense forward of 3 heads ({dense_flops // B} FLOP per row); the launch "
-                "also walks the trees and runs the Subleq interpreter, during which the MFMA pipes idle")
+        k1 = wl.get("l1_exec_inputs", wl["in_dim"])
+        exec_row = sum(2 * (k1 * H + H * H + H * (1 if h < 2 else A)) for h in heads)
+        flops, dense = T_instr * (S + 1) * exec_row * B, T_instr * (S + 1) * dense_flops
+        algo = (f"{T_instr} real steps x ({S} simulations + root) x {B} rows x forward of 3 heads as executed ({exec_row} FLOP per row: layer 1 over "
+                f"{k1} of the {wl['in_dim']} inputs; dense: {dense_flops // B}); the launch also walks the trees and runs the Subleq interpreter, "
+                "during which the MFMA pipes idle")
     elif persistent and name == "c3":
         # subleq16_search_kernel (EAZ_TUNE_PERSIST = 2): all S simulations of a real step in one launch (tree step + interpreter + forward per simulation, 16 trees per
         # workgroup).  A ~3 ms launch: the event pair of the instrumented pass is its duration (the ~4 us launch gap is 0.1 %).  FLOPs: the S

@@ -59,6 +59,7 @@ SIGNATURES = {
     "eaz_net_create_resnet": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _pp],
     "eaz_net_destroy": [_vp],
     "eaz_net_set_weights": [_vp, _vp, _vp, _vp],
+    "eaz_net_set_input_order": [_vp, _i, _vp, _vp, _vp],
     "eaz_net_set_resnet_weights": [_vp, _vp, _i, _vp],
     "eaz_net_set_simhash": [_vp, _vp, _vp],
     "eaz_net_set_bitset": [_vp, _vp, _vp],
@@ -77,6 +78,7 @@ SIGNATURES = {
     "eaz_search_expand": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eaz_search_tree_view": [_vp, _i, _pp, C.POINTER(C.c_int64), C.POINTER(_i)],
     "eaz_search_launch_info": [_vp, C.POINTER(_i), C.POINTER(_i)],
+    "eaz_search_debug_poison": [_vp, _i, _vp],
     "eaz_selfplay_run": [_vp, C.POINTER(SelfplayCfg), _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eaz_random_play": [_vp, _i, _i, _u64, _vp, _vp, _vp],
     "eaz_evaluate_run": [_vp, _f, _i, _vp, _vp, C.POINTER(_i), _vp],

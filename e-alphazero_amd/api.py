@@ -301,6 +301,11 @@ class Config:
     exploration_policy_target_temperature: float = 1.0
     exploitation_beta: float = 0.0
     reanalyze_beta: float = 0.0
+    # NOT a field of the reference: a switch of this engine's numerics contract (include/eaz.h eaz_net_set_input_order).  True:
+    # layer 1 of the Subleq FC network sums the episode-constant example_input / example_output inputs first (params.subleq_constants_first),
+    # which lets the one-launch kernel start every chain of a tree from a precomputed partial sum (layer 1 over 144 instead of 240 inputs).
+    # Results differ from the default order in the last float bits only; the test oracle follows the same switch.
+    layer1_constants_first: bool = False
 
     def __hash__(self):  # config.py:95-96
         return 0
@@ -353,9 +358,12 @@ class ForwardFn:
                 self._net = engine.ResNet(self.env._h.ctx, H, W, cin, self.env.num_actions, model_params, model_state, 64, self.num_blocks)
             else:
                 # get_network does not forward max_ube / max_epistemic_variance_reward to the FC net (context.py:68-75)
+                order = None
+                if isinstance(self.env, Subleq) and getattr(self.config, "layer1_constants_first", False):
+                    order = params_lib.subleq_constants_first(self.env.word_size, self.env.use_binary_encoding)
                 self._net = engine.FCNet(self.env._h.ctx, self.in_dim, self.config.linear_layer_size, self.env.num_actions,
                                          model_params, first_state, max_ube=1.0, max_epistemic_variance_reward=1.0,
-                                         hash_off=self.hash_off)
+                                         hash_off=self.hash_off, input_order=order)
             if self.simhash:
                 mod = params_lib.RESNET_SIMHASH_MODULE if self.residual else params_lib.SIMHASH_MODULE
                 self._net.set_simhash(model_state[mod]["random_matrix"], mod)

@@ -85,6 +85,9 @@ struct eaz_net {
     float* d_sim_matrix;                  // NetDev::sim_matrix storage (SimHash)
     unsigned long long* d_kstep_counter;  // executed layer-1 k-steps (profiling only; nullptr = off)
     unsigned long long* d_kstep_storage;
+    int32_t* d_in_perm;     // NetDev::in_perm / in_inv storage ([2][in_dim]); null: ascending input order
+    float* d_w_raw[4];      // layer-1 weights as uploaded (rows in the original order) while an input order is set
+    std::vector<int32_t> perm;  // host copy of the order (empty: ascending)
     float* d_w1q[4];        // NetDev::w1q storage (built on the first Subleq-16 one-launch call, sq16_pack_w1)
     uint64_t w_stamp;       // counts weight uploads (create, eaz_net_set_weights)
     uint64_t w1q_stamp;     // the upload d_w1q was packed from
@@ -106,6 +109,7 @@ struct eaz_search {
     std::vector<void*> allocs;
     // workspace of one simulation
     uint8_t* d_obs;
+    uint8_t* d_obs_perm;  // [B, obs_dim]: the observation rows in the network's layer-1 input order (fc_launch scratch)
     float *d_novelty, *d_exploit, *d_explore, *d_v, *d_u, *d_next_reward;
     uint8_t *d_next_term, *d_next_legal;
     int32_t* d_leaf_hot;
@@ -150,6 +154,8 @@ struct eaz_search {
     // Subleq-16 fused self-play (search_subleq_persist.hpp): one launch per selfplay() call, trees and states in LDS
     int sqp_lds;               // dynamic LDS bytes of that launch (0: the trees of a workgroup do not fit)
     float* d_sq_logits;        // [ceil16(B), N, 32] scratch rows: prior logits | their softmax
+    float* d_sq_l1init;        // [ceil16(B), 2, 3, 256]: start of the layer-1 chains per tree (Sq16SelfplayArgs::l1init)
+    int sqp_roots_fit;         // the roots of the search begun last fit the one-launch kernel's compact state (sq16_roots_fit)
 };
 
 extern "C" int eaz_ctx_create(int device, eaz_ctx** out) {
@@ -456,6 +462,7 @@ static int net_create_fc_impl(eaz_net* n, int in_dim, int hidden, int num_action
     HIP_OK(hipMemset(n->d_kstep_storage, 0, 8 * sizeof(unsigned long long)));
     n->d_kstep_counter = nullptr;
     n->dev.l1q_mode = -1;
+    for (int h = 0; h < 4; ++h) n->dev.w1raw[h] = n->d_w[h * 3];
     n->w_stamp = 1;
     return 0;
 }
@@ -576,6 +583,8 @@ extern "C" int eaz_net_destroy(eaz_net* n) {
     if (n->d_sim_matrix) (void)hipFree(n->d_sim_matrix);
     if (n->d_kstep_storage) (void)hipFree(n->d_kstep_storage);
     for (int h = 0; h < 4; ++h) if (n->d_w1q[h]) (void)hipFree(n->d_w1q[h]);
+    for (int h = 0; h < 4; ++h) if (n->d_w_raw[h]) (void)hipFree(n->d_w_raw[h]);
+    if (n->d_in_perm) (void)hipFree(n->d_in_perm);
     delete n;
     return 0;
 }
@@ -586,10 +595,68 @@ extern "C" int eaz_net_set_weights(eaz_net* n, const float* const* h_w, const fl
     for (int l = 0; l < 12; ++l) {
         int k, m;
         layer_dims(n->dev.in_dim, n->dev.H, n->dev.A, l, &k, &m);
-        HIP_OK(hipMemcpyAsync(n->d_w[l], h_w[l], sizeof(float) * k * m, hipMemcpyHostToDevice, S(stream)));
+        if ((l % 3) == 0 && n->dev.in_perm) {
+            // an input order is set: the upload lands in the original-order copy, the live copy gets its rows in chain order
+            HIP_OK(hipMemcpyAsync(n->d_w_raw[l / 3], h_w[l], sizeof(float) * k * m, hipMemcpyHostToDevice, S(stream)));
+            fc_permute_w1_kernel<<<k, 256, 0, S(stream)>>>(n->d_w_raw[l / 3], n->dev.in_perm, n->d_w[l], m);
+            LAUNCH_OK();
+        } else {
+            HIP_OK(hipMemcpyAsync(n->d_w[l], h_w[l], sizeof(float) * k * m, hipMemcpyHostToDevice, S(stream)));
+        }
         HIP_OK(hipMemcpyAsync(n->d_b[l], h_b[l], sizeof(float) * m, hipMemcpyHostToDevice, S(stream)));
     }
     n->w_stamp += 1;  // derived device copies (d_w1q) are rebuilt by their next user
+    return 0;
+}
+
+extern "C" int eaz_net_set_input_order(eaz_net* n, int n_seg, const int32_t* seg_start, const int32_t* seg_len, void* stream) {
+    ARG_OK(n && n_seg >= 0 && (n_seg == 0 || (seg_start && seg_len)));
+    if (n->kind != 0) return fail("eaz_net_set_input_order: FC networks only");
+    HIP_OK(hipSetDevice(n->ctx->device));
+    const int K = n->dev.in_dim, H = n->dev.H;
+    std::vector<int32_t> perm;
+    if (n_seg > 0) {
+        std::vector<uint8_t> seen(static_cast<size_t>(K), 0);
+        for (int s = 0; s < n_seg; ++s)
+            for (int k = seg_start[s]; k < seg_start[s] + seg_len[s]; ++k) {
+                if (k < 0 || k >= K || seen[k]) return fail("eaz_net_set_input_order: the segments are not a permutation of the %d inputs (input %d)", K, k);
+                seen[k] = 1;
+                perm.push_back(k);
+            }
+        if (static_cast<int>(perm.size()) != K) return fail("eaz_net_set_input_order: the segments cover %zu of the %d inputs", perm.size(), K);
+        bool ident = true;
+        for (int k = 0; k < K; ++k) ident = ident && perm[k] == k;
+        if (ident) perm.clear();
+    }
+    hipStream_t st = S(stream);
+    // the weights in their original order: kept beside the live copies from the first non-trivial order on
+    for (int h = 0; h < 4; ++h) {
+        if (!n->d_w_raw[h]) {
+            if (perm.empty()) continue;  // ascending before and after: nothing to do
+            HIP_OK(hipMalloc(&n->d_w_raw[h], sizeof(float) * K * H));
+            HIP_OK(hipMemcpyAsync(n->d_w_raw[h], n->d_w[h * 3], sizeof(float) * K * H, hipMemcpyDeviceToDevice, st));  // no order was set: d_w is the original
+        }
+    }
+    if (perm.empty()) {
+        if (n->d_w_raw[0])
+            for (int h = 0; h < 4; ++h) HIP_OK(hipMemcpyAsync(n->d_w[h * 3], n->d_w_raw[h], sizeof(float) * K * H, hipMemcpyDeviceToDevice, st));
+        n->dev.in_perm = nullptr; n->dev.in_inv = nullptr;
+        for (int h = 0; h < 4; ++h) n->dev.w1raw[h] = n->d_w[h * 3];
+    } else {
+        if (!n->d_in_perm) HIP_OK(hipMalloc(&n->d_in_perm, sizeof(int32_t) * 2 * K));
+        std::vector<int32_t> both(static_cast<size_t>(2) * K);
+        for (int kp = 0; kp < K; ++kp) { both[kp] = perm[kp]; both[K + perm[kp]] = kp; }
+        HIP_OK(hipMemcpyAsync(n->d_in_perm, both.data(), sizeof(int32_t) * 2 * K, hipMemcpyHostToDevice, st));
+        HIP_OK(hipStreamSynchronize(st));  // `both` is a stack-lifetime staging buffer
+        n->dev.in_perm = n->d_in_perm; n->dev.in_inv = n->d_in_perm + K;
+        for (int h = 0; h < 4; ++h) {
+            fc_permute_w1_kernel<<<K, 256, 0, st>>>(n->d_w_raw[h], n->dev.in_perm, n->d_w[h * 3], H);
+            LAUNCH_OK();
+            n->dev.w1raw[h] = n->d_w_raw[h];
+        }
+    }
+    n->perm = perm;
+    n->w_stamp += 1;
     return 0;
 }
 
@@ -701,6 +768,7 @@ extern "C" int eaz_tune_set(int knob, int value) {
 // forward of B one-hot observations given by index + their novelty lookup, ONE launch (fc16_forward_kernel<2>)
 static int fc_onehot_launch(eaz_net* n, int B, const int32_t* hot, float* novelty, const NetOut& o, const HeadList& heads, hipStream_t st) {
     if (B <= 0 || heads.n <= 0) return 0;
+    if (n->dev.in_perm) return fail("a layer-1 input order (eaz_net_set_input_order) is meaningless for one-hot observations: not supported with DeepSea");
     const int per_xcd = cdiv(cdiv(B, kF16M), 8);
     const int nb = 8 * per_xcd * heads.n;
     const FcIn in{nullptr, hot, novelty, n->dev.ztab};
@@ -709,12 +777,20 @@ static int fc_onehot_launch(eaz_net* n, int B, const int32_t* hot, float* novelt
     return 0;
 }
 
-static int fc_launch(eaz_net* n, int B, const uint8_t* obs, const NetOut& o, const HeadList& heads, hipStream_t st) {
+// `scratch`: [B, in_dim] bytes, needed when the network has a layer-1 input order (the rows are read through the permutation once, in front
+// of whichever forward kernel runs: every kernel then computes the chain in that order)
+static int fc_launch(eaz_net* n, int B, const uint8_t* obs, const NetOut& o, const HeadList& heads, hipStream_t st, uint8_t* scratch) {
     if (B <= 0 || heads.n <= 0) return 0;
     if (n->kind == 1) {  // residual tower: six samples per workgroup, all heads in one launch
         resnet_forward_kernel<<<cdiv(B, kRnSamples), 256, kRnLdsBytes, st>>>(n->rdev, obs, B, o);
         LAUNCH_OK();
         return 0;
+    }
+    if (n->dev.in_perm) {
+        if (!scratch) return fail("internal: a dense forward under a layer-1 input order needs a scratch row buffer");
+        fc_permute_obs_kernel<<<cdiv(static_cast<long>(B) * n->dev.in_dim, 256), 256, 0, st>>>(obs, n->dev.in_perm, scratch, B, n->dev.in_dim);
+        LAUNCH_OK();
+        obs = scratch;
     }
     if (n->dev.H != kFcH) {  // any other linear_layer_size: plain fmaf chains
         fc_generic_forward_kernel<<<dim3(cdiv(B, kFgRows), heads.n), 256, fg_lds_bytes(n->dev.H), st>>>(n->dev, obs, B, o, heads);
@@ -777,7 +853,10 @@ extern "C" int eaz_net_forward(eaz_net* n, int B, const uint8_t* d_obs, float* d
     if (d_exploit) hl.id[hl.n++] = 2;
     if (d_explore) hl.id[hl.n++] = 3;
     NetOut o{d_exploit, d_explore, d_value, d_ube};
-    int rc = fc_launch(n, B, d_obs, o, hl, S(stream));
+    uint8_t* scratch = nullptr;
+    if (n->kind == 0 && n->dev.in_perm) HIP_OK(hipMallocAsync(reinterpret_cast<void**>(&scratch), static_cast<size_t>(B) * n->dev.in_dim, S(stream)));
+    int rc = fc_launch(n, B, d_obs, o, hl, S(stream), scratch);
+    if (scratch) HIP_OK(hipFreeAsync(scratch, S(stream)));
     if (rc) return rc;
     if (d_ube) {
         ube_combine_kernel<<<cdiv(B, 256), 256, 0, S(stream)>>>(d_ube, nov, n->dev.max_u, B);
@@ -904,7 +983,7 @@ static int make_shard(eaz_search* p, int b0, int Bs, eaz_search** out) {
     OFF(t.net_logits, A); OFF(t.net_value, 1); OFF(t.net_ube, 1); OFF(t.net_novelty, 1);
     OFF(t.next_reward, 1); OFF(t.next_term, 1); OFF(t.next_legal, A);
     OFF(t.fuse_reward, 1); OFF(t.fuse_term, 1); OFF(t.leaf_hot, 1);
-    OFF(c->d_obs, OD); OFF(c->d_novelty, 1); OFF(c->d_exploit, A); OFF(c->d_explore, A); OFF(c->d_v, 1); OFF(c->d_u, 1);
+    OFF(c->d_obs, OD); OFF(c->d_obs_perm, OD); OFF(c->d_novelty, 1); OFF(c->d_exploit, A); OFF(c->d_explore, A); OFF(c->d_v, 1); OFF(c->d_u, 1);
     OFF(c->d_next_reward, 1); OFF(c->d_next_term, 1); OFF(c->d_next_legal, A); OFF(c->d_leaf_hot, 1);
 #undef OFF
     *out = c;
@@ -924,7 +1003,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     s->prof_on = 0; s->step_graph = nullptr; s->graph_states = nullptr; s->graph_flags = -1; s->pending_expand = -1;
     s->persist_ok = 0; s->persist_lds = 0; s->clear_pending = 0; s->sims_done = 0; s->d_stamps = nullptr;
     std::memset(&s->last_sp, 0, sizeof s->last_sp); s->d_replay_states = nullptr;
-    s->sqp_lds = 0; s->d_sq_logits = nullptr;
+    s->sqp_lds = 0; s->d_sq_logits = nullptr; s->d_sq_l1init = nullptr;
     HIP_OK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&s->main, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
@@ -970,6 +1049,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     t.bonus_after = opts->epistemic_bonus_after_rescale != 0; t.var_backup = opts->epistemic_variance_backup != 0;
     // per-simulation workspace
     DALLOC(s->d_obs, static_cast<size_t>(B) * env->dev.obs_dim + 16);
+    DALLOC(s->d_obs_perm, static_cast<size_t>(B) * env->dev.obs_dim + 16);
     DALLOC(s->d_novelty, B); DALLOC(s->d_exploit, static_cast<size_t>(B) * A); DALLOC(s->d_explore, static_cast<size_t>(B) * A);
     DALLOC(s->d_v, B); DALLOC(s->d_u, B); DALLOC(s->d_next_reward, B); DALLOC(s->d_next_term, B);
     DALLOC(s->d_next_legal, static_cast<size_t>(B) * A);
@@ -1011,6 +1091,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
                 s->sqp_lds = QL.total;
                 HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(subleq16_selfplay_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, QL.total));
                 DALLOC(s->d_sq_logits, static_cast<size_t>(cdiv(B, kQpTrees)) * kQpTrees * s->N * (2 * kQpA));
+                DALLOC(s->d_sq_l1init, static_cast<size_t>(kQpL1Tab) + static_cast<size_t>(cdiv(B, kQpTrees)) * kQpTrees * 3 * kFcH);
                 DALLOC(s->d_replay_states, static_cast<size_t>(B) * env->dev.state_bytes);
             }
         }
@@ -1062,6 +1143,7 @@ extern "C" int eaz_search_destroy(eaz_search* s) {
 static int tree_grid(const eaz_search* s) { return cdiv(static_cast<long>(s->B) * s->lpt, 256); }
 static bool sqp_eligible(const eaz_search* s);
 static int sqp_launch(eaz_search* s, const PersistSelfplay& sp, hipStream_t st);
+static int sq16_roots_fit(eaz_search* s, const void* d_states, hipStream_t st, bool* fit);
 
 extern "C" int eaz_search_begin(eaz_search* s, const float* d_prior_logits, const float* d_value, const float* d_value_var,
                                 const void* d_root_states, const float* d_beta, const uint8_t* d_invalid, const float* d_gumbel,
@@ -1073,7 +1155,14 @@ extern "C" int eaz_search_begin(eaz_search* s, const float* d_prior_logits, cons
         // The persistent kernel rewrites every tree array, so its searches skip the 24 MB clear; a caller that steps the search
         // simulation by simulation instead gets the (root-preserving) clear from ensure_cleared() before its first tree kernel.
         // (likewise the Subleq-16 one-launch kernel, search_subleq_persist.hpp)
-        s->clear_pending = (s->persist_ok && g_persist) || (g_persist == 1 && sqp_eligible(s));
+        s->sqp_roots_fit = 0;
+        if (!(s->persist_ok && g_persist) && g_persist == 1 && sqp_eligible(s)) {
+            bool fit = false;
+            const int rc = sq16_roots_fit(s, d_root_states, st, &fit);
+            if (rc) return rc;
+            s->sqp_roots_fit = fit ? 1 : 0;
+        }
+        s->clear_pending = (s->persist_ok && g_persist) || s->sqp_roots_fit;
         if (!s->clear_pending) {
             const long bna = static_cast<long>(s->B) * s->N * s->A;
             tree_clear_kernel<<<cdiv(bna, 256) < 4096 ? cdiv(bna, 256) : 4096, 256, 0, st>>>(s->tree, 0);
@@ -1119,11 +1208,25 @@ static int persist_launch(eaz_search* s, hipStream_t st, const PersistSelfplay* 
 
 // Subleq-16 + FC network whose novelty is the XXHash variant over the IO rows: every simulation of a search in one launch
 // (search_subleq.hpp).  Decided per run: the hash class of a network can change after the search was created (eaz_net_set_simhash).
+// layer-1 mode of the Subleq-16 one-launch kernel for this network's input order (search_subleq_persist.hpp sq16_l1_src): 0 = ascending,
+// 1 = example_input | example_output | memory | input_after | output_after ("constants first"), -1 = any other order (kernel not eligible)
+static int sq16_l1_mode_of(const eaz_net* n) {
+    if (n->perm.empty()) return 0;
+    if (n->dev.in_dim != 240) return -1;
+    static const int seg[5][2] = {{80, 40}, {160, 40}, {0, 80}, {120, 40}, {200, 40}};
+    int kp = 0;
+    for (const auto& sg : seg)
+        for (int k = sg[0]; k < sg[0] + sg[1]; ++k)
+            if (n->perm[kp++] != k) return -1;
+    return 1;
+}
 static bool sq16_persist_eligible(const eaz_search* s) {
     const EnvDev& ed = s->env->dev;
     if (!(ed.kind == EAZ_ENV_SUBLEQ && ed.W == 16 && ed.binary && ed.obs_dim == 240 && s->lpt == 16 && s->apl == 1 && s->net->kind == 0)) return false;
     const NetDev& nd = s->net->dev;
-    return nd.H == kFcH && fp_eligible(nd.in_dim, nd.A) && nd.in_dim == 240 && !nd.sim_matrix && nd.hash_off == 80 && nd.hash_len == 160;
+    // novelty: the XXHash variant over the IO rows (subleq_hash_only_io, config.py:30) or over the whole observation (fully_connected.py:84-89)
+    const bool hash_ok = (nd.hash_off == 80 && nd.hash_len == 160) || (nd.hash_off == 0 && nd.hash_len == 240);
+    return nd.H == kFcH && fp_eligible(nd.in_dim, nd.A) && nd.in_dim == 240 && !nd.sim_matrix && hash_ok;
 }
 static int sq16_persist_launch(eaz_search* s, int sim0, int n_sims, bool expand_first, bool expand_last, hipStream_t st) {
     Sq16SearchArgs a;
@@ -1146,13 +1249,31 @@ static int sq16_persist_launch(eaz_search* s, int sim0, int n_sims, bool expand_
 
 // Subleq-16 fused self-play: T real steps in one launch (search_subleq_persist.hpp)
 static bool sqp_eligible(const eaz_search* s) {
-    if (!(s->sqp_lds > 0 && sq16_persist_eligible(s) && s->tree.max_depth >= 1)) return false;
+    if (!(s->sqp_lds > 0 && sq16_persist_eligible(s) && s->tree.max_depth >= 1 && sq16_l1_mode_of(s->net) >= 0)) return false;
     for (int i = 0; i < s->env->dev.n_tasks; ++i)  // the kernel keeps a tree's task as 16 bits (QpMisc::task); a root blob's own task field likewise
         if (s->env->dev.tasks[i] < -32768 || s->env->dev.tasks[i] > 32767) return false;
     return true;
 }
+// Do the blobs a call starts from fit the one-launch kernel's compact state (search_subleq_persist.hpp sq16_roots_fit_kernel)?  One small
+// launch, a 4-byte copy and a stream synchronisation; while the stream is being captured the question cannot be answered and the answer
+// is "no" (the per-simulation kernels keep whole blobs and are always right).
+static int sq16_roots_fit(eaz_search* s, const void* d_states, hipStream_t st, bool* fit) {
+    *fit = false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 0;
+    HIP_OK(hipMemsetAsync(s->d_alive, 0, sizeof(int), st));
+    sq16_roots_fit_kernel<<<cdiv(s->B, 256), 256, 0, st>>>(static_cast<const char*>(d_states), static_cast<long>(sizeof(eaz_subleq_state)), s->B, s->d_alive);
+    LAUNCH_OK();
+    int misfit = 1;
+    HIP_OK(hipMemcpyAsync(&misfit, s->d_alive, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    *fit = misfit == 0;
+    return 0;
+}
 // layer-1 weights in the one-launch kernel's packed input order (sq16_l1_src), rebuilt on the launch stream after every weight upload
-static int sq16_pack_w1(eaz_net* n, int mode, hipStream_t st) {
+static int sq16_pack_w1(eaz_net* n, hipStream_t st) {
+    const int mode = sq16_l1_mode_of(n);
+    if (mode < 0) return fail("internal: the Subleq-16 one-launch kernel does not support this layer-1 input order");
     if (n->dev.l1q_mode == mode && n->w1q_stamp == n->w_stamp) return 0;
     const int rows = 32 * sq16_l1_halves(0);  // the larger of the two modes
     for (int h = 0; h < 4; ++h)
@@ -1164,9 +1285,10 @@ static int sq16_pack_w1(eaz_net* n, int mode, hipStream_t st) {
     return 0;
 }
 static int sqp_launch(eaz_search* s, const PersistSelfplay& sp, hipStream_t st) {
-    const int rc = sq16_pack_w1(s->net, 0, st);
+    const int rc = sq16_pack_w1(s->net, st);
     if (rc) return rc;
     Sq16SelfplayArgs a;
+    a.l1init = s->d_sq_l1init;
     a.sp = sp;
     a.t = s->tree;
     a.e = s->env->dev;
@@ -1174,6 +1296,10 @@ static int sqp_launch(eaz_search* s, const PersistSelfplay& sp, hipStream_t st) 
     a.heads = HeadList{3, {0, 1, s->opts.exploration ? 3 : 2, 0}};  // context.py:132
     a.logits = s->d_sq_logits;
     a.stamps = s->d_stamps;
+    if (a.net.l1q_mode == 1) {  // chain starts of the six task branches for the heads this search reads (search_subleq_persist.hpp qp_l1_chain)
+        sq16_l1_table_kernel<<<dim3(6, 3), 256, 0, st>>>(a.net, a.heads, a.l1init);
+        LAUNCH_OK();
+    }
     subleq16_selfplay_kernel<<<cdiv(s->B, kQpTrees), kQpThreads, s->sqp_lds, st>>>(a);
     LAUNCH_OK();
     return 0;
@@ -1203,7 +1329,7 @@ static int infer_launch(eaz_search* s, const uint8_t* obs, float* novelty, const
     const int B = s->B;
     if (novelty_done) {  // the env-step kernel already looked the observations up
         ProfScope ps(s, EAZ_K_NET, st);
-        return fc_launch(s->net, B, obs, o, hl, st);
+        return fc_launch(s->net, B, obs, o, hl, st, s->d_obs_perm);
     }
     hipStream_t hs = st;
     if (s->side) {
@@ -1219,7 +1345,7 @@ static int infer_launch(eaz_search* s, const uint8_t* obs, float* novelty, const
     if (s->side) HIP_OK(hipEventRecord(s->ev_join, s->side));
     {
         ProfScope ps(s, EAZ_K_NET, st);
-        int rc = fc_launch(s->net, B, obs, o, hl, st);
+        int rc = fc_launch(s->net, B, obs, o, hl, st, s->d_obs_perm);
         if (rc) return rc;
     }
     if (s->side) HIP_OK(hipStreamWaitEvent(st, s->ev_join, 0));
@@ -1247,11 +1373,21 @@ static int recurrent_launch(eaz_search* s, hipStream_t st) {
         } else if (env->dev.kind == EAZ_ENV_CONNECT4) {
             StateRef src{s->tree.embeddings, s->tree.sim_parent, s->N};
             StateRef dst{s->tree.embeddings, s->tree.sim_next, s->N};
-            connect4_step_kernel<<<cdiv(B, 256), 256, 0, st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0}, nullptr,
-                                                              s->d_next_reward, s->d_next_term, s->d_next_legal);
-            LAUNCH_OK();
-            obs_emit_kernel<<<cdiv(static_cast<long>(B) * 64, 256), 256, 0, st>>>(env->dev, dst, B, s->d_obs);
-            LAUNCH_OK();
+            const NetDev& nd = s->net->dev;
+            if (g_fused_leaf) {
+                // step + child state + observation row + novelty lookup in one launch (env_kernels.hpp connect4_leaf_kernel)
+                novelty_done = s->net->kind == 1 && !nd.sim_matrix && nd.hash_off == 0 && nd.hash_len == 84 && nd.in_dim == 84;
+                connect4_leaf_kernel<<<cdiv(static_cast<long>(B) * 4, 64), 64, 0, st>>>(
+                    env->dev, src, dst, s->tree.sim_action, B, s->d_next_reward, s->d_next_term, s->d_next_legal, s->d_obs,
+                    NoveltyFuse{nd.bitset, novelty_done ? s->d_novelty : nullptr, nd.hash_bits, nd.nov_scale});
+                LAUNCH_OK();
+            } else {
+                connect4_step_kernel<<<cdiv(B, 256), 256, 0, st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0}, nullptr,
+                                                                  s->d_next_reward, s->d_next_term, s->d_next_legal);
+                LAUNCH_OK();
+                obs_emit_kernel<<<cdiv(static_cast<long>(B) * 64, 256), 256, 0, st>>>(env->dev, dst, B, s->d_obs);
+                LAUNCH_OK();
+            }
         } else {
             StateRef src{s->tree.embeddings, s->tree.sim_parent, s->N};
             StateRef dst{s->tree.embeddings, s->tree.sim_next, s->N};
@@ -1334,6 +1470,17 @@ static int flush_expand(eaz_search* s, hipStream_t st) {
     return rc;
 }
 
+extern "C" int eaz_search_debug_poison(eaz_search* s, int byte_value, void* stream) {
+    ARG_OK(s != nullptr && byte_value >= 0 && byte_value <= 255);
+    hipStream_t st = S(stream);
+    const TreeDev& t = s->tree;
+    const size_t B = static_cast<size_t>(s->B), BS = B * s->S;
+    HIP_OK(hipMemsetAsync(t.sim_parent, byte_value, sizeof(int32_t) * B, st)); HIP_OK(hipMemsetAsync(t.sim_action, byte_value, sizeof(int32_t) * B, st));
+    HIP_OK(hipMemsetAsync(t.sim_next, byte_value, sizeof(int32_t) * B, st)); HIP_OK(hipMemsetAsync(t.path_len, byte_value, sizeof(int32_t) * B, st));
+    HIP_OK(hipMemsetAsync(t.path_node, byte_value, sizeof(int32_t) * BS, st)); HIP_OK(hipMemsetAsync(t.path_action, byte_value, sizeof(int32_t) * BS, st));
+    return 0;
+}
+
 extern "C" int eaz_search_launch_info(const eaz_search* s, int* one_launch, int* lds_bytes) {
     ARG_OK(s != nullptr);
     const bool ds = s->persist_ok && g_persist;
@@ -1354,7 +1501,7 @@ extern "C" int eaz_search_run(eaz_search* s, void* stream) {
         s->sims_done = s->S;
         return 0;
     }
-    if (g_persist == 1 && s->clear_pending && s->sims_done == 0 && s->pending_expand < 0 && sqp_eligible(s)) {
+    if (g_persist == 1 && s->clear_pending && s->sims_done == 0 && s->pending_expand < 0 && s->sqp_roots_fit && sqp_eligible(s)) {
         // Subleq-16: all S simulations in one launch on LDS node-record trees, the whole tree written back at the end
         // (search_subleq_persist.hpp, search-only mode)
         ProfScope ps(s, EAZ_K_SEARCH, S(stream));
@@ -1655,7 +1802,14 @@ extern "C" int eaz_selfplay_run(eaz_search* s, const eaz_selfplay_cfg* cfg, uint
         ProfScope ps(s, EAZ_K_SEARCH, S(stream));
         return persist_launch(s, S(stream), &sp);
     }
-    if (g_persist == 1 && sqp_eligible(s)) {
+    bool sq_fit = false;
+    if (g_persist == 1 && sqp_eligible(s) && cfg->selfplay_steps > 0) {
+        // a hand-made state beyond the compact form of the one-launch kernel (program words >= 16, IO values > 16, ...) sends the call to
+        // the per-step path below, which keeps whole blobs
+        const int rc = sq16_roots_fit(s, d_states, S(stream), &sq_fit);
+        if (rc) return rc;
+    }
+    if (g_persist == 1 && sqp_eligible(s) && (sq_fit || cfg->selfplay_steps == 0)) {
         // Subleq-16 + FC network: likewise the whole call in ONE launch (csrc/search_subleq_persist.hpp)
         if (cfg->selfplay_steps == 0) return 0;
         PersistSelfplay sp;
@@ -1792,7 +1946,7 @@ extern "C" int eaz_reanalyze_run(eaz_search* s, const eaz_reanalyze_cfg* cfg, ui
     {
         HeadList hl{1, {0, 0, 0, 0}};
         NetOut o{nullptr, nullptr, s->d_next_v, nullptr};
-        rc = fc_launch(s->net, B, s->d_obs, o, hl, st);
+        rc = fc_launch(s->net, B, s->d_obs, o, hl, st, s->d_obs_perm);
         if (rc) return rc;
     }
     env_fields_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->env->dev, static_cast<const char*>(d_next_states), B, s->d_term2, nullptr, s->d_reward_tmp,
@@ -1954,7 +2108,7 @@ extern "C" int eaz_profile_replay(eaz_search* s, int cls, int iters, double* ms_
             if (sqp) return sqp_launch(s, sp, st);
             return persist_launch(s, st, &sp);
         }
-        if (cls == EAZ_K_NET) return fused ? fc_onehot_launch(s->net, s->B, s->d_leaf_hot, s->d_novelty, o, hl, st) : fc_launch(s->net, s->B, s->d_obs, o, hl, st);
+        if (cls == EAZ_K_NET) return fused ? fc_onehot_launch(s->net, s->B, s->d_leaf_hot, s->d_novelty, o, hl, st) : fc_launch(s->net, s->B, s->d_obs, o, hl, st, s->d_obs_perm);
         leaf_gather_deepsea_kernel<<<cdiv(static_cast<long>(s->B) * 64, 256), 256, 0, st>>>(s->env->dev, s->tree, s->d_obs, s->d_next_reward,
                                                                                           s->d_next_term, s->d_next_legal);
         LAUNCH_OK();

@@ -390,6 +390,39 @@ struct NoveltyFuse {
     float nov_scale;
 };
 
+// XXHash-variant index (hashes.py:162-229) of a Subleq-16 binary observation from its 48 row-word codes (5 observation bits each: bits 0..3
+// = v mod 16, bit 4 = the pad flag, subleq.py:88-98), four lanes per observation: lane i = stripe i = the contiguous quarter i of the hashed
+// slice (hashes.py:211), an observation byte is 0 or 1 (bitcast float 1.0 = 0x3F800000, :207).  The slice is the four IO rows
+// (subleq_hash_only_io, fully_connected.py:85-87: 32 words -> stripes of 8 words, L = 40) or, full_obs, the whole observation
+// (config.py:30 False, fully_connected.py:88-89: 48 words -> stripes of 12 words, L = 60).  `words48` is 4-byte aligned.  The index is
+// returned on all four lanes of the observation (lanes 4 e .. 4 e + 3 of the wavefront).
+__device__ __forceinline__ uint32_t sq16_words_hash_index(const uint8_t* words48, const int i, const bool full_obs, const int hash_bits) {
+    const uint32_t P1 = 0x9E3779B1u, P2 = 0x85EBCA77u, P3 = 0xC2B2AE3Du, SEED = 1u, ONE = 0x3F800000u * P2;
+    uint32_t acc = i == 0 ? SEED + P1 + P2 : (i == 1 ? SEED + P2 : (i == 2 ? SEED : SEED - P1));  // :217-220
+    const int nw = full_obs ? 12 : 8;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(words48 + (full_obs ? 12 * i : 16 + 8 * i));
+#pragma unroll 1
+    for (int q = 0; q < nw; q += 4) {
+        const uint32_t ww = p[q >> 2];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t code = (ww >> (8 * w)) & 0xFFu;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const uint32_t t = acc + ((code >> j) & 1u ? ONE : 0u);
+                acc = ((t << 13) | (t >> 19)) * P1;  // :176-181
+            }
+        }
+    }
+    const int rot = i == 0 ? 1 : (i == 1 ? 7 : (i == 2 ? 12 : 18));  // :184-187
+    uint32_t h = (acc << rot) | (acc >> (32 - rot));
+    h += __shfl_xor(h, 1);
+    h += __shfl_xor(h, 2);
+    h += full_obs ? 60u : 40u;  // :226 (stripe count L, not the byte length)
+    h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;  // :190-197
+    return h >> (32 - hash_bits);                                // :229
+}
+
 __device__ __forceinline__ void subleq16_novelty(const NoveltyFuse& nf, const int b, const uint32_t index) {
     const bool seen = nf.bitset ? ((nf.bitset[index >> 3] >> (index & 7u)) & 1u) != 0 : false;  // hashes.py:29-38
     nf.novelty[b] = (seen ? 0.0f : 1.0f) * nf.nov_scale;                                        // fully_connected.py:90
@@ -868,35 +901,102 @@ __global__ void __launch_bounds__(64) subleq_wave_kernel(EnvDev e, StateRef src,
 }
 
 // ---- connect_four -------------------------------------------------------------------------------------------------
-// One thread per environment.  mode as deepsea_step_kernel.  mover_reward[b] = rewards[b, current_player BEFORE the step]
-// (context.py:125,139 / evaluate.py:48-50).
+// One thread per environment, the game on bitboards (envs.hpp c4_bits_*: no indexed local array, no scratch).  mode as deepsea_step_kernel.
+// mover_reward[b] = rewards[b, current_player BEFORE the step] (context.py:125,139 / evaluate.py:48-50).
 __global__ void __launch_bounds__(256) connect4_step_kernel(EnvDev e, StateRef src, StateRef dst, const int32_t* action, int B, int mode,
                                                             Key key_arg, const Key* key_ptr, float* mover_reward, uint8_t* next_term,
                                                             uint8_t* next_legal) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const Key key = key_ptr ? *key_ptr : key_arg;
-    eaz_connect4_state s;
+    C4Bits s;
     int mover = 0;
     if (mode == 2) {
-        c4_init(s, fold(key, static_cast<uint32_t>(b)));
+        c4_bits_init(s, fold(key, static_cast<uint32_t>(b)));
     } else {
         const uint4* sp = reinterpret_cast<const uint4*>(state_ptr(src, b, e.state_bytes));
-        uint4* sv = reinterpret_cast<uint4*>(&s);
+        uint4 v[5];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) sv[i] = sp[i];
+        for (int i = 0; i < 5; ++i) v[i] = sp[i];
+        c4_bits_load(s, v);
         mover = s.current_player;
-        if (mode == 1 && (s.terminated | s.truncated)) c4_init(s, fold(fold(key, static_cast<uint32_t>(b)), 1u));
-        else c4_step(s, action[b]);
+        if (mode == 1 && (s.terminated | s.truncated)) c4_bits_init(s, fold(fold(key, static_cast<uint32_t>(b)), 1u));
+        else c4_bits_step(s, action[b]);
     }
     uint4* dp = reinterpret_cast<uint4*>(state_ptr(dst, b, e.state_bytes));
-    const uint4* sv = reinterpret_cast<const uint4*>(&s);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) dp[i] = sv[i];
+    for (int i = 0; i < 5; ++i) dp[i] = make_uint4(c4_bits_word(s, 4 * i), c4_bits_word(s, 4 * i + 1), c4_bits_word(s, 4 * i + 2), c4_bits_word(s, 4 * i + 3));
     if (mover_reward) mover_reward[b] = mover == 0 ? s.reward0 : s.reward1;
-    if (next_term) next_term[b] = s.terminated;
+    if (next_term) next_term[b] = static_cast<uint8_t>(s.terminated);
     if (next_legal)
-        for (int a = 0; a < 7; ++a) next_legal[static_cast<long>(b) * 7 + a] = c4_legal(s, a) ? 1 : 0;
+        for (int a = 0; a < 7; ++a) next_legal[static_cast<long>(b) * 7 + a] = c4_bits_legal(s, a) ? 1 : 0;
+}
+
+// The leaf step of a connect_four simulation in ONE launch (context.py:125-131 up to the forward): gather the parent state, env.step of the
+// selected edge, child state into its embedding slot, the [6, 7, 2] observation row of the inference batch, mover reward / terminated / legal
+// mask, and the novelty lookup of the new observation (XXHash variant over the whole row: four lanes per environment, lane i = the contiguous
+// quarter i = 21 observation bytes, hashes.py:162-229) -- what connect4_step_kernel + obs_emit_kernel + hash_kernel (on a side stream,
+// forked and joined per simulation) did in three.  Four lanes per environment, each computes the step (a few dozen integer operations on
+// two 64-bit boards), the stores are shared out.  novelty == nullptr (SimHash networks): no lookup, the caller runs its hash kernel.
+__global__ void __launch_bounds__(64) connect4_leaf_kernel(EnvDev e, StateRef src, StateRef dst, const int32_t* action, int B, float* mover_reward,
+                                                           uint8_t* next_term, uint8_t* next_legal, uint8_t* obs, NoveltyFuse nf) {
+    const int gt = blockIdx.x * 64 + threadIdx.x;
+    const int b = gt >> 2, q = gt & 3;
+    const bool live = b < B;
+    const int bb = live ? b : B - 1;
+    C4Bits s;
+    {
+        const uint4* sp = reinterpret_cast<const uint4*>(state_ptr(src, bb, e.state_bytes));
+        uint4 v[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) v[i] = sp[i];
+        c4_bits_load(s, v);
+    }
+    const int mover = s.current_player;
+    c4_bits_step(s, action[bb]);
+    // child state: lane q writes 16-byte words q and q + 4 of the blob's five
+    uint4* dp = reinterpret_cast<uint4*>(state_ptr(dst, bb, e.state_bytes));
+    if (live) {
+        dp[q] = make_uint4(c4_bits_word(s, 4 * q), c4_bits_word(s, 4 * q + 1), c4_bits_word(s, 4 * q + 2), c4_bits_word(s, 4 * q + 3));
+        if (q == 0) dp[4] = make_uint4(c4_bits_word(s, 16), 0u, 0u, 0u);
+    }
+    // observation row (84 bytes = 21 words): lane q writes words 6 q .. 6 q + 5 (lane 3: three)
+    if (live) {
+        uint32_t* orow = reinterpret_cast<uint32_t*>(obs + static_cast<long>(b) * 84);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int w = 6 * q + k;
+            if (w < 21) {
+                uint32_t word = 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) word |= c4_bits_obs(s, 4 * w + j) << (8 * j);
+                orow[w] = word;
+            }
+        }
+    }
+    if (nf.novelty) {
+        const uint32_t P1 = 0x9E3779B1u, P2 = 0x85EBCA77u, P3 = 0xC2B2AE3Du, SEED = 1u, ONE = 0x3F800000u * P2;
+        uint32_t acc = q == 0 ? SEED + P1 + P2 : (q == 1 ? SEED + P2 : (q == 2 ? SEED : SEED - P1));  // :217-220
+#pragma unroll
+        for (int l = 0; l < 21; ++l) {
+            const uint32_t t = acc + (c4_bits_obs(s, 21 * q + l) ? ONE : 0u);
+            acc = ((t << 13) | (t >> 19)) * P1;  // :176-181
+        }
+        const int rot = q == 0 ? 1 : (q == 1 ? 7 : (q == 2 ? 12 : 18));  // :184-187
+        uint32_t h = (acc << rot) | (acc >> (32 - rot));
+        h += __shfl_xor(h, 1);
+        h += __shfl_xor(h, 2);
+        h += 21u;  // :226 (stripe count)
+        h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;  // :190-197
+        const uint32_t index = nf.hash_bits >= 32 ? h : h >> (32 - nf.hash_bits);  // :229
+        if (q == 0 && live) subleq16_novelty(nf, b, index);
+    }
+    if (live && q == 1) {
+        if (mover_reward) mover_reward[b] = mover == 0 ? s.reward0 : s.reward1;
+        if (next_term) next_term[b] = static_cast<uint8_t>(s.terminated);
+    }
+    if (live && q == 2 && next_legal)
+        for (int a = 0; a < 7; ++a) next_legal[static_cast<long>(b) * 7 + a] = c4_bits_legal(s, a) ? 1 : 0;
 }
 
 // ---- state field export (pgx.State-visible fields) -----------------------------------------------------------------

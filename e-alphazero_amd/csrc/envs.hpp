@@ -453,4 +453,102 @@ __device__ __forceinline__ void c4_step(eaz_connect4_state& s, int action) {
     }
 }
 
+// ---- the same game on bitboards (device kernels): no indexed local array, hence no scratch memory ------------------------------
+// Stones of colour c as bits of m[c], bit r * 7 + col (row 0 at the top, the blob's board order).  Results identical to c4_step /
+// c4_init / c4_legal above (tests/test_gpu_golden.py::test_connect4_env_matches_oracle, the golden c4r case and the full-size C4 tests).
+struct C4Bits {
+    int32_t step_count, current_player, winner;
+    float reward0, reward1;
+    uint32_t terminated, truncated, color;
+    unsigned long long m[2];
+};
+constexpr unsigned long long kC4Col0 = 1ull | (1ull << 7) | (1ull << 14) | (1ull << 21) | (1ull << 28) | (1ull << 35);  // column 0, rows 0..5
+constexpr unsigned long long kC4All = (1ull << 42) - 1ull;
+constexpr unsigned long long kC4ColLe3 = kC4Col0 | (kC4Col0 << 1) | (kC4Col0 << 2) | (kC4Col0 << 3);  // cells whose column is <= 3
+constexpr unsigned long long kC4ColGe3 = (kC4Col0 << 3) | (kC4Col0 << 4) | (kC4Col0 << 5) | (kC4Col0 << 6);
+// the 42 board bytes of a blob (words 6..16: board[0] is byte 24) -> bitboards
+__device__ __forceinline__ void c4_bits_load(C4Bits& s, const uint4 (&v)[5]) {
+    const uint32_t w[20] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w,
+                            v[3].x, v[3].y, v[3].z, v[3].w, v[4].x, v[4].y, v[4].z, v[4].w};
+    s.step_count = static_cast<int32_t>(w[0]); s.current_player = static_cast<int32_t>(w[1]);
+    s.reward0 = __builtin_bit_cast(float, w[2]);
+    s.terminated = w[3] & 0xFFu; s.truncated = (w[3] >> 8) & 0xFFu; s.color = (w[3] >> 16) & 0xFFu;
+    s.reward1 = __builtin_bit_cast(float, w[4]);
+    s.winner = static_cast<int32_t>(w[5]);
+    unsigned long long m0 = 0ull, m1 = 0ull;
+#pragma unroll
+    for (int i = 0; i < 42; ++i) {
+        const uint32_t byte = (w[6 + (i >> 2)] >> (8 * (i & 3))) & 0xFFu;
+        m0 |= static_cast<unsigned long long>(byte == 0u) << i;
+        m1 |= static_cast<unsigned long long>(byte == 1u) << i;
+    }
+    s.m[0] = m0; s.m[1] = m1;
+}
+// word j (0..19) of the 80-byte blob
+__device__ __forceinline__ uint32_t c4_bits_word(const C4Bits& s, const int j) {
+    if (j == 0) return static_cast<uint32_t>(s.step_count);
+    if (j == 1) return static_cast<uint32_t>(s.current_player);
+    if (j == 2) return __builtin_bit_cast(uint32_t, s.reward0);
+    if (j == 3) return s.terminated | (s.truncated << 8) | (s.color << 16);
+    if (j == 4) return __builtin_bit_cast(uint32_t, s.reward1);
+    if (j == 5) return static_cast<uint32_t>(s.winner);
+    if (j > 16) return 0u;
+    uint32_t word = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = 4 * (j - 6) + k;
+        uint32_t byte = 0u;  // pad2
+        if (i < 42) byte = ((s.m[0] >> i) & 1ull) ? 0u : (((s.m[1] >> i) & 1ull) ? 1u : 0xFFu);
+        word |= byte << (8 * k);
+    }
+    return word;
+}
+__device__ __forceinline__ bool c4_bits_won(const unsigned long long m) {
+    const unsigned long long h = m & (m >> 1) & (m >> 2) & (m >> 3) & kC4ColLe3;     // right
+    const unsigned long long v = m & (m >> 7) & (m >> 14) & (m >> 21);                // down
+    const unsigned long long d = m & (m >> 8) & (m >> 16) & (m >> 24) & kC4ColLe3;    // down-right
+    const unsigned long long a = m & (m >> 6) & (m >> 12) & (m >> 18) & kC4ColGe3;    // down-left
+    return (h | v | d | a) != 0ull;
+}
+__device__ __forceinline__ void c4_bits_init(C4Bits& s, Key key) {
+    s.step_count = 0;
+    s.current_player = static_cast<int32_t>(rbits(key, 0) & 1u);  // jnp.int32(jax.random.bernoulli(key))
+    s.reward0 = 0.0f; s.reward1 = 0.0f;
+    s.terminated = 0u; s.truncated = 0u; s.color = 0u;
+    s.winner = -1;
+    s.m[0] = 0ull; s.m[1] = 0ull;
+}
+__device__ __forceinline__ int c4_bits_col_count(const C4Bits& s, const int a) { return __builtin_popcountll((s.m[0] | s.m[1]) & (kC4Col0 << a)); }
+__device__ __forceinline__ bool c4_bits_legal(const C4Bits& s, const int a) { return s.terminated ? true : c4_bits_col_count(s, a) < 6; }
+// pgx.Env.step wrapper (A.1) around ConnectFour._step: c4_step on bitboards
+__device__ __forceinline__ void c4_bits_step(C4Bits& s, const int action) {
+    if (s.terminated | s.truncated) { s.reward0 = 0.0f; s.reward1 = 0.0f; return; }
+    const int mover = s.current_player;
+    const uint32_t color = s.color;
+    const int n = c4_bits_col_count(s, action);
+    const bool illegal = n >= 6;
+    s.step_count += 1;
+    const unsigned long long stone = illegal ? 0ull : 1ull << ((5 - n) * 7 + action);
+    const unsigned long long mine = (color ? s.m[1] : s.m[0]) | stone;
+    if (color) s.m[1] = mine; else s.m[0] = mine;
+    const bool won = c4_bits_won(mine);
+    s.winner = won ? static_cast<int32_t>(color) : -1;
+    s.color = 1u - color;
+    s.current_player = 1 - mover;
+    const bool full = (s.m[0] | s.m[1]) == kC4All;
+    s.terminated = (won || full) ? 1u : 0u;
+    s.reward0 = 0.0f; s.reward1 = 0.0f;
+    if (won) { s.reward0 = mover == 0 ? 1.0f : -1.0f; s.reward1 = mover == 1 ? 1.0f : -1.0f; }
+    if (illegal) {  // _step_with_illegal_action: mover -1, the other player +1, terminated
+        s.reward0 = mover == 0 ? -1.0f : 1.0f;
+        s.reward1 = mover == 1 ? -1.0f : 1.0f;
+        s.terminated = 1u;
+    }
+}
+// observation byte i of [6, 7, 2] (obs_byte): plane 0 = stones of the colour to move, plane 1 = the other colour
+__device__ __forceinline__ uint32_t c4_bits_obs(const C4Bits& s, const int i) {
+    const unsigned long long plane = (((i & 1) != 0) != (s.color != 0u)) ? s.m[1] : s.m[0];
+    return static_cast<uint32_t>((plane >> (i >> 1)) & 1ull);
+}
+
 }  // namespace eaz

@@ -44,6 +44,12 @@ struct NetDev {
     // [32 l1q_halves][256] each; l1q_mode -1: not built
     const float* w1q[4];
     int l1q_mode, l1q_halves;
+    // Layer-1 input order (eaz_net_set_input_order, a switch of the numerics contract): the chain of layer 1 visits the inputs in the order
+    // in_perm[0], in_perm[1], ... instead of ascending.  Row kp of the device copies w[0], w[3], w[6], w[9] then holds the weights of input
+    // in_perm[kp] and every dense forward reads its observation rows through the same permutation (fc_permute_obs_kernel); null: ascending.
+    const int32_t* in_perm;
+    const int32_t* in_inv;    // the inverse: position of input k in the chain
+    const float* w1raw[4];    // layer-1 weights of the four heads with their rows in the ORIGINAL input order (= w[3 h] without an order)
 };
 
 struct NetOut {
@@ -52,6 +58,20 @@ struct NetOut {
     float* value;          // [B] or null
     float* ube;            // [B] or null: 0.5 * (tanh + 1) * max_u, BEFORE the novelty max / clip (see ube_combine)
 };
+
+// rows of a head's W1 in the network's input order: out[kp][c] = raw[perm[kp]][c]   (grid = in_dim, block = H threads)
+__global__ void fc_permute_w1_kernel(const float* __restrict__ raw, const int32_t* __restrict__ perm, float* __restrict__ out, int H) {
+    const int kp = blockIdx.x;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) out[static_cast<long>(kp) * H + c] = raw[static_cast<long>(perm[kp]) * H + c];
+}
+// observation rows in the network's input order: out[b][kp] = obs[b][perm[kp]]
+__global__ void __launch_bounds__(256) fc_permute_obs_kernel(const uint8_t* __restrict__ obs, const int32_t* __restrict__ perm, uint8_t* __restrict__ out,
+                                                            int B, int K) {
+    const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= static_cast<long>(B) * K) return;
+    const int b = static_cast<int>(i / K), kp = static_cast<int>(i - static_cast<long>(b) * K);
+    out[i] = obs[static_cast<long>(b) * K + perm[kp]];
+}
 
 __global__ void __launch_bounds__(256) ube_combine_kernel(float* ube, const float* novelty, float max_u, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;

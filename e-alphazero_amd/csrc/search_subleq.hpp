@@ -182,11 +182,12 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
             // (element (5 w + j, row) = bit j of word w: subleq.py:88-98); the first barrier of the bodies below publishes it.  The
             // observation rows never go through memory.
             float* Xs = reinterpret_cast<float*>(lds + kSqHeadGroups * fp_lds_bytes(240, 16));
+            const int32_t* inv = a->net.in_inv;  // layer-1 input order (eaz_net_set_input_order): input k sits at position inv[k] of the chain
             for (int idx = ft; idx < 16 * 48; idx += kSqThreads) {
                 const int row = idx / 48, w = idx - row * 48;
                 const uint32_t code = sq_words[row][w];
 #pragma unroll
-                for (int j = 0; j < 5; ++j) Xs[h16_off(5 * w + j, row)] = (code >> j) & 1u ? 1.0f : 0.0f;
+                for (int j = 0; j < 5; ++j) Xs[h16_off(inv ? inv[5 * w + j] : 5 * w + j, row)] = (code >> j) & 1u ? 1.0f : 0.0f;
             }
 #pragma unroll 1
             for (int h0 = 0; h0 < a->heads.n; h0 += kSqHeadGroups) {
@@ -194,28 +195,10 @@ __global__ void __launch_bounds__(kSqThreads) subleq16_search_kernel(Sq16SearchA
                     fc16p_body(a->net, a->obs, a->t.B, a->out, a->heads.id[h0 + hg], b0, lds + hg * fp_lds_bytes(240, 16), pt, nullptr, Xs);
                 } else {
                     // this head group has no head left: one of its waves looks the 16 observations' novelty up meanwhile (XXHash variant,
-                    // hashes.py:162-229: lane = (environment, stripe), stripe i = IO row i = 8 words x 5 bytes that are 0 or 1)
+                    // hashes.py:162-229: lane = (environment, stripe); the IO rows or the whole observation, sq16_words_hash_index)
                     if ((wave & 3) == 0) {
-                        const uint32_t P1 = 0x9E3779B1u, P2 = 0x85EBCA77u, P3 = 0xC2B2AE3Du, SEED = 1u, ONE = 0x3F800000u * P2;
                         const int lane = ft & 63, e = lane >> 2, i = lane & 3;
-                        uint32_t acc = i == 0 ? SEED + P1 + P2 : (i == 1 ? SEED + P2 : (i == 2 ? SEED : SEED - P1));  // :217-220
-                        const uint2 ww = *reinterpret_cast<const uint2*>(&sq_words[e][16 + 8 * i]);
-#pragma unroll
-                        for (int w = 0; w < 8; ++w) {
-                            const uint32_t code = ((w < 4 ? ww.x : ww.y) >> (8 * (w & 3))) & 0xFFu;
-#pragma unroll
-                            for (int j = 0; j < 5; ++j) {
-                                const uint32_t t = acc + ((code >> j) & 1u ? ONE : 0u);
-                                acc = ((t << 13) | (t >> 19)) * P1;  // :176-181
-                            }
-                        }
-                        const int rot = i == 0 ? 1 : (i == 1 ? 7 : (i == 2 ? 12 : 18));  // :184-187
-                        uint32_t h = (acc << rot) | (acc >> (32 - rot));
-                        h += __shfl_xor(h, 1);
-                        h += __shfl_xor(h, 2);
-                        h += 40u;  // :226 (stripe count)
-                        h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;  // :190-197
-                        const uint32_t index = h >> (32 - a->nf.hash_bits);          // :229
+                        const uint32_t index = sq16_words_hash_index(&sq_words[e][0], i, a->net.hash_off == 0, a->nf.hash_bits);
                         if (i == 0 && b0 + e < a->t.B) subleq16_novelty(a->nf, b0 + e, index);
                     }
 #pragma unroll

@@ -84,6 +84,7 @@ struct QpMisc {
                                                 // byte, 0x38 = 1.0 or 0 (inputs 240..255: 0) -- lane (row, kq) reads its 64 k-steps as four 16-byte words and
                                                 // one v_cvt_pk_f32_fp8 makes the operands of TWO k-steps (subleq.py:88-98)
     uint8_t words[kQpTrees][48];        // row-words of the 16 observations in flight, 5 observation bits each (subleq.py:88-98)
+    uint8_t l1var[kQpTrees];            // layer-1 mode 1: which start vector the observation in flight chains from (0: the task's example rows, 1: the root blob's)
 };
 constexpr int kQpPartLd = 20;  // quarter sums [4 waves][16 rows][kQpPartLd]: slot 0 value, 1 ube, 2..17 policy logits
 
@@ -114,6 +115,9 @@ struct Sq16SelfplayArgs {
     NetDev net;
     HeadList heads;      // value, ube, the policy head the search reads (context.py:132)
     float* logits;       // [ceil16(B), N, 32] scratch rows of the trees: masked prior logits [16] | their softmax [16]
+    float* l1init;       // layer-1 mode 1, start of the layer-1 chains (qp_l1_start): [6 task branches][3 heads][256] for the example rows of a task's
+                         // table (written by sq16_l1_table_kernel in front of every launch), then [ceil16(B)][3][256] for the example rows of the trees'
+                         // root blobs (written by the kernel's prologue; read only for states that carry the blob's rows)
     unsigned long long* stamps;
 };
 
@@ -243,7 +247,7 @@ __global__ void __launch_bounds__(256) sq16_pack_w1_kernel(NetDev net, int mode,
     const int kp = blockIdx.x, head = blockIdx.y, c = threadIdx.x;
     float* out = head == 0 ? o0 : (head == 1 ? o1 : (head == 2 ? o2 : o3));
     const int src = sq16_l1_src(mode, kp);
-    out[kp * kFcH + c] = src >= 0 ? net.w[head * 3][src * kFcH + c] : 0.0f;
+    out[kp * kFcH + c] = src >= 0 ? net.w1raw[head][src * kFcH + c] : 0.0f;  // w1raw: rows in the ORIGINAL input order (w[3 head] may be permuted)
 }
 
 // The observation of a state, twice: the 48 row-words (memory | example_input | input_after | example_output | output_after,
@@ -304,6 +308,9 @@ __device__ __forceinline__ floatx2 qp_abytes2(const uint2& w, const int i /* eve
 }
 constexpr int kQpAAhead = 2;  // layer 1: a pair of A operands is converted this many k-steps before the MFMAs that read them (ring av[])
 constexpr int kQpHalf = 8;    // k-steps of a half-round
+#ifndef EAZ_QP_SB_MASK
+#define EAZ_QP_SB_MASK 0
+#endif
 template <int CHAIN, bool ABITS, int PH>
 __device__ __forceinline__ void qp_half(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDepth], float (&av)[kPsARing], const float* apn, const uint2 abits,
                                         const uint2 abits_next, __amdgpu_buffer_rsrc_t rs, int voff, int sbase, floatx4& a3, const float* hpA,
@@ -335,7 +342,7 @@ __device__ __forceinline__ void qp_half(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDept
         } else {
             av[i] = apn[i * 68];
         }
-        __builtin_amdgcn_sched_barrier(0);  // keep every refill right behind the k-step that freed its registers
+        __builtin_amdgcn_sched_barrier(EAZ_QP_SB_MASK);  // keep every refill right behind the k-step that freed its registers
     }
 }
 // the same with the phase as an argument (a constant once the head loop is unrolled)
@@ -353,7 +360,7 @@ __device__ __forceinline__ void qp_half_ph(const int ph, floatx4 (&acc)[4], floa
 __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src, uint32_t* dst, const uint32_t* root_ex, uint8_t* words,
                                             uint8_t* xb, const int action, const int mode, const Key envkey, const int b, const int lane, char* blob0,
                                             char* blob1, float& reward_out, int& term_out, int16_t* tree_task, const int l1_mode,
-                                            unsigned long long* dstamp = nullptr) {
+                                            uint8_t* l1var, unsigned long long* dstamp = nullptr) {
     EAZ_QESTAMP(dstamp, 8);
     uint32_t s[QS_WORDS];
 #pragma unroll
@@ -468,6 +475,7 @@ __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src
                            __builtin_bit_cast(uint32_t, reward));
     }
     EAZ_QESTAMP(dstamp, 11);
+    if (lane == 0) *l1var = static_cast<uint8_t>(exroot);
     qp_emit_obs(words, xb, mem, exin, inaf, exout, outaf, lane, l1_mode);
     EAZ_QESTAMP(dstamp, 12);
 #pragma unroll
@@ -502,35 +510,78 @@ __device__ __forceinline__ void qp_env_step(const EnvDev& e, const uint32_t* src
     EAZ_QESTAMP(dstamp, 13);
 }
 
-// novelty of the 16 observations whose row-words are in M.words (XXHash variant, hashes.py:162-229: lane = (environment, stripe), stripe i =
-// IO row i = 8 words x 5 bytes that are 0 or 1), one wavefront
+// novelty of the 16 observations whose row-words are in M.words (XXHash variant, hashes.py:162-229: lane = (environment, stripe); the IO
+// rows or, subleq_hash_only_io = False, the whole observation: sq16_words_hash_index), one wavefront
 __device__ __forceinline__ void qp_novelty(const NetDev& net, QpMisc& M, const int lane) {
-    // novelty of the 16 observations (XXHash variant, hashes.py:162-229: lane = (environment, stripe), stripe i = IO row i =
-    // 8 words x 5 bytes that are 0 or 1)
-    const uint32_t P1 = 0x9E3779B1u, P2 = 0x85EBCA77u, P3 = 0xC2B2AE3Du, SEED = 1u, ONE = 0x3F800000u * P2;
     const int ev = lane >> 2, i = lane & 3;
-    uint32_t acc = i == 0 ? SEED + P1 + P2 : (i == 1 ? SEED + P2 : (i == 2 ? SEED : SEED - P1));  // :217-220
-    const uint2 ww = *reinterpret_cast<const uint2*>(&M.words[ev][16 + 8 * i]);
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        const uint32_t code = ((w < 4 ? ww.x : ww.y) >> (8 * (w & 3))) & 0xFFu;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const uint32_t tt = acc + ((code >> j) & 1u ? ONE : 0u);
-            acc = ((tt << 13) | (tt >> 19)) * P1;  // :176-181
-        }
-    }
-    const int rot = i == 0 ? 1 : (i == 1 ? 7 : (i == 2 ? 12 : 18));  // :184-187
-    uint32_t hsh = (acc << rot) | (acc >> (32 - rot));
-    hsh += __shfl_xor(hsh, 1);
-    hsh += __shfl_xor(hsh, 2);
-    hsh += 40u;  // :226 (stripe count)
-    hsh ^= hsh >> 15; hsh *= P2; hsh ^= hsh >> 13; hsh *= P3; hsh ^= hsh >> 16;  // :190-197
-    const uint32_t index = hsh >> (32 - net.hash_bits);                        // :229
+    const uint32_t index = sq16_words_hash_index(&M.words[ev][0], i, net.hash_off == 0, net.hash_bits);
     if (i == 0) {
         const bool seen = net.bitset ? ((net.bitset[index >> 3] >> (index & 7u)) & 1u) != 0 : false;  // hashes.py:29-38
         M.o_nov[ev] = (seen ? 0.0f : 1.0f) * net.nov_scale;                                            // fully_connected.py:90
     }
+}
+
+// Layer-1 mode 1 (the network's input order puts example_input / example_output first, sq16_l1_src): those 80 inputs are constants of a
+// tree between two resets, so the chain over them -- acc = +0; acc = fmaf(x[k], W1[k][c], acc) for k = 80..119, 160..199, the first 80 steps
+// of the oracle's chain under that order -- is computed once and every forward starts from it.  A zero input leaves the accumulator as it
+// is (exact), a one adds its weight row: fmaf(1, w, acc).  The vectors of the six task branches (get_test_cases clamps, subleq.py:459-501)
+// are shared by all trees: kQpL1Tab floats at the start of `l1init`, filled by sq16_l1_table_kernel; a tree's root blob may carry other rows
+// (a hand-made state), whose vector the prologue writes behind the table.
+constexpr int kQpL1Tab = 6 * 3 * kFcH;
+__device__ __forceinline__ float qp_l1_chain(const float* W /* column of the head's W1, original input order */, const unsigned long long exin,
+                                             const unsigned long long exout) {
+    float acc = 0.0f;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const unsigned long long row = half == 0 ? exin : exout;
+        const int k0 = half == 0 ? 80 : 160;  // observation inputs of example_input / example_output (subleq.py:697-705)
+#pragma unroll 1
+        for (int w = 0; w < 8; ++w) {
+            const uint32_t code = qp_code(static_cast<uint32_t>(row >> (8 * w)) & 0xFFu);
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                if ((code >> j) & 1u) acc = __builtin_fmaf(1.0f, W[(k0 + 5 * w + j) * kFcH], acc);
+        }
+    }
+    return acc;
+}
+// grid = (6 task branches, 3 heads), 256 threads = hidden columns
+__global__ void __launch_bounds__(256) sq16_l1_table_kernel(NetDev net, HeadList heads, float* l1init) {
+    const int branch = blockIdx.x, head = blockIdx.y, col = threadIdx.x;
+    l1init[(branch * 3 + head) * kFcH + col] = qp_l1_chain(net.w1raw[heads.id[head]] + col, kSq16Cases.v[branch][0][0], kSq16Cases.v[branch][0][1]);
+}
+// the root blobs' vectors of the workgroup's 16 trees: thread -> (tree, head, column)
+__device__ __forceinline__ void qp_l1_start_roots(const NetDev& net, const HeadList& heads, float* l1root_wg /* [16][3][256] */, const QpMisc& M, const int tid) {
+    for (int it = tid; it < kQpTrees * 3 * kFcH; it += kQpThreads) {
+        const int col = it & (kFcH - 1), head = (it >> 8) % 3, ti = it / (3 * kFcH);
+        l1root_wg[it] = qp_l1_chain(net.w1raw[heads.id[head]] + col, qp_u64(M.root_ex[ti][0], M.root_ex[ti][1]), qp_u64(M.root_ex[ti][2], M.root_ex[ti][3]));
+    }
+}
+
+// The compact state of this kernel (QS_*) holds less than the 336-byte blob of include/eaz.h: program words as 4 bits (and none beyond the
+// sixteenth), IO values as bytes with 16 as "beyond the valid ones", the step count in 8 bits, the task in 16.  Every state the environment
+// itself produces fits (subleq.py:88-98,648-677); a caller's hand-made blob may not, and would be truncated silently.  The host runs this
+// check on the blobs a call starts from and sends a batch with any misfit to the per-simulation kernels, which keep whole blobs.
+__global__ void __launch_bounds__(256) sq16_roots_fit_kernel(const char* __restrict__ states, long stride, int B, int* misfit) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const uint4* p = reinterpret_cast<const uint4*>(states + static_cast<long>(b) * stride);
+    const uint4 hv = p[0];
+    const int step = static_cast<int>(hv.x), task = static_cast<int>(hv.y);
+    bool ok = step >= 0 && step <= 255 && task >= -32768 && task <= 32767;
+#pragma unroll
+    for (int i = 1; i <= 4; ++i) {  // four rows of eight uint16: every value <= 16
+        const uint4 r = p[i];
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ok = ok && (w[k] & 0xFFFFu) <= 16u && (w[k] >> 16) <= 16u;
+    }
+    const uint4 m0 = p[5];  // the sixteen program words: each < 16
+    ok = ok && ((m0.x | m0.y | m0.z | m0.w) & 0xF0F0F0F0u) == 0u;
+    uint32_t tail = 0u;
+    for (int i = 6; i < 21; ++i) { const uint4 m = p[i]; tail |= m.x | m.y | m.z | m.w; }  // bytes 16..255 of the memory: zero
+    ok = ok && tail == 0u;
+    if (!ok) *misfit = 1;
 }
 
 // The kernel's arguments live in the kernarg segment and every phase reads them through a pointer the compiler cannot see through (an
@@ -636,6 +687,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             rs[QS_REWARD] = hv.z;
             M.root_ex[j][0] = static_cast<uint32_t>(exin); M.root_ex[j][1] = static_cast<uint32_t>(exin >> 32);
             M.root_ex[j][2] = static_cast<uint32_t>(exout); M.root_ex[j][3] = static_cast<uint32_t>(exout >> 32);
+            M.l1var[j] = 1;  // the root's example rows are the blob's
         }
         qp_emit_obs(M.words[j], M.obytes[j], mem, exin, inaf, exout, outaf, lane, a.net.l1q_mode);
     }
@@ -685,6 +737,13 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
         }
     }
     __syncthreads();
+    {
+        EAZ_QP_ARGS;
+        if (a.net.l1q_mode == 1) {
+            qp_l1_start_roots(a.net, a.heads, a.l1init + kQpL1Tab + static_cast<long>(b0) * (3 * kFcH), M, phase_tid());
+            __syncthreads();  // global stores -> loads of other waves of the workgroup (one CU, one L1)
+        }
+    }
     if (search_only) {
         EAZ_QP_TREE_LANES;
         if (tl < QS_WORDS) ST[tl] = M.root_state[ti][tl];  // embedding of node 0
@@ -1033,7 +1092,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                         unsigned long long* dsp = nullptr;
 #endif
                         qp_env_step(a.e, SJ + node * QS_WORDS, SJ + dstn * QS_WORDS, M.root_ex[j], M.words[j], M.obytes[j], action, 0, env_key, bj, lane,
-                                    nullptr, nullptr, rew, term, &M.task[j], a.net.l1q_mode, dsp);
+                                    nullptr, nullptr, rew, term, &M.task[j], a.net.l1q_mode, &M.l1var[j], dsp);
                         EAZ_QESTAMP(dsp, 14);
 #ifdef EAZ_FC_STAMPS
                         if (step == 0 && blockIdx.x < 64 && s <= 64) {
@@ -1050,7 +1109,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                         char* blob0 = (jlive && a.sp.out_states) ? a.sp.out_states + o * sizeof(eaz_subleq_state) : nullptr;
                         char* blob1 = (jlive && step == n_steps) ? a.sp.states + static_cast<long>(bj) * sizeof(eaz_subleq_state) : nullptr;
                         qp_env_step(a.e, M.root_state[j], M.root_state[j], M.root_ex[j], M.words[j], M.obytes[j], action, 1, env_key, bj, lane, blob0, blob1,
-                                    rew, term, &M.task[j], a.net.l1q_mode);
+                                    rew, term, &M.task[j], a.net.l1q_mode, &M.l1var[j]);
                     }
                     j = env_at(claim());
                 }
@@ -1075,6 +1134,19 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             EAZ_QP_ARGS;
             EAZ_QP_FWD_LANES;
             const int n1 = a.net.l1q_halves;  // half-rounds of layer 1: 7 (224 packed inputs) or 5 (144 + 16 zero rows), sq16_l1_halves
+            const int l1_mode = a.net.l1q_mode;
+            // layer-1 mode 1: where the chains of this lane's four rows start (the task's vector, or the root blob's for a state that carries its rows)
+            const float* l1src[4];
+            floatx4 accn[4];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = 4 * fkq + reg;
+                const int task = M.task[row];
+                const int branch = task - 1 < 0 ? 0 : (task - 1 > 5 ? 5 : task - 1);
+                l1src[reg] = (M.l1var[row] ? a.l1init + kQpL1Tab + static_cast<long>(b0 + row) * (3 * kFcH) : a.l1init + branch * (3 * kFcH)) + fcol;
+                accn[reg] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (l1_mode == 1) accn[reg] = *reinterpret_cast<const floatx4*>(l1src[reg]);  // head 0
+            }
             __amdgpu_buffer_rsrc_t W1r[3], W2r[3];
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
@@ -1106,6 +1178,14 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 floatx4 acc[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (l1_mode == 1) {
+                    // the chains of row 4 kq + reg start from the partial sum over the row's constant inputs (qp_l1_chain), requested a head ago
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[c][reg] = accn[reg][c];
+                    }
+                }
                 floatx4 a3 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
                 // ---- layer 1: [16 x 32 n1] x [32 n1 x 256] on the packed inputs (sq16_l1_src); half-round e refills its registers for half-round
                 // e + 2 of the head's sequence L1_0 .. L1_(n1-1), L2_0 .. L2_7; the first two carry the quarter chain of the head before ----
@@ -1116,7 +1196,6 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 }
                 if (h > 0) qp_half_ph<1, true>(P, acc, Bq, av, nullptr, xcur, xnext, W1r[h], fvoff, 2 * kHalfBytes, a3, hpA, w3v);
                 else qp_half_ph<0, true>(P, acc, Bq, av, nullptr, xcur, xnext, W1r[h], fvoff, 2 * kHalfBytes, a3, hpA, w3v);
-                EAZ_QRSTAMP(h * 16);
                 xcur = xnext; xnext = xrow(2);
                 if (h > 0) qp_half_ph<2, true>(P ^ 1, acc, Bq, av, nullptr, xcur, xnext, W1r[h], fvoff, 3 * kHalfBytes, a3, hpA, w3v);
                 else qp_half_ph<0, true>(P ^ 1, acc, Bq, av, nullptr, xcur, xnext, W1r[h], fvoff, 3 * kHalfBytes, a3, hpA, w3v);
@@ -1130,18 +1209,24 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
 #pragma unroll
                     for (int qq = 0; qq < 16; ++qq) w3v[qq] = pwp[4 * qq * kQpA];
                 }
+                // n1 is odd: pairs (2, 3), (4, 5), ... then the single half-round n1 - 1.  The last pair is peeled: inside the loop every refill is
+                // the same head's W1 at a running offset (scalar work per iteration: two adds; the selects of a generic body sat outside the
+                // MFMAs' shadow behind the sched_barriers and cost ~100 clocks per iteration)
 #pragma unroll 1
-                for (int j = 2; j + 1 < n1; j += 2) {  // n1 is odd: pairs (2, 3), (4, 5), ... then the single half-round n1 - 1
+                for (int j = 2; j + 3 < n1; j += 2) {
                     xcur = xnext; xnext = xrow(j + 1);
                     qp_half_ph<0, true>(P, acc, Bq, av, nullptr, xcur, xnext, W1r[h], fvoff, (j + 2) * kHalfBytes, a3, hpA, w3v);
-                    EAZ_QRSTAMP(h * 16 + j);
                     xcur = xnext; xnext = xrow(j + 2);
-                    const bool same = j + 3 < n1;  // otherwise: the first half-round of layer 2
-                    qp_half_ph<0, true>(P ^ 1, acc, Bq, av, nullptr, xcur, xnext, same ? W1r[h] : W2r[h], fvoff, same ? (j + 3) * kHalfBytes : 0, a3, hpA, w3v);
+                    qp_half_ph<0, true>(P ^ 1, acc, Bq, av, nullptr, xcur, xnext, W1r[h], fvoff, (j + 3) * kHalfBytes, a3, hpA, w3v);
                     EAZ_QRSTAMP(h * 16 + j + 1);
                 }
+                xcur = xnext; xnext = xrow(n1 - 2);
+                qp_half_ph<0, true>(P, acc, Bq, av, nullptr, xcur, xnext, W1r[h], fvoff, (n1 - 1) * kHalfBytes, a3, hpA, w3v);  // half-round n1 - 3 -> n1 - 1
+                xcur = xnext; xnext = xrow(n1 - 1);
+                qp_half_ph<0, true>(P ^ 1, acc, Bq, av, nullptr, xcur, xnext, W2r[h], fvoff, 0, a3, hpA, w3v);                   // n1 - 2 -> layer 2, half-round 0
+                EAZ_QRSTAMP(h * 16 + n1 - 2);
                 xcur = xnext;  // (the last half-round converts nothing of `abits_next` that is used: layer 2 refills the ring)
-                qp_half_ph<0, true>(P, acc, Bq, av, nullptr, xcur, xcur, W2r[h], fvoff, kHalfBytes, a3, hpA, w3v);
+                qp_half_ph<0, true>(P, acc, Bq, av, nullptr, xcur, xcur, W2r[h], fvoff, kHalfBytes, a3, hpA, w3v);               // n1 - 1 -> layer 2, half-round 1
                 EAZ_QRSTAMP(h * 16 + n1 - 1);
                 EAZ_QWSTAMP(1 + 2 * h);
                 {
@@ -1159,6 +1244,10 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                     }
                 }
                 __syncthreads();  // H1 of head h
+                if (l1_mode == 1 && h < 2) {  // the next head's chain starts: in flight during layer 2
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) accn[reg] = *reinterpret_cast<const floatx4*>(l1src[reg] + (h + 1) * kFcH);
+                }
                 // ---- layer 2: [16 x 256] x [256 x 256], half-rounds in phases P ^ 1, P, ...; the refills of the last two are the first two
                 // half-rounds of the next head (third head: of the next forward, whose first phase is 0 again -- the skipped phase) ----
                 floatx4 acc2[4];
@@ -1167,17 +1256,18 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                 const float* Ap = H1 + (h & 1) * kF16HFloats + fkq * 16 + fr;  // h16_off(4 ks + kq, r) = 68 ks + 16 kq + r
 #pragma unroll
                 for (int i = 0; i < kPsARing; ++i) av[i] = Ap[i * 68];
+                // reads past k-step 63 land in the next tile and are never used
 #pragma unroll 1
-                for (int j = 0; j < 8; j += 2) {
-                    const bool same = j + 2 < 8;
-                    // reads past k-step 63 land in the next tile and are never used
-                    qp_half_ph<0, false>(P ^ 1, acc2, Bq, av, Ap + (j * kQpHalf + kPsARing) * 68, uint2{}, uint2{}, same ? W2r[h] : W1r[hn], fvoff,
-                                         same ? (j + 2) * kHalfBytes : (h == 2 ? kHalfBytes : 0), a3, hpA, w3v);
-                    EAZ_QRSTAMP(h * 16 + 8 + j);
-                    qp_half_ph<0, false>(P, acc2, Bq, av, Ap + ((j + 1) * kQpHalf + kPsARing) * 68, uint2{}, uint2{}, same ? W2r[h] : W1r[hn], fvoff,
-                                         same ? (j + 3) * kHalfBytes : (h == 2 ? 0 : kHalfBytes), a3, hpA, w3v);
+                for (int j = 0; j < 6; j += 2) {
+                    qp_half_ph<0, false>(P ^ 1, acc2, Bq, av, Ap + (j * kQpHalf + kPsARing) * 68, uint2{}, uint2{}, W2r[h], fvoff, (j + 2) * kHalfBytes, a3, hpA, w3v);
+                    qp_half_ph<0, false>(P, acc2, Bq, av, Ap + ((j + 1) * kQpHalf + kPsARing) * 68, uint2{}, uint2{}, W2r[h], fvoff, (j + 3) * kHalfBytes, a3, hpA, w3v);
                     EAZ_QRSTAMP(h * 16 + 9 + j);
                 }
+                // the last pair refills for the first two half-rounds of the next head; after the third head the next forward starts in
+                // phase 0 again (one phase is skipped), so its two targets swap
+                qp_half_ph<0, false>(P ^ 1, acc2, Bq, av, Ap + (6 * kQpHalf + kPsARing) * 68, uint2{}, uint2{}, W1r[hn], fvoff, h == 2 ? kHalfBytes : 0, a3, hpA, w3v);
+                qp_half_ph<0, false>(P, acc2, Bq, av, Ap + (7 * kQpHalf + kPsARing) * 68, uint2{}, uint2{}, W1r[hn], fvoff, h == 2 ? 0 : kHalfBytes, a3, hpA, w3v);
+                EAZ_QRSTAMP(h * 16 + 15);
                 EAZ_QWSTAMP(2 + 2 * h);
                 const floatx4 bb2 = *reinterpret_cast<const floatx4*>(&M.b12[h][1][fcol]);
 #pragma unroll

@@ -196,8 +196,10 @@ class FCNet:
     hash_module = HASH_MODULE  # haiku module path of the novelty set inside model_state
 
     def __init__(self, ctx: Context, in_dim: int, hidden: int, num_actions: int, params, state=None, max_ube: float = 1.0,
-                 max_epistemic_variance_reward: float = 1.0, hash_off: int = 0, hash_len: Optional[int] = None, hash_bits: int = 24):
+                 max_epistemic_variance_reward: float = 1.0, hash_off: int = 0, hash_len: Optional[int] = None, hash_bits: int = 24,
+                 input_order=None):
         self.ctx, self.in_dim, self.hidden, self.num_actions = ctx, in_dim, hidden, num_actions
+        self.input_order = None
         self.hash_bits = hash_bits
         hash_len = in_dim - hash_off if hash_len is None else hash_len
         wl = fc_weight_list(params)
@@ -212,6 +214,18 @@ class FCNet:
         self.state_fp = fingerprint([np.zeros(1 << (hash_bits - 3), np.uint8)])
         if state is not None:
             self.set_state(state)
+        if input_order:
+            self.set_input_order(input_order)
+
+    def set_input_order(self, segments):
+        """Layer-1 input order (include/eaz.h eaz_net_set_input_order; a switch of the numerics contract that the test oracle follows):
+        `segments` = [(start, len), ...] whose concatenation is a permutation of range(in_dim), e.g. params.subleq_constants_first(16);
+        None / [] restores the k-ascending default."""
+        segments = [(int(a), int(b)) for a, b in (segments or [])]
+        st = np.ascontiguousarray([a for a, _ in segments], np.int32)
+        ln = np.ascontiguousarray([b for _, b in segments], np.int32)
+        check(_lib.load().eaz_net_set_input_order(self.h, len(segments), st.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p), _stream()))
+        self.input_order = segments or None
 
     def set_params(self, params):
         wl = fc_weight_list(params)
@@ -377,6 +391,10 @@ class Search:
 
     def run(self):
         check(_lib.load().eaz_search_run(self.h, _stream()))
+
+    def debug_poison(self, byte_value: int = 0x7F):
+        """Test hook (include/eaz.h eaz_search_debug_poison): fill the select scratch arrays with a byte pattern."""
+        check(_lib.load().eaz_search_debug_poison(self.h, byte_value, _stream()))
 
     def launch_info(self) -> dict:
         """one_launch: selfplay() / run() are ONE kernel launch on LDS-resident trees for this search under the current tuning; lds_bytes of it."""

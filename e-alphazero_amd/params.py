@@ -72,6 +72,16 @@ def init_simhash_state(hash_len: int, bits_per_hash: int = 24, fill: float = 0.0
     return {module: {"binary_set": bs, "random_matrix": rm}}
 
 
+def subleq_constants_first(word_size: int, use_binary_encoding: bool = True):
+    """Layer-1 input order "constants first" for a Subleq observation (engine.FCNet(input_order=...), OracleNet.set_input_order): the
+    observation is memory | example_input | input_after | example_output | output_after (src/envs/subleq.py:697-705), each row-word
+    `cols` inputs wide (:59-60); example_input / example_output are constants of an episode (:398-501), so they go first:
+    [(start, len), ...] = example_input, example_output, memory, input_after, output_after."""
+    cols = (word_size - 1).bit_length() + 1 if use_binary_encoding else word_size + 1
+    mem, row = word_size * cols, 8 * cols
+    return [(mem, row), (mem + 2 * row, row), (0, mem), (mem + row, row), (mem + 3 * row, row)]
+
+
 def fc_weight_list(params):
     """[(w, b)] * 12 in haiku creation order."""
     return [(np.asarray(params[fc_layer_name(i)]["w"], np.float32), np.asarray(params[fc_layer_name(i)]["b"], np.float32))

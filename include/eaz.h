@@ -137,6 +137,16 @@ EAZ_API int eaz_net_create_resnet(eaz_ctx* ctx, int H, int W, int Cin, int num_c
 EAZ_API int eaz_net_destroy(eaz_net* net);
 /* replace weights (after a learner update) -- same layout as eaz_net_create_fc */
 EAZ_API int eaz_net_set_weights(eaz_net* net, const float* const* h_w, const float* const* h_b, void* stream);
+/* Layer-1 INPUT ORDER of an FC network -- a switch of this library's numerics contract, no reference counterpart (XLA leaves the order of a
+ * dot unspecified; forward.apply of src/network/fully_connected.py:45-81 is what is computed either way).  hk.Linear is evaluated as one
+ * fmaf chain per output, acc = +0; acc = fmaf(x[k], w[k][j], acc); y = acc + b[j], over the inputs k ascending by default.  With an order
+ * -- n_seg segments (seg_start[i], seg_len[i]) whose concatenation is a permutation of [0, in_dim) -- the chain visits the inputs in that
+ * order instead; every kernel and the test oracle (eazo_net_set_input_order) follow, results differ from the default in the last bits only
+ * (<= 1e-6 on the reference's networks).  Subleq uses {example_input, example_output, memory, input_after, output_after}: the example rows
+ * are constants of an episode (src/envs/subleq.py:398-501,697-705), so the one-launch kernel starts every chain of a tree from one
+ * precomputed partial sum and layer 1 runs over 144 instead of 240 inputs.  n_seg = 0 restores the default.  Not for one-hot (DeepSea)
+ * observations.  Synchronises `stream`. */
+EAZ_API int eaz_net_set_input_order(eaz_net* net, int n_seg, const int32_t* seg_start, const int32_t* seg_len, void* stream);
 /* the same for a residual network: h_arrays as in eaz_net_create_resnet (same architecture).  The packed device buffer is rewritten in place
  * (same addresses and offsets), so searches and captured graphs that use this network see the new weights.  Synchronous. */
 EAZ_API int eaz_net_set_resnet_weights(eaz_net* net, const float* const* h_arrays, int n_arrays, void* stream);
@@ -220,6 +230,11 @@ enum {
 /* device pointer + shape ([B,N], [B,N,A], [B,N,state_bytes], [B,A] or [B]; unused dims = 0) + element size */
 EAZ_API int eaz_search_tree_view(eaz_search* s, int field_id, void** d_ptr, int64_t shape[3], int* elem_bytes);
 
+/* TEST HOOK (no reference counterpart): fills the search's select scratch (the recorded root-to-leaf paths, their lengths, the
+ * selected (parent, action, next) triples) with `byte_value` -- the content a freed allocation may leave behind.  Between eaz_search_begin
+ * and eaz_search_run it reproduces the precondition of round 3's 257-second launch (a lane group beyond a ragged batch read another
+ * workgroup's path length before it was written): the search must finish in its normal time with unchanged results. */
+EAZ_API int eaz_search_debug_poison(eaz_search* s, int byte_value, void* stream);
 /* Launch structure the library will use for this search under the current tuning (EAZ_TUNE_PERSIST): *one_launch = 1 when eaz_selfplay_run
  * (the whole call) and eaz_search_run (all simulations) each run as ONE kernel launch on LDS-resident trees -- DeepSea + FC network with two
  * actions (csrc/search_persist.hpp) or Subleq word_size 16, binary observations, FC network, XXHash novelty over the IO rows

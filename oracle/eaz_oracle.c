@@ -667,6 +667,8 @@ typedef struct ONet {
     int hash_off, hash_len, hash_bits;
     const uint8_t* bitset; /* 2^(bits-3) bytes, caller-owned */
     const float* sim_matrix; /* non-NULL: hash_class = SimHash with this [hash_len, hash_bits] random matrix (caller-owned); NULL: XXHash */
+    int* order;      /* non-NULL: layer-1 input order, a permutation of [0, in_dim) (eazo_net_set_input_order) */
+    float* w1p[4];   /* the heads' layer-1 weights with their rows in that order */
 } ONet;
 
 /* hash_obj.get_indices(hash_input) of the configured hash class (config.py:27, context.py:42-49) */
@@ -699,9 +701,41 @@ EXPORT void eazo_net_free(ONet* n) {
     if (!n) return;
     if (n->resnet) { o_resnet_free(n->resnet); free(n); return; }
     for (int l = 0; l < 12; ++l) { free(n->w[l]); free(n->b[l]); }
+    free(n->order);
+    for (int h = 0; h < 4; ++h) free(n->w1p[h]);
     free(n);
 }
 EXPORT void eazo_net_set_bitset(ONet* n, const uint8_t* bitset) { n->bitset = bitset; }
+
+/* Layer-1 INPUT ORDER (a switch of the build's numerics contract; no reference counterpart: XLA leaves the order of a dot
+ * unspecified).  By default the layer-1 chain of o_linear visits the inputs k ascending.  With an order -- n_seg segments (start, len) whose
+ * concatenation is a permutation of [0, in_dim) -- the chain visits the inputs in that order instead: acc = +0; for s in segments: for k in
+ * start_s .. start_s + len_s - 1: acc = fmaf(x[k], w[k][j], acc); y = acc + b[j].  Subleq uses it to put the inputs that are constants of
+ * an episode (the example_input / example_output rows, subleq.py:398-501,697-705) first, so that a device kernel may start every chain of a
+ * tree from one precomputed partial sum.  Returns 0, or -1 if the segments are not a permutation.  n_seg == 0 restores the default. */
+EXPORT int eazo_net_set_input_order(ONet* n, int n_seg, const int32_t* start, const int32_t* len) {
+    if (n->resnet) return -1;
+    free(n->order); n->order = NULL;
+    for (int h = 0; h < 4; ++h) { free(n->w1p[h]); n->w1p[h] = NULL; }
+    if (n_seg == 0) return 0;
+    const int K = n->in_dim, H = n->H;
+    int* ord = (int*)malloc((size_t)K * sizeof(int));
+    uint8_t* seen = (uint8_t*)calloc((size_t)K, 1);
+    int pos = 0, ok = 1;
+    for (int s = 0; s < n_seg && ok; ++s)
+        for (int k = start[s]; k < start[s] + len[s]; ++k) {
+            if (k < 0 || k >= K || seen[k] || pos >= K) { ok = 0; break; }
+            seen[k] = 1; ord[pos++] = k;
+        }
+    free(seen);
+    if (!ok || pos != K) { free(ord); return -1; }
+    n->order = ord;
+    for (int h = 0; h < 4; ++h) {
+        n->w1p[h] = (float*)malloc((size_t)K * H * sizeof(float));
+        for (int kp = 0; kp < K; ++kp) memcpy(n->w1p[h] + (size_t)kp * H, n->w[h * 3] + (size_t)ord[kp] * H, (size_t)H * sizeof(float));
+    }
+    return 0;
+}
 
 /* hk.Linear: y = x @ w + b.  Spec of the build: acc = +0; acc = fmaf(x[k], w[k][j], acc) for k ascending; y = acc + b[j].
  * (This is exactly what one chain of gfx950 f32 MFMA accumulation computes.)  Rows are blocked by 4 so the j loop vectorises.
@@ -755,11 +789,16 @@ EXPORT void eazo_net_forward(const ONet* n, int B, const uint8_t* obs, float* ex
     float* h1 = (float*)malloc((size_t)B * H * sizeof(float));
     float* h2 = (float*)malloc((size_t)B * H * sizeof(float));
     float* o = (float*)malloc((size_t)B * (A > 1 ? A : 1) * sizeof(float));
-    for (size_t i = 0; i < (size_t)B * K; ++i) x[i] = (float)obs[i]; /* :45 astype(float32) */
+    if (n->order) {  /* the layer-1 chain visits the inputs in the configured order (eazo_net_set_input_order): same products, same bias */
+        for (int b = 0; b < B; ++b)
+            for (int kp = 0; kp < K; ++kp) x[(size_t)b * K + kp] = (float)obs[(size_t)b * K + n->order[kp]];
+    } else {
+        for (size_t i = 0; i < (size_t)B * K; ++i) x[i] = (float)obs[i]; /* :45 astype(float32) */
+    }
     for (int head = 0; head < 4; ++head) {
         const int l = head * 3;
         const int No = o_layer_out(n, l + 2);
-        o_linear(B, K, H, x, n->w[l], n->b[l], h1, 1);
+        o_linear(B, K, H, x, n->order ? n->w1p[head] : n->w[l], n->b[l], h1, 1);
         o_linear(B, H, H, h1, n->w[l + 1], n->b[l + 1], h2, 1);
         o_linear_parts(B, H, No, h2, n->w[l + 2], n->b[l + 2], o, 0, 4);  /* four partial chains, see o_linear_parts */
         if (head == 0) { for (int b = 0; b < B; ++b) v[b] = o_tanhf(o[b]); }                       /* :50-56 */

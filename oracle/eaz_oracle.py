@@ -68,6 +68,7 @@ def lib():
             "eazo_xxhash_indices": (None, [vp, i32, i32, i32, vp]),
             "eazo_simhash_indices": (None, [vp, i32, i32, i32, vp, vp]),
             "eazo_net_set_simhash": (None, [vp, vp]),
+            "eazo_net_set_input_order": (i32, [vp, i32, vp, vp]),
             "eazo_hash_update": (None, [vp, vp, i32]),
             "eazo_hash_seen": (None, [vp, vp, i32, vp]),
             "eazo_xxh_round": (u32, [u32, u32]),
@@ -227,6 +228,15 @@ class OracleNet:
     def set_bitset(self, bitset):
         self.bitset = bitset
         lib().eazo_net_set_bitset(self.h, _p(bitset))
+
+    def set_input_order(self, segments):
+        """Layer-1 input order (numerics-contract switch, eaz_oracle.c eazo_net_set_input_order): `segments` = [(start, len), ...] whose
+        concatenation is a permutation of range(in_dim); None / [] restores the k-ascending default."""
+        segments = list(segments or [])
+        st = np.ascontiguousarray([s for s, _ in segments], np.int32)
+        ln = np.ascontiguousarray([n for _, n in segments], np.int32)
+        if lib().eazo_net_set_input_order(self.h, len(segments), _p(st), _p(ln)) != 0:
+            raise ValueError("input order: the segments are not a permutation of the inputs")
 
     def set_simhash(self, random_matrix):
         """hash_class = SimHash (hashes.py:100-139) with this [hash_len, bits_per_hash] random matrix instead of XXHash."""

@@ -34,13 +34,16 @@ CASES = {
     # from a terminated root and auto-reset (selfplay.py:26-75,135) inside the window
     "c3r_subleq16": ("subleq", 16, 24, 32, 16, 3, 0.25, {}),
     "c3b_subleq16_beta": ("subleq", 16, 24, 32, 16, 4, 0.25, dict(directed_exploration=True, exploration_beta=1.0)),
+    # the same under the numerics switch "layer-1 constants first" (include/eaz.h eaz_net_set_input_order, oracle eazo_net_set_input_order):
+    # every kernel variant has to follow the order, the one-launch kernel starts its layer-1 chains from per-tree partial sums
+    "c3k_subleq16_constants_first": ("subleq", 16, 24, 32, 16, 6, 0.25, dict(directed_exploration=True, exploration_beta=1.0, constants_first=True)),
     # configs[3] reduced: connect_four, two-player discount, residual network with `size` blocks; T = 26: 10 of the 12 games end (win or
     # full column -> illegal move) and restart inside the window
     "c4r_connect4": ("connect4", 1, 12, 16, 26, 5, 0.3, dict(two_player=True)),
 }
 
 
-def build(kind, size, seed, fill):
+def build(kind, size, seed, fill, constants_first=False):
     if kind == "deepsea":
         am, params, state = deepsea_setup(eaz, size, seed=seed, fill=fill)
         env, net = oracle_deepsea(O, eaz, size, am, params, state)
@@ -55,12 +58,15 @@ def build(kind, size, seed, fill):
     env = O.OracleEnv.subleq(size, (1,), True)
     net = O.OracleNet(dims["in_dim"], 256, size, eaz.params.fc_weight_list(params), hash_off=dims["hash_off"],
                       hash_len=dims["hash_len"], bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+    if constants_first:
+        net.set_input_order(eaz.params.subleq_constants_first(size, True))
     return env, net, 0.97  # config.py:122 discount for subleq
 
 
 def main():
     for name, (kind, size, B, S, T, seed, fill, flags) in CASES.items():
-        env, net, discount = build(kind, size, seed, fill)
+        flags = dict(flags)
+        env, net, discount = build(kind, size, seed, fill, flags.pop("constants_first", False))
         st = env.init(B, key=(seed, 0))
         out = O.selfplay(env, net, st, T=T, S=S, key=(1000 + seed, 0), discount=discount, **flags)
         # one extra search from the final states with a full tree dump

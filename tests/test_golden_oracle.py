@@ -21,7 +21,8 @@ def test_all_cases_have_fixtures():
 def test_oracle_reproduces_golden(oracle, name):
     kind, size, B, S, T, seed, fill, flags = MG.CASES[name]
     z = np.load(os.path.join(HERE, "golden", f"{name}.npz"))
-    env, net, discount = MG.build(kind, size, seed, fill)
+    flags = dict(flags)
+    env, net, discount = MG.build(kind, size, seed, fill, flags.pop("constants_first", False))
     st = env.init(B, key=(seed, 0))
     out = oracle.selfplay(env, net, st, T=T, S=S, key=(1000 + seed, 0), discount=discount, **flags)
     for k, v in out.items():

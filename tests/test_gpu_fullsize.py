@@ -100,21 +100,27 @@ def test_c2_tree_invariants_on_every_tree(oracle, eaz, torch):
     assert (vc[np.arange(B), act.cpu().numpy()] == vc.max(1)).all()
 
 
-@pytest.mark.parametrize("flags", [{}, dict(directed_exploration=True, exploration_beta=1.0)], ids=["beta0", "beta1"])
-def test_c3_selfplay_subset_matches_oracle(oracle, eaz, torch, flags):
+@pytest.mark.parametrize("flags,constants_first,full_obs_hash", [({}, False, False), (dict(directed_exploration=True, exploration_beta=1.0), False, False),
+                                                                 (dict(directed_exploration=True, exploration_beta=1.0), True, False), ({}, True, False),
+                                                                 ({}, False, True)],
+                         ids=["beta0", "beta1", "beta1-constants-first", "beta0-constants-first", "beta0-full-obs-hash"])
+def test_c3_selfplay_subset_matches_oracle(oracle, eaz, torch, flags, constants_first, full_obs_hash):
     """T = 16 real steps: Subleq-16 episodes end at _step_count >= 13 (subleq.py:671-673), so the window holds searches from terminated roots
     and the auto-reset inside selfplay for every environment; beta1 = the reference's experiment setting (directed exploration, beta = 1,
     slurm_experiment_submitter.py:203,209) at full size."""
     from e_alphazero_amd import engine
 
     W, B, S, T, NSUB = 16, 4096, 64, 16, 16
-    dims, params, state = subleq_setup(eaz, W, seed=0, fill=0.5)
+    dims, params, state = subleq_setup(eaz, W, seed=0, fill=0.5, hash_io=not full_obs_hash)  # full_obs_hash: subleq_hash_only_io = False (config.py:30)
     env = engine.EnvHandle.subleq(W, (1,), True, device=0)
-    net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
+    order = eaz.params.subleq_constants_first(W, True) if constants_first else None  # the numerics switch of include/eaz.h eaz_net_set_input_order
+    net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"], input_order=order)
     oenv = oracle.OracleEnv.subleq(W, (1,), True)
     onet = oracle.OracleNet(dims["in_dim"], 256, W, eaz.params.fc_weight_list(params), hash_off=dims["hash_off"],
                             hash_len=dims["hash_len"], bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+    onet.set_input_order(order)
     search = engine.Search(env, net, B, S, discount=0.97, exploration=bool(flags))
+    assert search.launch_info()["one_launch"], "C3 is expected on the one-launch kernel (both layer-1 input orders)"
     gum = oracle.gumbel((3, 4), T * B * W).reshape(T, B, W)
     st = env.init(B, key=0)
     out = search.selfplay(st, T, key=23, gumbel=torch.from_numpy(gum).cuda(), **flags)

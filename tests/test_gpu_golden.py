@@ -22,7 +22,7 @@ def torch():
     return t
 
 
-def _build_engine(eaz, kind, size, seed, fill):
+def _build_engine(eaz, kind, size, seed, fill, constants_first=False):
     from e_alphazero_amd import engine
 
     if kind == "deepsea":
@@ -37,7 +37,8 @@ def _build_engine(eaz, kind, size, seed, fill):
         return engine, env, engine.ResNet(env.ctx, 6, 7, 2, 7, params, state, num_blocks=size), 0.997
     dims, params, state = subleq_setup(eaz, size, seed=seed, fill=fill)
     env = engine.EnvHandle.subleq(size, (1,), True, device=0)
-    net = engine.FCNet(env.ctx, dims["in_dim"], 256, size, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
+    net = engine.FCNet(env.ctx, dims["in_dim"], 256, size, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"],
+                       input_order=eaz.params.subleq_constants_first(size, True) if constants_first else None)
     return engine, env, net, 0.97
 
 
@@ -50,9 +51,9 @@ def _to_oracle_states(kind, size, dev_states):
 def test_selfplay_and_tree_match_golden(eaz, torch, name):
     kind, size, B, S, T, seed, fill, flags = MG.CASES[name]
     z = np.load(os.path.join(HERE, "golden", f"{name}.npz"))
-    engine, env, net, discount = _build_engine(eaz, kind, size, seed, fill)
-    explore = bool(flags.get("directed_exploration", False))
     flags = dict(flags)
+    engine, env, net, discount = _build_engine(eaz, kind, size, seed, fill, flags.pop("constants_first", False))
+    explore = bool(flags.get("directed_exploration", False))
     two_player = bool(flags.pop("two_player", False))
     search = engine.Search(env, net, B, S, discount=discount, exploration=explore, two_players_game=two_player)
     st = env.init(B, key=seed)
@@ -166,25 +167,33 @@ def test_wide_action_sets_selfplay_matches_oracle(oracle, eaz, torch, W, B, S):
 
 
 @pytest.mark.parametrize("flags", [{}, dict(directed_exploration=True, exploration_beta=1.0), dict(sample_actions=True),
-                                   dict(sample_from_improved_policy=True, uniform_search_policy=True)])
+                                   dict(sample_from_improved_policy=True, uniform_search_policy=True),
+                                   dict(full_obs_hash=True), dict(full_obs_hash=True, constants_first=True, directed_exploration=True, exploration_beta=1.0)],
+                         ids=["default", "beta1", "sample-visits", "sample-improved-uniform", "full-obs-hash", "full-obs-hash-constants-first-beta1"])
 def test_subleq16_selfplay_crosses_episode_boundaries(oracle, eaz, torch, flags, kernel_variant):
     """Subleq-16 self-play over more real steps than an episode has (episodes end at _step_count >= 13, subleq.py:671-673): searches from
     terminated roots, the auto-reset inside selfplay (selfplay.py:26-75,135) with a task drawn per reset (subleq.py:624), a ragged batch
     (40 = 2.5 workgroups of the one-launch kernel), every action-choice flag.  Generated Gumbel noise (the engine's key derivation)."""
     from e_alphazero_amd import engine
 
-    if kernel_variant in ("tile16-unfused", "tile64-sharded") and flags:
+    flags = dict(flags)
+    full_obs_hash, constants_first = flags.pop("full_obs_hash", False), flags.pop("constants_first", False)
+    if kernel_variant in ("tile16-unfused", "tile64-sharded") and flags and not full_obs_hash:
         pytest.skip("the per-simulation variants run this window once (default flags); the golden c3r / c3b cases cover them at T = 16 as well")
     W, B, S, T = 16, 40, 24, 17
     tasks = (1, 2, 3)
-    dims, params, state = subleq_setup(eaz, W, seed=11, fill=0.4)
+    # full_obs_hash: subleq_hash_only_io = False (config.py:30, fully_connected.py:84-89), the reference's "E-AZ (full-obs hash)" curve
+    dims, params, state = subleq_setup(eaz, W, seed=11, fill=0.4, hash_io=not full_obs_hash)
+    order = eaz.params.subleq_constants_first(W, True) if constants_first else None
     env = engine.EnvHandle.subleq(W, tasks, True, device=0)
-    net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
+    net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"], input_order=order)
     oenv = oracle.OracleEnv.subleq(W, tasks, True)
     onet = oracle.OracleNet(dims["in_dim"], 256, W, eaz.params.fc_weight_list(params), hash_off=dims["hash_off"],
                             hash_len=dims["hash_len"], bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+    onet.set_input_order(order)
     explore = bool(flags.get("directed_exploration", False))
     search = engine.Search(env, net, B, S, discount=0.97, exploration=explore)
+    assert search.launch_info()["one_launch"] == (kernel_variant == "persist"), "Subleq-16 self-play runs as ONE launch for both hash slices and both layer-1 input orders"
     st = env.init(B, key=13)
     ost = oenv.init(B, key=(13, 0))
     assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost)
@@ -273,6 +282,107 @@ def test_subleq16_one_launch_selfplay_edges(oracle, eaz, torch, case, kernel_var
     assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost)
     for k in ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction", "q_values_epistemic_variance"):
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
+
+
+def test_subleq16_states_beyond_the_compact_form_take_the_per_simulation_path(oracle, eaz, torch, kernel_variant):
+    """The one-launch Subleq-16 kernel keeps a state as 32 bytes (4-bit program words, IO values as bytes with 16 = "beyond the valid ones",
+    8-bit step count, 16-bit task).  Everything the environment produces fits; a caller's hand-made blob may not.  eaz_selfplay_run /
+    eaz_search_begin check the blobs a call starts from (sq16_roots_fit_kernel) and send a batch with a misfit to the per-simulation
+    kernels instead of truncating it: every variant, the default one included, gives the oracle's result."""
+    from e_alphazero_amd import engine
+    from helpers import DEVICE_SUBLEQ
+
+    W, B, S, T = 16, 20, 12, 3
+    dims, params, state = subleq_setup(eaz, W, seed=5, fill=0.4)
+    env = engine.EnvHandle.subleq(W, (1, 3), True, device=0)
+    net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
+    oenv = oracle.OracleEnv.subleq(W, (1, 3), True)
+    onet = oracle.OracleNet(dims["in_dim"], 256, W, eaz.params.fc_weight_list(params), hash_off=dims["hash_off"],
+                            hash_len=dims["hash_len"], bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+    ost, _ = oracle.random_play(oenv, B, 5, key=(21, 0))               # mid-episode states
+    d = subleq_oracle_to_device(ost).view(DEVICE_SUBLEQ).reshape(B).copy()
+    d["ex_in_after"][4, 2] = 40                                        # an IO value the byte-with-16-as-padding form cannot hold
+    d["task"][9] = 70000                                               # beyond 16 bits (get_test_cases clamps it to the last branch)
+    d["ex_out"][11, 5] = 300
+    ost = subleq_device_to_oracle(d.view(np.uint8).reshape(B, 336), W)
+    ost0 = ost.copy()                                                  # selfplay advances its states in place
+    st = torch.from_numpy(d.view(np.uint8).reshape(B, 336).copy()).cuda()
+    search = engine.Search(env, net, B, S, discount=0.97)
+    out = search.selfplay(st, T, key=91)
+    ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(91, 0), discount=0.97)
+    assert np.array_equal(out["action"].cpu().numpy(), ref["action"])
+    assert np.array_equal(subleq_device_to_oracle(out["state"].cpu().numpy(), W), ref["state"])
+    for k in ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction", "q_values_epistemic_variance"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
+    # the emctx call shape from the same roots: begin -> run -> finish
+    ex, xp, v, u, _ = onet.forward(oenv.observe(ost0))
+    g = oracle.gumbel((4, 4), B * W).reshape(B, W)
+    beta = np.zeros(B, np.float32)
+    act, aw, summ, tree = oracle.search(oenv, onet, ost0, S, ex, v, u, beta, g, discount=0.97)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    st2 = torch.from_numpy(d.view(np.uint8).reshape(B, 336).copy()).cuda()
+    search.begin(cu(ex), cu(v), cu(u), st2, cu(beta), None, cu(g))
+    search.run()
+    a2, aw2 = search.finish()
+    assert np.array_equal(a2.cpu().numpy(), act)
+    np.testing.assert_allclose(aw2.cpu().numpy(), aw, rtol=0, atol=ATOL)
+    dd, od = search.dump(), tree.dump()
+    for k in MG.TREE_INT:
+        assert np.array_equal(dd[k], od[k]), k
+
+
+@pytest.mark.parametrize("env_kind", ["subleq", "deepsea"])
+def test_poisoned_select_arrays_cost_neither_time_nor_results(oracle, eaz, torch, kernel_variant, env_kind):
+    """Regression for round 3's 257-second launch: in a one-launch search the lane groups beyond a ragged batch mirrored
+    tree 0 of ANOTHER workgroup and read its path length before it was written; a leftover 0x7F7F7F7F from a freed allocation made the
+    backward loop run 2^28 times (results correct, one launch of 257 s).  Here the select scratch is filled with exactly that pattern
+    between begin() and run() (eaz_search_debug_poison), on a ragged batch, for every kernel variant: the search has to finish in its
+    normal time AND agree with the oracle -- a depth clamp that merely masked a stale read would pass the second but not a future
+    regression of the first, so both are asserted."""
+    import time
+
+    from e_alphazero_amd import engine
+
+    if env_kind == "subleq":
+        W, B, S = 16, 37, 24   # 2 workgroups of 16 trees + 5: the last workgroup of the one-launch kernels has 11 mirror groups
+        dims, params, state = subleq_setup(eaz, W, seed=3, fill=0.4)
+        env = engine.EnvHandle.subleq(W, (1,), True, device=0)
+        net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
+        oenv = oracle.OracleEnv.subleq(W, (1,), True)
+        onet = oracle.OracleNet(dims["in_dim"], 256, W, eaz.params.fc_weight_list(params), hash_off=dims["hash_off"],
+                                hash_len=dims["hash_len"], bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+        A, to_dev = W, lambda o: torch.from_numpy(subleq_oracle_to_device(o)).cuda()
+    else:
+        G, B, S = 8, 37, 24
+        am, params, state = deepsea_setup(eaz, G, seed=3, fill=0.4)
+        env = engine.EnvHandle.deepsea(G, am, device=0)
+        net = engine.FCNet(env.ctx, G * G, 256, 2, params, state)
+        oenv = oracle.OracleEnv.deepsea(G, am)
+        onet = oracle.OracleNet(G * G, 256, 2, eaz.params.fc_weight_list(params), bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+        A, to_dev = 2, lambda o: torch.from_numpy(o).cuda()
+    ost, _ = oracle.random_play(oenv, B, 4, key=(31, 0))
+    ex, xp, v, u, _ = onet.forward(oenv.observe(ost))
+    g = oracle.gumbel((5, 5), B * A).reshape(B, A)
+    beta = np.zeros(B, np.float32)
+    act, aw, summ, tree = oracle.search(oenv, onet, ost, S, ex, v, u, beta, g, discount=0.97)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    search = engine.Search(env, net, B, S, discount=0.97)
+    st = to_dev(ost)
+    for rep in range(2):   # the second round runs on arrays the first one used
+        search.begin(cu(ex), cu(v), cu(u), st, cu(beta), None, cu(g))
+        search.debug_poison(0x7F)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        search.run()
+        a2, aw2 = search.finish()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert dt < 5.0, f"the search took {dt:.1f} s: a stale select array is being trusted again"
+        assert np.array_equal(a2.cpu().numpy(), act)
+        np.testing.assert_allclose(aw2.cpu().numpy(), aw, rtol=0, atol=ATOL)
+        dd, od = search.dump(), tree.dump()
+        for k in MG.TREE_INT:
+            assert np.array_equal(dd[k], od[k]), k
 
 
 def test_empty_batches_are_no_ops(eaz, torch):
@@ -488,6 +598,46 @@ def test_connect4_evaluate_matches_oracle(oracle, eaz, torch):
 
 
 # ---- weight refresh: the facade must never search on stale weights (the reference re-applies model_params on every call) --------
+@pytest.mark.parametrize("W,binary,B", [(16, True, 200), (32, True, 70), (256, True, 40), (16, False, 33)])
+def test_fc_forward_follows_the_layer1_input_order(oracle, eaz, torch, W, binary, B):
+    """The numerics switch eaz_net_set_input_order (include/eaz.h) against the oracle's eazo_net_set_input_order: every forward kernel
+    (the variants of tests/conftest.py) computes the layer-1 chain in the configured order, bit for bit; a weight upload under an order
+    lands in the right rows; n_seg = 0 restores the ascending default; the results of the two orders differ in the last bits only."""
+    from e_alphazero_amd import engine
+
+    dims, params, state = subleq_setup(eaz, W, binary=binary, seed=W + 3, fill=0.5)
+    env = engine.EnvHandle.subleq(W, (1,), binary, device=0)
+    oenv = oracle.OracleEnv.subleq(W, (1,), binary)
+    order = eaz.params.subleq_constants_first(W, binary)
+    net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"], input_order=order)
+    onet = oracle.OracleNet(dims["in_dim"], 256, W, eaz.params.fc_weight_list(params), hash_off=dims["hash_off"],
+                            hash_len=dims["hash_len"], bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+    ost, _ = oracle.random_play(oenv, B, 9, key=(W, 2))
+    obs = oenv.observe(ost)
+    dobs = torch.from_numpy(obs).cuda()
+    ref_default = onet.forward(obs)
+    onet.set_input_order(order)
+    ref = onet.forward(obs)
+    out = net.forward(dobs)
+    assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(out, ref)), "the forward does not follow the configured input order"
+    assert any(not np.array_equal(a, b) for a, b in zip(ref[:3], ref_default[:3])), "the order changed no bit: the test lost its point"
+    for a, b in zip(ref, ref_default):
+        np.testing.assert_allclose(a, b, rtol=0, atol=ATOL)
+    # new weights under the order
+    params2 = eaz.params.init_fc_params(dims["in_dim"], 256, W, seed=W + 4)
+    net.set_params(params2)
+    onet2 = oracle.OracleNet(dims["in_dim"], 256, W, eaz.params.fc_weight_list(params2), hash_off=dims["hash_off"],
+                             hash_len=dims["hash_len"], bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+    onet2.set_input_order(order)
+    assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(net.forward(dobs), onet2.forward(obs))), "weight upload under an input order"
+    # back to the default
+    net.set_input_order(None)
+    onet2.set_input_order(None)
+    assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(net.forward(dobs), onet2.forward(obs))), "restoring the ascending order"
+    with pytest.raises(eaz.EazError, match="permutation"):
+        net.set_input_order([(0, 10), (5, dims["in_dim"] - 5)])
+
+
 def test_weights_mutated_in_place_reach_the_device_fc(oracle, eaz, torch):
     """api.selfplay with the SAME params dict whose arrays were overwritten in place (and with a replaced dict): the device copy is
     refreshed by content fingerprint, and the result equals the oracle on the new weights -- also through the captured step graph."""
