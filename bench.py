@@ -153,7 +153,8 @@ def build_workload(name, args, device, rank, beta=0.0):
         net_kernel, net_flops = "fc16p_forward_kernel" if W == 16 else "fc16_forward_kernel | fc_forward_kernel (by sub-batch size)", fc_flops_per_eval(in_dim, A, (0, 1, 2)) * B
         pmc_tag = f"Subleq-{W}, B={B}, {S} sims"
         gather_kernel = ("subleq16_tree_leaf_kernel (tree step + env step + observation row + novelty)" if W == 16 else
-                         "subleq_step_kernel + obs_emit_kernel")
+                         "subleq_tree_leaf_kernel (tree step + env step + observation row + novelty, one wavefront per tree)" if W >= 64 else
+                         "subleq_wave_kernel (env step + observation row + novelty)")
         w["metric"] = w["metric"].replace("Subleq-16", f"Subleq-{W}")
 
         def oracle(O):
@@ -171,7 +172,7 @@ def build_workload(name, args, device, rank, beta=0.0):
         desc = f"connect_four, batch={B}/GPU, {S} sims, {T} real steps per selfplay() call, ResNet 64ch x {nb} blocks, two-player (BASELINE.json configs[3])"
         data = "synthetic (random-init ResNet with synthetic BatchNorm statistics, empty novelty set)"
         net_kernel, net_flops = "resnet_forward_kernel", resnet_flops_per_eval(nb=nb, A=A) * B
-        pmc_tag, gather_kernel = None, "connect4_step_kernel + obs_emit_kernel"
+        pmc_tag, gather_kernel = None, "connect4_leaf_kernel (env.step on bitboards + child state + observation row + novelty lookup, one launch)"
 
         def oracle(O):
             oenv = O.OracleEnv.connect4()
@@ -396,7 +397,7 @@ def run_rank(args):
         #                tag              workload (steps, warmup, T)  beta  hash fill
         for tag, name, (xs, xw, xt), xbeta, xfill in (("c3", "c3", (3, 1, 0), 0.0, None), ("c3_beta1", "c3", (3, 1, 0), 1.0, None),
                                                       ("c3_ascending", "c3", (3, 1, 0), 0.0, None),
-                                                      ("c2_empty_set", "c2", (3, 1, 0), 0.0, 0.0), ("c4", "c4", (1, 1, 2), 0.0, None)):
+                                                      ("c2_empty_set", "c2", (3, 1, 0), 0.0, 0.0), ("c4", "c4", (1, 1, 8), 0.0, None)):
             xargs = argparse.Namespace(**vars(args))
             xargs.workload, xargs.selfplay_steps = name, xt
             if tag == "c3_ascending":   # the default numerics contract (k-ascending layer-1 chain): extra.c3 runs the constants-first switch
@@ -645,8 +646,10 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
         fields["roofline_gather"] = {"kernel": wl["gather_kernel"], "bound": "hbm", "achieved": gach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                      "frac": gach / PEAK_HBM_GBPS, "traffic": None, "avg_us_per_simulation": 1e3 * g_ms,
                                      "bytes_per_simulation": gbytes,
-                                     "note": "event pairs around the env-step (+ observation) launches of one simulation; interpreter / "
-                                             "launch-latency bound, not bandwidth bound (DESIGN.md 4.4)"}
+                                     "note": "event pairs around the leaf-step launch(es) of one simulation (env.step + child state + observation row + "
+                                             "novelty) against 2 x state + observation bytes per tree: a few hundred bytes per tree, i.e. 1-4 MB per "
+                                             "launch -- far below what a launch needs to approach the HBM roof; the launch is bound by its latency "
+                                             "(one dependent chain per environment: state load -> step -> stores), not by bandwidth (DESIGN.md 4.4, 5)"}
     fields["launch_structure"] = search.launch_info()  # one_launch: the whole selfplay() call is ONE kernel launch (include/eaz.h eaz_search_launch_info)
     fields["kernel_ms_instrumented_pass"] = {k: round(v["ms"], 3) for k, v in prof.items()}
     fields["instrumented_pass_env_steps_per_s"] = B * T_instr * n_instr / dt_instr

@@ -323,7 +323,7 @@ static int env_step_launch(eaz_env* env, int B, const void* in, const int32_t* a
         } else {
             if (g_subleq_wave) {  // one wavefront per environment (default)
                 subleq_wave_kernel<<<B, 64, 0, st>>>(env->dev, src, dst, action, B, mode, key, d_key, static_cast<char*>(out_copy), mover_reward, nullptr,
-                                                     nullptr, nullptr);
+                                                     nullptr, nullptr, NoveltyFuse{nullptr, nullptr, 0, 0.0f});
             } else {
                 const int epw = subleq_envs_per_wg(B);
                 subleq_step_kernel<<<cdiv(B, epw), 64, subleq_lds_bytes(env->dev.W), st>>>(env->dev, src, dst, action, B, mode, key, d_key,
@@ -1398,13 +1398,18 @@ static int recurrent_launch(eaz_search* s, hipStream_t st) {
             // ... and, for the XXHash variant over the IO rows (the FCNet default, fully_connected.py:85-87), the novelty lookup
             const NetDev& nd = s->net->dev;
             novelty_done = fused_obs && !nd.sim_matrix && nd.hash_off == 80 && nd.hash_len == 160 && nd.in_dim == 240;
+            // other word sizes (wavefront-per-environment kernel): likewise when the hashed slice is exactly the four IO rows
+            const bool wave_novelty = fused_obs && env->dev.W != 16 && s->net->kind == 0 && !nd.sim_matrix && nd.in_dim == env->dev.obs_dim &&
+                                      nd.hash_off == env->dev.W * env->dev.obs_cols && nd.hash_len == 32 * env->dev.obs_cols;
+            novelty_done = novelty_done || wave_novelty;
             if (env->dev.W == 16)
                 subleq16_wave_kernel<<<B, 64, 0, st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0}, nullptr, nullptr, s->d_next_reward,
                                                        s->d_next_term, s->d_next_legal, 16, fused_obs ? s->d_obs : nullptr,
                                                        NoveltyFuse{nd.bitset, novelty_done ? s->d_novelty : nullptr, nd.hash_bits, nd.nov_scale});
             else if (g_subleq_wave)
                 subleq_wave_kernel<<<B, 64, 0, st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0}, nullptr, nullptr, s->d_next_reward,
-                                                     s->d_next_term, s->d_next_legal, fused_obs ? s->d_obs : nullptr);
+                                                     s->d_next_term, s->d_next_legal, fused_obs ? s->d_obs : nullptr,
+                                                     NoveltyFuse{nd.bitset, wave_novelty ? s->d_novelty : nullptr, nd.hash_bits, nd.nov_scale});
             else
                 subleq_step_kernel<<<cdiv(B, epw), 64, subleq_lds_bytes(env->dev.W), st>>>(env->dev, src, dst, s->tree.sim_action, B, 0, Key{0, 0},
                                                                                           nullptr, nullptr, s->d_next_reward, s->d_next_term,
@@ -1444,6 +1449,27 @@ extern "C" int eaz_search_simulate(eaz_search* s, int sim, void* stream) {
             ProfScope ps(s, EAZ_K_GATHER, st);
             StateRef dst{s->tree.embeddings, s->tree.sim_next, s->N};
             obs_emit_kernel<<<cdiv(static_cast<long>(s->B) * 64, 256), 256, 0, st>>>(ed, dst, s->B, s->d_obs);
+            LAUNCH_OK();
+        }
+        HeadList hl{3, {0, 1, s->opts.exploration ? 3 : 2, 0}};
+        NetOut o{s->opts.exploration ? nullptr : s->d_exploit, s->opts.exploration ? s->d_explore : nullptr, s->d_v, s->d_u};
+        rc = infer_launch(s, s->d_obs, s->d_novelty, o, hl, st, novelty_done);
+        if (rc) return rc;
+        s->pending_expand = sim;
+        s->sims_done += 1;
+        return 0;
+    }
+    if (g_fused_leaf && g_subleq_wave && ed.kind == EAZ_ENV_SUBLEQ && ed.W != 16 && ed.binary && s->lpt == 64 && s->net->kind == 0 &&
+        (s->apl == 1 || s->apl == 4)) {  // (APL = 2, word sizes 65..128: the fused instantiation spills 20 bytes into scratch memory -- left on the two-launch path)
+        // word sizes 64..256 (256: the reference's code default): tree step + leaf step + observation row (+ novelty over the IO rows) in one
+        // launch of one wavefront per tree (search_kernels.hpp subleq_tree_leaf_kernel), then the forward
+        const NetDev& nd = s->net->dev;
+        const bool novelty_done = !nd.sim_matrix && nd.in_dim == ed.obs_dim && nd.hash_off == ed.W * ed.obs_cols && nd.hash_len == 32 * ed.obs_cols;
+        {
+            ProfScope ps(s, EAZ_K_TREE, st);
+            const NoveltyFuse nf{nd.bitset, novelty_done ? s->d_novelty : nullptr, nd.hash_bits, nd.nov_scale};
+            if (s->apl == 1) subleq_tree_leaf_kernel<1><<<s->B, 64, 0, st>>>(s->tree, sim, mode, ed, s->d_next_reward, s->d_next_term, s->d_next_legal, s->d_obs, nf);
+            else subleq_tree_leaf_kernel<4><<<s->B, 64, 0, st>>>(s->tree, sim, mode, ed, s->d_next_reward, s->d_next_term, s->d_next_legal, s->d_obs, nf);
             LAUNCH_OK();
         }
         HeadList hl{3, {0, 1, s->opts.exploration ? 3 : 2, 0}};

@@ -767,15 +767,13 @@ __device__ __forceinline__ bool subleqw_wave_run(const int W, const int lane, ui
     return error == 0 && pack8_eq(sout, stout);
 }
 
-// Same contract as subleq_step_kernel; grid = B workgroups of one wavefront.  Lane l carries bytes 4 l .. 4 l + 3 of the state's 256-byte
-// memory field (all of it: the bytes beyond word_size are zero and travel with the copy), lane 0 the header and the four IO rows.
-__global__ void __launch_bounds__(64) subleq_wave_kernel(EnvDev e, StateRef src, StateRef dst, const int32_t* action, int B, int mode, Key key_arg,
-                                                         const Key* key_ptr, char* out_copy, float* next_reward, uint8_t* next_term,
-                                                         uint8_t* next_legal, uint8_t* obs_out) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+// env.step of environment `b` by one wavefront: state blob `sp` -> `dp` (mode / keys / outputs as subleq_step_kernel; `act_in` is read when a
+// step is taken).  obs_out: the binary observation row; nf.novelty: its novelty where the hashed slice is the four IO rows
+// (fully_connected.py:85-87: lane q = stripe q = IO row q, 8 words x obs_cols bytes, hashes.py:162-229) -- the caller checks both.
+__device__ __forceinline__ void subleq_wave_body(const EnvDev& e, const char* sp, char* dp, const int b, const int lane, const int act_in, const int mode,
+                                                 const Key key_arg, const Key* key_ptr, char* out_copy, float* next_reward, uint8_t* next_term,
+                                                 uint8_t* next_legal, uint8_t* obs_out, const NoveltyFuse& nf) {
     const int W = e.W;
-    const char* sp = state_ptr(src, b, e.state_bytes);
-    char* dp = state_ptr(dst, b, e.state_bytes);
     const eaz_subleq_state* ss = reinterpret_cast<const eaz_subleq_state*>(sp);
     int h_step = 0, h_task = 0, h_flags = 0;
     uint32_t md = 0u;
@@ -807,7 +805,7 @@ __global__ void __launch_bounds__(64) subleq_wave_kernel(EnvDev e, StateRef src,
         } else {
             task = h_task;
             step_count = h_step + 1;
-            act = __builtin_amdgcn_readfirstlane(action[b]);
+            act = act_in;
             if (step_count >= W - 3 || s_solved) finish = true;  // subleq.py:671-673
             else run = true;
         }
@@ -821,9 +819,8 @@ __global__ void __launch_bounds__(64) subleq_wave_kernel(EnvDev e, StateRef src,
         if (!do_init && idx >= 0 && idx < W && lane == (idx >> 2)) md = (md & ~(0xFFu << (8 * (idx & 3)))) | ((static_cast<uint32_t>(act) & 0xFFu) << (8 * (idx & 3)));
         all_correct = true;
         for (int c = 0; c < 3 && all_correct; ++c) {  // subleq.py:511 vmap; `solved` is the AND (:525), only case 0 feeds the state
-            uint16_t tin[8], tout[8];
-            subleq_test_case(task, c, W, tin, tout);
-            const Pack8 pin = pack8(tin), pout = pack8(tout);
+            Pack8 pin, pout;
+            subleq_test_case_packed(task, c, W, pin, pout);
             Pack8 ia, oa;
             int bytes_c = 0;
             const bool correct = subleqw_wave_run(W, lane, md, pin, pout, ia, oa, bytes_c);
@@ -848,21 +845,21 @@ __global__ void __launch_bounds__(64) subleq_wave_kernel(EnvDev e, StateRef src,
     const int truncated = do_init ? 0 : s_trunc;
     const uint4 header = make_uint4(static_cast<uint32_t>(step_count), static_cast<uint32_t>(task), __builtin_bit_cast(uint32_t, reward),
                                     static_cast<uint32_t>(terminated) | (static_cast<uint32_t>(truncated) << 8) | (static_cast<uint32_t>(solved) << 16));
-    uint4 rows[4];
+    uint4 row0, row1, row2, row3;  // (four named registers sets: an indexed array of them lived in scratch memory)
     if (run) {
         auto r4 = [](const Pack8& p) { return make_uint4(static_cast<uint32_t>(p.lo), static_cast<uint32_t>(p.lo >> 32), static_cast<uint32_t>(p.hi), static_cast<uint32_t>(p.hi >> 32)); };
-        rows[0] = r4(ex_in); rows[1] = r4(in_after); rows[2] = r4(ex_out); rows[3] = r4(out_after);
+        row0 = r4(ex_in); row1 = r4(in_after); row2 = r4(ex_out); row3 = r4(out_after);
     } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rows[i] = *reinterpret_cast<const uint4*>(sp + 16 + 16 * i);
+        row0 = *reinterpret_cast<const uint4*>(sp + 16); row1 = *reinterpret_cast<const uint4*>(sp + 32);
+        row2 = *reinterpret_cast<const uint4*>(sp + 48); row3 = *reinterpret_cast<const uint4*>(sp + 64);
     }
     (void)ss;
     auto emit = [&](char* base, bool everything) {
         if (lane == 0) {
             *reinterpret_cast<uint4*>(base) = header;
             if (everything || run) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(base + 16 + 16 * i) = rows[i];
+                *reinterpret_cast<uint4*>(base + 16) = row0; *reinterpret_cast<uint4*>(base + 32) = row1;
+                *reinterpret_cast<uint4*>(base + 48) = row2; *reinterpret_cast<uint4*>(base + 64) = row3;
             }
         }
         if (everything || run) reinterpret_cast<uint32_t*>(base + 80)[lane] = md;
@@ -886,7 +883,7 @@ __global__ void __launch_bounds__(64) subleq_wave_kernel(EnvDev e, StateRef src,
             if (i < W) v = static_cast<int>((mdw >> (8 * (i & 3))) & 0xFFu);
             else {
                 const int r = (i - W) >> 3, k = (i - W) & 7;
-                const uint4 rw = r == 0 ? rows[0] : (r == 1 ? rows[1] : (r == 2 ? rows[2] : rows[3]));
+                const uint4 rw = r == 0 ? row0 : (r == 1 ? row1 : (r == 2 ? row2 : row3));
                 const uint32_t pair = (k >> 1) == 0 ? rw.x : ((k >> 1) == 1 ? rw.y : ((k >> 1) == 2 ? rw.z : rw.w));
                 v = static_cast<int>((pair >> (16 * (k & 1))) & 0xFFFFu);
             }
@@ -898,6 +895,45 @@ __global__ void __launch_bounds__(64) subleq_wave_kernel(EnvDev e, StateRef src,
             }
         }
     }
+    if (nf.novelty) {
+        // XXHash variant over the IO rows (hashes.py:162-229): lane q < 4 = stripe q = row q, every observation byte is 0 or 1 (bitcast 1.0f)
+        const uint32_t P1 = 0x9E3779B1u, P2 = 0x85EBCA77u, P3 = 0xC2B2AE3Du, SEED = 1u, ONE = 0x3F800000u * P2;
+        const int q = lane & 3, cols = e.obs_cols;
+        uint32_t acc = q == 0 ? SEED + P1 + P2 : (q == 1 ? SEED + P2 : (q == 2 ? SEED : SEED - P1));  // :217-220
+        const uint4 rw = q == 0 ? row0 : (q == 1 ? row1 : (q == 2 ? row2 : row3));
+#pragma unroll 1
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t pair = (k >> 1) == 0 ? rw.x : ((k >> 1) == 1 ? rw.y : ((k >> 1) == 2 ? rw.z : rw.w));
+            const int v = static_cast<int>((pair >> (16 * (k & 1))) & 0xFFFFu);
+            const unsigned m = static_cast<unsigned>(pymod(v, W)) & 0xFFu;  // :90
+#pragma unroll 1
+            for (int j = 0; j < cols - 1; ++j) {
+                const uint32_t t = acc + ((j < 8 && ((m >> j) & 1u)) ? ONE : 0u);
+                acc = ((t << 13) | (t >> 19)) * P1;  // :176-181
+            }
+            const uint32_t t = acc + (v == W ? ONE : 0u);  // :96
+            acc = ((t << 13) | (t >> 19)) * P1;
+        }
+        const int rot = q == 0 ? 1 : (q == 1 ? 7 : (q == 2 ? 12 : 18));  // :184-187
+        uint32_t h = (acc << rot) | (acc >> (32 - rot));
+        h += __shfl_xor(h, 1);
+        h += __shfl_xor(h, 2);
+        h += static_cast<uint32_t>(8 * cols);  // :226 (stripe count)
+        h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;  // :190-197
+        const uint32_t index = nf.hash_bits >= 32 ? h : h >> (32 - nf.hash_bits);  // :229
+        if (lane == 0) subleq16_novelty(nf, b, index);
+    }
+}
+
+// Same contract as subleq_step_kernel; grid = B workgroups of one wavefront.  Lane l carries bytes 4 l .. 4 l + 3 of the state's 256-byte
+// memory field (all of it: the bytes beyond word_size are zero and travel with the copy), lane 0 the header and the four IO rows.
+__global__ void __launch_bounds__(64) subleq_wave_kernel(EnvDev e, StateRef src, StateRef dst, const int32_t* action, int B, int mode, Key key_arg,
+                                                         const Key* key_ptr, char* out_copy, float* next_reward, uint8_t* next_term,
+                                                         uint8_t* next_legal, uint8_t* obs_out, NoveltyFuse nf) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int act = (action && mode != 2) ? __builtin_amdgcn_readfirstlane(action[b]) : 0;
+    subleq_wave_body(e, state_ptr(src, b, e.state_bytes), state_ptr(dst, b, e.state_bytes), b, lane, act, mode, key_arg, key_ptr, out_copy, next_reward,
+                     next_term, next_legal, obs_out, nf);
 }
 
 // ---- connect_four -------------------------------------------------------------------------------------------------

@@ -101,52 +101,94 @@ __host__ __device__ __forceinline__ int pymod(int x, int m) {
     return r < 0 ? r + m : r;
 }
 
-// subleq.py:398-501 get_test_cases: test case `c` of `task`, already modulo'd and padded (:101-107,:402-404).
-// lax.switch clamps the branch index, so task ids >= 6 all select the multiplication table.
-// (host + device: eaz_subleq_test_vectors hands the same function to the CPU test that holds it against the oracle's generator)
-__host__ __device__ __forceinline__ void subleq_test_case(int task, int c, int W, uint16_t tin[8], uint16_t tout[8]) {
-    int branch = task - 1;
-    branch = branch < 0 ? 0 : (branch > 5 ? 5 : branch);
+// subleq.py:398-501 get_test_cases, the tables themselves: test case `c` of branch `branch` (= task - 1 clamped to 0..5: lax.switch clamps the
+// index, so task ids >= 6 all select the multiplication table) as raw integers, before the modulo and the padding (:101-107,:402-404).  ONE
+// statement of the tables for the host (eaz_subleq_test_vectors, held against the oracle's generator by tests/test_abi_and_host.py), the
+// word_size-16 interpreter's packed table (kSq16Cases) and the other word sizes' table (kSqRaw).
+struct SqRawCase {
     int in[8], out[8];
-    int nin = 0, nout = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { in[i] = 0; out[i] = 0; }
+    int nin, nout;
+};
+constexpr SqRawCase sq_raw_case(int branch, int c) {
+    SqRawCase r{{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, 0, 0};
     if (branch == 0) {  // NEGATION_POSITIVE :406-411
         const int t1[8] = {5, 4, 4, 5, 1, 2, 3, 1}, t2[8] = {1, 1, 6, 2, 4, 4, 5, 3};
-        if (c == 0) { nin = 7; for (int i = 0; i < 7; ++i) in[i] = i + 1; }
-        else { nin = 8; for (int i = 0; i < 8; ++i) in[i] = c == 1 ? t1[i] : t2[i]; }
-        nout = nin;
-        for (int i = 0; i < 8; ++i) out[i] = -in[i];
+        if (c == 0) { r.nin = 7; for (int i = 0; i < 7; ++i) r.in[i] = i + 1; }
+        else { r.nin = 8; for (int i = 0; i < 8; ++i) r.in[i] = c == 1 ? t1[i] : t2[i]; }
+        r.nout = r.nin;
+        for (int i = 0; i < 8; ++i) r.out[i] = -r.in[i];
     } else if (branch == 1 || branch == 2) {  // NEGATION :413-418 / IDENTITY :420-421
         const int t2[5] = {0, -1, 2, -3, 4};
-        if (c == 0) { nin = 8; for (int i = 0; i < 8; ++i) in[i] = -4 + i; }
-        else if (c == 1) { nin = 7; for (int i = 0; i < 7; ++i) in[i] = i + 1; }
-        else { nin = 5; for (int i = 0; i < 5; ++i) in[i] = t2[i]; }
-        nout = nin;
-        for (int i = 0; i < 8; ++i) out[i] = branch == 1 ? -in[i] : in[i];
+        if (c == 0) { r.nin = 8; for (int i = 0; i < 8; ++i) r.in[i] = -4 + i; }
+        else if (c == 1) { r.nin = 7; for (int i = 0; i < 7; ++i) r.in[i] = i + 1; }
+        else { r.nin = 5; for (int i = 0; i < 5; ++i) r.in[i] = t2[i]; }
+        r.nout = r.nin;
+        for (int i = 0; i < 8; ++i) r.out[i] = branch == 1 ? -r.in[i] : r.in[i];
     } else if (branch == 3 || branch == 4) {  // SUBTRACTION :423-432 / ADDITION :434-443
         const int a0[6] = {1, 1, 5, 4, 0, -3}, a1[6] = {2, 3, 0, 0, -1, -2}, a2[8] = {1, 2, 3, 4, 4, 3, 2, 1};
         const int s0[3] = {0, 1, 3}, s1[3] = {-1, 0, 1}, s2[4] = {-1, -1, 1, 1};
         const int p0[3] = {2, 9, -3}, p1[3] = {5, 0, -3}, p2[4] = {3, 7, 7, 3};
-        if (c == 0) { nin = 6; nout = 3; for (int i = 0; i < 6; ++i) in[i] = a0[i]; for (int i = 0; i < 3; ++i) out[i] = branch == 3 ? s0[i] : p0[i]; }
-        else if (c == 1) { nin = 6; nout = 3; for (int i = 0; i < 6; ++i) in[i] = a1[i]; for (int i = 0; i < 3; ++i) out[i] = branch == 3 ? s1[i] : p1[i]; }
-        else { nin = 8; nout = 4; for (int i = 0; i < 8; ++i) in[i] = a2[i]; for (int i = 0; i < 4; ++i) out[i] = branch == 3 ? s2[i] : p2[i]; }
+        if (c == 0) { r.nin = 6; r.nout = 3; for (int i = 0; i < 6; ++i) r.in[i] = a0[i]; for (int i = 0; i < 3; ++i) r.out[i] = branch == 3 ? s0[i] : p0[i]; }
+        else if (c == 1) { r.nin = 6; r.nout = 3; for (int i = 0; i < 6; ++i) r.in[i] = a1[i]; for (int i = 0; i < 3; ++i) r.out[i] = branch == 3 ? s1[i] : p1[i]; }
+        else { r.nin = 8; r.nout = 4; for (int i = 0; i < 8; ++i) r.in[i] = a2[i]; for (int i = 0; i < 4; ++i) r.out[i] = branch == 3 ? s2[i] : p2[i]; }
     } else {  // MULTIPLICATION :445-454
         const int m0[6] = {1, 2, 2, 3, -7, 4}, m1[6] = {-1, -5, 5, 2, 0, 1}, m2[6] = {0, 0, 1, 1, -3, 3};
         const int o0[3] = {2, 6, -28}, o1[3] = {5, 10, 0}, o2[3] = {0, 1, -9};
-        nin = 6; nout = 3;
-        for (int i = 0; i < 6; ++i) in[i] = c == 0 ? m0[i] : (c == 1 ? m1[i] : m2[i]);
-        for (int i = 0; i < 3; ++i) out[i] = c == 0 ? o0[i] : (c == 1 ? o1[i] : o2[i]);
+        r.nin = 6; r.nout = 3;
+        for (int i = 0; i < 6; ++i) r.in[i] = c == 0 ? m0[i] : (c == 1 ? m1[i] : m2[i]);
+        for (int i = 0; i < 3; ++i) r.out[i] = c == 0 ? o0[i] : (c == 1 ? o1[i] : o2[i]);
     }
+    return r;
+}
+__host__ __device__ constexpr int sq_task_branch(int task) { return task - 1 < 0 ? 0 : (task - 1 > 5 ? 5 : task - 1); }
+
+// the raw tables packed for the device (any word size): eight signed bytes per row in one 64-bit word -- a case is read with scalar loads
+// and its elements come out by shifts; an indexed local array (SqRawCase by value) would live in scratch memory
+struct SqRawPacked {
+    unsigned long long in, out;
+    int nin, nout;
+};
+struct SqRawTable {
+    SqRawPacked v[6][3];
+};
+constexpr SqRawTable sq_make_raw() {
+    SqRawTable t{};
+    for (int branch = 0; branch < 6; ++branch)
+        for (int c = 0; c < 3; ++c) {
+            const SqRawCase r = sq_raw_case(branch, c);
+            unsigned long long pi = 0, po = 0;
+            for (int i = 0; i < 8; ++i) {
+                pi |= (static_cast<unsigned long long>(r.in[i]) & 0xFFull) << (8 * i);
+                po |= (static_cast<unsigned long long>(r.out[i]) & 0xFFull) << (8 * i);
+            }
+            t.v[branch][c] = SqRawPacked{pi, po, r.nin, r.nout};
+        }
+    return t;
+}
+__device__ constexpr SqRawTable kSqRaw = sq_make_raw();
+__host__ __device__ constexpr int sq_raw_elem(unsigned long long packed, int i) { return static_cast<int>(static_cast<signed char>((packed >> (8 * i)) & 0xFFull)); }
+
+// test case `c` of `task`, already modulo'd and padded (host + device: eaz_subleq_test_vectors hands the same function to the CPU test that
+// holds it against the oracle's generator; the device reads the packed table, the host evaluates sq_raw_case)
+__host__ __device__ __forceinline__ void subleq_test_case(int task, int c, int W, uint16_t tin[8], uint16_t tout[8]) {
+#ifdef __HIP_DEVICE_COMPILE__
+    const SqRawPacked r = kSqRaw.v[sq_task_branch(task)][c];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        tin[i] = static_cast<uint16_t>(i < nin ? pymod(in[i], W) : W);
-        tout[i] = static_cast<uint16_t>(i < nout ? pymod(out[i], W) : W);
+        tin[i] = static_cast<uint16_t>(i < r.nin ? pymod(sq_raw_elem(r.in, i), W) : W);
+        tout[i] = static_cast<uint16_t>(i < r.nout ? pymod(sq_raw_elem(r.out, i), W) : W);
     }
+#else
+    const SqRawCase r = sq_raw_case(sq_task_branch(task), c);
+    for (int i = 0; i < 8; ++i) {
+        tin[i] = static_cast<uint16_t>(i < r.nin ? pymod(r.in[i], W) : W);
+        tout[i] = static_cast<uint16_t>(i < r.nout ? pymod(r.out[i], W) : W);
+    }
+#endif
 }
 
 // The test vectors of word_size 16, packed for the one-wavefront interpreter (env_kernels.hpp): [branch][case][0 = input, 1 = expected
-// output], element i in byte i, W (= 16) beyond the valid ones -- subleq_test_case evaluated at compile time (its branch tree is ~300
+// output], element i in byte i, W (= 16) beyond the valid ones -- sq_raw_case evaluated at compile time (its branch tree is ~300
 // scalar instructions, ~2 k clocks of a lone wavefront per case, most of what an interpreter run used to cost).
 struct Sq16CaseTable {
     unsigned long long v[6][3][2];
@@ -156,39 +198,11 @@ constexpr Sq16CaseTable sq16_make_cases() {
     Sq16CaseTable t{};
     for (int branch = 0; branch < 6; ++branch)
         for (int c = 0; c < 3; ++c) {
-            int in[8] = {0, 0, 0, 0, 0, 0, 0, 0}, out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            int nin = 0, nout = 0;
-            if (branch == 0) {  // NEGATION_POSITIVE :406-411
-                const int t1[8] = {5, 4, 4, 5, 1, 2, 3, 1}, t2[8] = {1, 1, 6, 2, 4, 4, 5, 3};
-                if (c == 0) { nin = 7; for (int i = 0; i < 7; ++i) in[i] = i + 1; }
-                else { nin = 8; for (int i = 0; i < 8; ++i) in[i] = c == 1 ? t1[i] : t2[i]; }
-                nout = nin;
-                for (int i = 0; i < 8; ++i) out[i] = -in[i];
-            } else if (branch == 1 || branch == 2) {  // NEGATION :413-418 / IDENTITY :420-421
-                const int t2[5] = {0, -1, 2, -3, 4};
-                if (c == 0) { nin = 8; for (int i = 0; i < 8; ++i) in[i] = -4 + i; }
-                else if (c == 1) { nin = 7; for (int i = 0; i < 7; ++i) in[i] = i + 1; }
-                else { nin = 5; for (int i = 0; i < 5; ++i) in[i] = t2[i]; }
-                nout = nin;
-                for (int i = 0; i < 8; ++i) out[i] = branch == 1 ? -in[i] : in[i];
-            } else if (branch == 3 || branch == 4) {  // SUBTRACTION :423-432 / ADDITION :434-443
-                const int a0[6] = {1, 1, 5, 4, 0, -3}, a1[6] = {2, 3, 0, 0, -1, -2}, a2[8] = {1, 2, 3, 4, 4, 3, 2, 1};
-                const int s0[3] = {0, 1, 3}, s1[3] = {-1, 0, 1}, s2[4] = {-1, -1, 1, 1};
-                const int p0[3] = {2, 9, -3}, p1[3] = {5, 0, -3}, p2[4] = {3, 7, 7, 3};
-                if (c == 0) { nin = 6; nout = 3; for (int i = 0; i < 6; ++i) in[i] = a0[i]; for (int i = 0; i < 3; ++i) out[i] = branch == 3 ? s0[i] : p0[i]; }
-                else if (c == 1) { nin = 6; nout = 3; for (int i = 0; i < 6; ++i) in[i] = a1[i]; for (int i = 0; i < 3; ++i) out[i] = branch == 3 ? s1[i] : p1[i]; }
-                else { nin = 8; nout = 4; for (int i = 0; i < 8; ++i) in[i] = a2[i]; for (int i = 0; i < 4; ++i) out[i] = branch == 3 ? s2[i] : p2[i]; }
-            } else {  // MULTIPLICATION :445-454
-                const int m0[6] = {1, 2, 2, 3, -7, 4}, m1[6] = {-1, -5, 5, 2, 0, 1}, m2[6] = {0, 0, 1, 1, -3, 3};
-                const int o0[3] = {2, 6, -28}, o1[3] = {5, 10, 0}, o2[3] = {0, 1, -9};
-                nin = 6; nout = 3;
-                for (int i = 0; i < 6; ++i) in[i] = c == 0 ? m0[i] : (c == 1 ? m1[i] : m2[i]);
-                for (int i = 0; i < 3; ++i) out[i] = c == 0 ? o0[i] : (c == 1 ? o1[i] : o2[i]);
-            }
+            const SqRawCase r = sq_raw_case(branch, c);
             unsigned long long pi = 0, po = 0;
             for (int i = 0; i < 8; ++i) {
-                pi |= static_cast<unsigned long long>(i < nin ? sq16_pymod(in[i]) : 16) << (8 * i);
-                po |= static_cast<unsigned long long>(i < nout ? sq16_pymod(out[i]) : 16) << (8 * i);
+                pi |= static_cast<unsigned long long>(i < r.nin ? sq16_pymod(r.in[i]) : 16) << (8 * i);
+                po |= static_cast<unsigned long long>(i < r.nout ? sq16_pymod(r.out[i]) : 16) << (8 * i);
             }
             t.v[branch][c][0] = pi;
             t.v[branch][c][1] = po;
@@ -196,7 +210,6 @@ constexpr Sq16CaseTable sq16_make_cases() {
     return t;
 }
 __device__ constexpr Sq16CaseTable kSq16Cases = sq16_make_cases();
-
 // subleq.py:156-395 simulate.  `mem` is a private, mutable copy of the program (W bytes, LDS or scratch).
 // Returns correct (:394); in/out hold input_after / output_after on return.
 // Eight uint16 values (test input / expected output / produced output) packed into two 64-bit registers: element i lives in
@@ -222,6 +235,18 @@ __device__ __forceinline__ void unpack8(const Pack8& p, uint16_t v[8]) {
     }
 }
 __device__ __forceinline__ bool pack8_eq(const Pack8& a, const Pack8& b) { return a.lo == b.lo && a.hi == b.hi; }
+// subleq_test_case as two Pack8, from the compile-time table (no local arrays: the indexed uint16 arrays of subleq_test_case + pack8 cost the
+// wavefront-per-environment kernel 112 bytes of scratch memory per lane)
+__device__ __forceinline__ void subleq_test_case_packed(const int task, const int c, const int W, Pack8& pin, Pack8& pout) {
+    const SqRawPacked r = kSqRaw.v[sq_task_branch(task)][c];
+    pin = Pack8{0ull, 0ull}; pout = Pack8{0ull, 0ull};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned long long vi = static_cast<unsigned long long>(i < r.nin ? pymod(sq_raw_elem(r.in, i), W) : W) << (16 * (i & 3));
+        const unsigned long long vo = static_cast<unsigned long long>(i < r.nout ? pymod(sq_raw_elem(r.out, i), W) : W) << (16 * (i & 3));
+        if (i < 4) { pin.lo |= vi; pout.lo |= vo; } else { pin.hi |= vi; pout.hi |= vo; }
+    }
+}
 
 // Program memory of one interpreter run: W bytes in LDS + W bytes for the periodicity snapshot (any word size; word_size 16, the
 // size of the reference's experiments (slurm_experiment_submitter.py:196), has its own kernel: subleq16_wave_kernel).

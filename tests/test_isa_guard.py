@@ -66,6 +66,59 @@ def test_no_scratch_and_register_budget(asm, stem):
     assert count(body, "v_mfma_f32_16x16x4_f32") > 0, f"{stem} has lost its f32 MFMA stream"
 
 
+def all_kernels(asm):
+    """{mangled name: metadata dict} of every kernel of the library"""
+    out = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)", asm):
+        name = m.group(1)
+        i = asm.index(f".name:           {name}")
+        j = asm.rfind("- .agpr_count", 0, i)
+        k = asm.find("- .agpr_count", i)
+        txt = asm[j:k if k > 0 else len(asm)]
+        out[name] = {key: int(v) for key, v in re.findall(r"\.(\w+):\s+(\d+)\s*$", txt, re.M)}
+    return out
+
+
+# kernels that are compiled but never launched (eaz_api.hip does not dispatch them) and may keep their scratch use
+NOT_DISPATCHED = ("subleq_tree_leaf_kernelILi2E",)   # word sizes 65..128: 20 bytes of scratch; those searches stay on tree_step + subleq_wave
+
+
+def test_no_launched_kernel_uses_scratch_memory(asm):
+    """Round 3 shipped two kernels on BASELINE / code-default paths with scratch memory nobody had asked for (subleq_wave_kernel 112 bytes: indexed
+    local arrays of the test vectors and the IO rows; connect4_step_kernel 84 bytes: the board as an indexed int8 array).  Both are gone
+    (packed compile-time tables / bitboards); this holds it for EVERY kernel of the library, the new ones included."""
+    ks = all_kernels(asm)
+    assert len(ks) >= 40
+    bad = {n: d["private_segment_fixed_size"] for n, d in ks.items() if d.get("private_segment_fixed_size", 0) and not any(x in n for x in NOT_DISPATCHED)}
+    assert not bad, f"kernels with scratch memory: {bad}"
+    for stem in ("subleq_wave_kernel", "connect4_step_kernel", "connect4_leaf_kernel", "subleq_step_kernel", "subleq16_tree_leaf_kernel",
+                 "subleq_tree_leaf_kernelILi1E", "subleq_tree_leaf_kernelILi4E", "sq16_roots_fit_kernel", "sq16_l1_table_kernel"):
+        body, _ = kernel(asm, stem)
+        assert count(body, "scratch_load_dword") + count(body, "scratch_store_dword") + count(body, "scratch_load_dwordx4") + count(body, "scratch_store_dwordx4") == 0, stem
+
+
+# occupancy each of the remaining hot kernels is designed for: (VGPRs + AGPRs) budget
+WIDE_BUDGET = {
+    r"tree_step_kernelILi\d+ELi\d+EE": 256,     # one-wavefront workgroups, two waves per SIMD (DESIGN.md 4.0: memory-level parallelism, not lanes)
+    r"fc_forward_kernelILb[01]EE": 512,         # 64-row tiles: 4 x 4 MFMA tiles per wave = 256 accumulator registers (AGPRs) + operands: one wave per SIMD
+    r"fc16_forward_kernelILi[012]EE": 168,      # three workgroups per CU
+    r"subleq16_tree_leaf_kernel": 128,          # one wavefront per tree, four per SIMD
+    r"subleq_tree_leaf_kernelILi[14]E": 128,
+    r"connect4_leaf_kernel": 128,
+    r"subleq_wave_kernel": 64,
+}
+
+
+@pytest.mark.parametrize("pattern", sorted(WIDE_BUDGET))
+def test_register_budgets_of_the_per_simulation_kernels(asm, pattern):
+    ks = {n: d for n, d in all_kernels(asm).items() if re.search(pattern, n)}
+    assert ks, f"no kernel matches {pattern}"
+    for n, d in ks.items():
+        total = d["vgpr_count"]  # (the metadata's vgpr_count already includes the AGPRs of a unified register file allocation)
+        assert total <= WIDE_BUDGET[pattern], f"{n}: {total} registers exceed the {WIDE_BUDGET[pattern]} of its designed occupancy"
+        assert d.get("vgpr_spill_count", 0) == 0, f"{n} spills {d['vgpr_spill_count']} VGPRs"
+
+
 @pytest.mark.parametrize("stem", ["search_persist_kernel", "subleq16_search_kernel", "subleq16_selfplay_kernel", "fc16p_forward_kernel", "resnet_forward_kernel"])
 def test_weight_stream_is_buffer_loads(asm, stem):
     body, _ = kernel(asm, stem)
