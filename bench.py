@@ -505,15 +505,25 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
             pool.TrajectoryPooler(to_host=rehearsal).submit(search.selfplay(states, 1, key=(1000 * rank + 998), **wl["sp_kw"])).wait()
     # ---- timed region: EXACTLY K steps in the production configuration (one captured hipGraph per real step) ----
     sync()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for i in range(steps):
         one_step(i)
+    ev1.record()   # this rank's own launch stream is done here (the collectives of the last two steps may still be in flight)
     sync()
     dt = time.perf_counter() - t0
+    rank_ms = None
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        # per-rank time of the K steps on the rank's own launch stream (HIP events): the first real scaling run shows a straggling GPU
+        # without a second run -- value / ms_per_step stay the barrier-to-barrier maximum over the ranks
+        own = torch.tensor([ev0.elapsed_time(ev1) / max(steps, 1)], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        allr = [torch.zeros_like(own) for _ in range(dist.get_world_size())]
+        dist.all_gather(allr, own)
+        rank_ms = [float(x.item()) for x in allr]
     # ---- instrumented pass: the same kernels again with HIP events recorded on the launch stream around every kernel
     # (event records cannot sit between the nodes of a replayed graph, so this pass uses plain stream launches; kernel
     # durations are unaffected, only the host-side launch gaps differ).  Feeds `roofline`, never `value`. ----
@@ -650,6 +660,9 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
                                              "novelty) against 2 x state + observation bytes per tree: a few hundred bytes per tree, i.e. 1-4 MB per "
                                              "launch -- far below what a launch needs to approach the HBM roof; the launch is bound by its latency "
                                              "(one dependent chain per environment: state load -> step -> stores), not by bandwidth (DESIGN.md 4.4, 5)"}
+    if rank_ms is not None:
+        fields["ms_per_step_by_rank"] = {"min": min(rank_ms), "max": max(rank_ms), "ranks": [round(x, 3) for x in rank_ms],
+                                         "what": "HIP-event time of the K timed steps on each rank's own launch stream / K (no barrier inside)"}
     fields["launch_structure"] = search.launch_info()  # one_launch: the whole selfplay() call is ONE kernel launch (include/eaz.h eaz_search_launch_info)
     fields["kernel_ms_instrumented_pass"] = {k: round(v["ms"], 3) for k, v in prof.items()}
     fields["instrumented_pass_env_steps_per_s"] = B * T_instr * n_instr / dt_instr

@@ -156,6 +156,7 @@ struct eaz_search {
     float* d_sq_logits;        // [ceil16(B), N, 32] scratch rows: prior logits | their softmax
     float* d_sq_l1init;        // [ceil16(B), 2, 3, 256]: start of the layer-1 chains per tree (Sq16SelfplayArgs::l1init)
     int sqp_roots_fit;         // the roots of the search begun last fit the one-launch kernel's compact state (sq16_roots_fit)
+    int* d_eval_wg;            // [1 + workgroups]: evaluate's trip count, then the workgroups' own (PersistSelfplay::eval_iters / eval_wg_iters)
 };
 
 extern "C" int eaz_ctx_create(int device, eaz_ctx** out) {
@@ -1003,7 +1004,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     s->prof_on = 0; s->step_graph = nullptr; s->graph_states = nullptr; s->graph_flags = -1; s->pending_expand = -1;
     s->persist_ok = 0; s->persist_lds = 0; s->clear_pending = 0; s->sims_done = 0; s->d_stamps = nullptr;
     std::memset(&s->last_sp, 0, sizeof s->last_sp); s->d_replay_states = nullptr;
-    s->sqp_lds = 0; s->d_sq_logits = nullptr; s->d_sq_l1init = nullptr;
+    s->sqp_lds = 0; s->d_sq_logits = nullptr; s->d_sq_l1init = nullptr; s->d_eval_wg = nullptr;
     HIP_OK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&s->main, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
@@ -1092,6 +1093,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
                 HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(subleq16_selfplay_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, QL.total));
                 DALLOC(s->d_sq_logits, static_cast<size_t>(cdiv(B, kQpTrees)) * kQpTrees * s->N * (2 * kQpA));
                 DALLOC(s->d_sq_l1init, static_cast<size_t>(kQpL1Tab) + static_cast<size_t>(cdiv(B, kQpTrees)) * kQpTrees * 3 * kFcH);
+                DALLOC(s->d_eval_wg, static_cast<size_t>(1 + cdiv(B, kQpTrees)));
                 DALLOC(s->d_replay_states, static_cast<size_t>(B) * env->dev.state_bytes);
             }
         }
@@ -1459,7 +1461,8 @@ extern "C" int eaz_search_simulate(eaz_search* s, int sim, void* stream) {
         s->sims_done += 1;
         return 0;
     }
-    if (g_fused_leaf && g_subleq_wave && ed.kind == EAZ_ENV_SUBLEQ && ed.W != 16 && ed.binary && s->lpt == 64 && s->net->kind == 0 &&
+    static const int wide_tree_leaf = [] { const char* e = std::getenv("EAZ_SUBLEQ_TREE_LEAF"); return e ? std::atoi(e) : 1; }();
+    if (wide_tree_leaf && g_fused_leaf && g_subleq_wave && ed.kind == EAZ_ENV_SUBLEQ && ed.W != 16 && ed.binary && s->lpt == 64 && s->net->kind == 0 &&
         (s->apl == 1 || s->apl == 4)) {  // (APL = 2, word sizes 65..128: the fused instantiation spills 20 bytes into scratch memory -- left on the two-launch path)
         // word sizes 64..256 (256: the reference's code default): tree step + leaf step + observation row (+ novelty over the IO rows) in one
         // launch of one wavefront per tree (search_kernels.hpp subleq_tree_leaf_kernel), then the forward
@@ -1467,9 +1470,12 @@ extern "C" int eaz_search_simulate(eaz_search* s, int sim, void* stream) {
         const bool novelty_done = !nd.sim_matrix && nd.in_dim == ed.obs_dim && nd.hash_off == ed.W * ed.obs_cols && nd.hash_len == 32 * ed.obs_cols;
         {
             ProfScope ps(s, EAZ_K_TREE, st);
-            const NoveltyFuse nf{nd.bitset, novelty_done ? s->d_novelty : nullptr, nd.hash_bits, nd.nov_scale};
-            if (s->apl == 1) subleq_tree_leaf_kernel<1><<<s->B, 64, 0, st>>>(s->tree, sim, mode, ed, s->d_next_reward, s->d_next_term, s->d_next_legal, s->d_obs, nf);
-            else subleq_tree_leaf_kernel<4><<<s->B, 64, 0, st>>>(s->tree, sim, mode, ed, s->d_next_reward, s->d_next_term, s->d_next_legal, s->d_obs, nf);
+            SqTreeLeafArgs ta;
+            ta.t = s->tree; ta.sim = sim; ta.mode = mode; ta.e = ed;
+            ta.next_reward = s->d_next_reward; ta.next_term = s->d_next_term; ta.next_legal = s->d_next_legal; ta.obs_out = s->d_obs;
+            ta.nf = NoveltyFuse{nd.bitset, novelty_done ? s->d_novelty : nullptr, nd.hash_bits, nd.nov_scale};
+            if (s->apl == 1) subleq_tree_leaf_kernel<1><<<s->B, 64, 0, st>>>(ta);
+            else subleq_tree_leaf_kernel<4><<<s->B, 64, 0, st>>>(ta);
             LAUNCH_OK();
         }
         HeadList hl{3, {0, 1, s->opts.exploration ? 3 : 2, 0}};
@@ -1920,6 +1926,37 @@ extern "C" int eaz_evaluate_run(eaz_search* s, float exploitation_beta, int max_
     HIP_OK(hipSetDevice(s->ctx->device));
     hipStream_t st = S(stream);
     const int B = s->B;
+    if (g_persist == 1 && sqp_eligible(s) && max_episode_length >= 0 && max_episode_length < (1 << 24)) {
+        // Subleq-16: the whole while_loop (evaluate.py:13-57) as ONE launch of the one-launch kernel in its evaluate mode -- no host round trip
+        // between the first and the last step (the host driver below copies a counter back and synchronises after every real step)
+        bool fit = false;
+        int rc = sq16_roots_fit(s, d_states, st, &fit);
+        if (rc) return rc;
+        if (fit) {
+            PersistSelfplay sp;
+            std::memset(&sp, 0, sizeof sp);
+            sp.on = 2; sp.T = max_episode_length + 1;  // cond_fn: counter <= max_episode_length
+            sp.sbeta = exploitation_beta; sp.gumbel_scale = s->opts.gumbel_scale;
+            sp.states = static_cast<char*>(d_states);
+            sp.eval_sum = d_sum_rewards; sp.eval_iters = s->d_eval_wg; sp.eval_wg_iters = s->d_eval_wg + 1;
+            HIP_OK(hipMemsetAsync(s->d_eval_wg, 0, sizeof(int) * (1 + cdiv(B, kQpTrees)), st));
+            {
+                ProfScope ps(s, EAZ_K_SEARCH, st);
+                rc = sqp_launch(s, sp, st);
+                if (rc) return rc;
+            }
+            {
+                ProfScope ps(s, EAZ_K_MISC, st);
+                sq16_eval_finalize_kernel<<<cdiv(B, 256), 256, 0, st>>>(static_cast<char*>(d_states), B, s->d_eval_wg + 1, s->d_eval_wg);
+                LAUNCH_OK();
+            }
+            if (h_iterations) {
+                HIP_OK(hipMemcpyAsync(h_iterations, s->d_eval_wg, sizeof(int), hipMemcpyDeviceToHost, st));
+                HIP_OK(hipStreamSynchronize(st));
+            }
+            return 0;
+        }
+    }
     HIP_OK(hipMemsetAsync(d_sum_rewards, 0, sizeof(float) * B, st));
     int counter = 0;
     for (;;) {

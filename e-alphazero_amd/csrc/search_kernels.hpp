@@ -288,17 +288,39 @@ __global__ void __launch_bounds__(64) subleq16_tree_leaf_kernel(TreeDev t, int s
 // The same for the word sizes whose tree is walked by a whole wavefront (64 <= word_size <= 256: 64 lanes x APL actions): tree_step_kernel<64, APL>
 // followed by subleq_wave_kernel (program in the lanes of one VGPR) in one launch, the binary observation row and -- where the hashed slice is
 // the IO rows -- its novelty included.  word_size 256 is the reference's code default (main.py:159): a simulation is this launch and the forward.
+// The arguments are ONE struct read through the laundered kernarg segment pointer, once per phase (the trick of the one-launch kernels,
+// search_subleq.hpp): passed by value, TreeDev + EnvDev + the output pointers were all loaded at the kernel entry and held in scalar
+// registers across both phases -- 142 SGPR spills into VGPR lanes in the first version, which then ran no faster than the two launches.
+struct SqTreeLeafArgs {
+    TreeDev t;
+    int sim, mode;
+    EnvDev e;
+    float* next_reward;
+    uint8_t *next_term, *next_legal, *obs_out;
+    NoveltyFuse nf;
+};
+__device__ __forceinline__ const SqTreeLeafArgs* sq_tree_leaf_args() {
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (const SqTreeLeafArgs*)p;
+}
 template <int APL>
-__global__ void __launch_bounds__(64) subleq_tree_leaf_kernel(TreeDev t, int sim, int mode, EnvDev e, float* next_reward, uint8_t* next_term,
-                                                              uint8_t* next_legal, uint8_t* obs_out, NoveltyFuse nf) {
+__global__ void __launch_bounds__(64) subleq_tree_leaf_kernel(SqTreeLeafArgs) {
     const int b = blockIdx.x, lane = threadIdx.x;
-    const TreeSel sel = tree_step_body<64, APL>(t, sim, mode, b, lane);
-    if (!(mode & kTreeSelect)) return;
-    const int node = __builtin_amdgcn_readfirstlane(sel.node), action = __builtin_amdgcn_readfirstlane(sel.action);
-    const int dst = __builtin_amdgcn_readfirstlane(sel.dst);
-    char* base = t.embeddings + static_cast<long>(b) * t.N * t.state_bytes;
-    subleq_wave_body(e, base + static_cast<long>(node) * t.state_bytes, base + static_cast<long>(dst) * t.state_bytes, b, lane, action, 0, Key{0, 0}, nullptr,
-                     nullptr, next_reward, next_term, next_legal, obs_out, nf);
+    int node, action, dst;
+    {
+        const SqTreeLeafArgs& a = *sq_tree_leaf_args();
+        const TreeSel sel = tree_step_body<64, APL>(a.t, a.sim, a.mode, b, lane);
+        if (!(a.mode & kTreeSelect)) return;
+        node = __builtin_amdgcn_readfirstlane(sel.node); action = __builtin_amdgcn_readfirstlane(sel.action);
+        dst = __builtin_amdgcn_readfirstlane(sel.dst);
+    }
+    {
+        const SqTreeLeafArgs& a = *sq_tree_leaf_args();
+        char* base = a.t.embeddings + static_cast<long>(b) * a.t.N * a.t.state_bytes;
+        subleq_wave_body(a.e, base + static_cast<long>(node) * a.t.state_bytes, base + static_cast<long>(dst) * a.t.state_bytes, b, lane, action, 0, Key{0, 0},
+                         nullptr, nullptr, a.next_reward, a.next_term, a.next_legal, a.obs_out, a.nf);
+    }
 }
 
 }  // namespace eaz

@@ -72,6 +72,13 @@ struct PersistSelfplay {
     char* out_states;         // SelfplayOutput fields [T,B(,A)]; any may be null
     float *out_root_value, *out_root_std, *out_value_pred, *out_ube_pred, *out_qvar;
     int32_t* out_action;
+    // on == 2: the evaluate driver (src/evaluate.py:13-57) as a device-side loop: T = max_episode_length + 1 is a cap, sbeta the constant
+    // exploitation beta (:34), the real step is a plain env.step (:47, no auto-reset); a workgroup stops when its 16 environments have all
+    // terminated (the reference's loop runs on until EVERY environment has: for an environment that is already terminal those further steps
+    // only zero its rewards field, which eval_finalize does from the workgroups' iteration counts)
+    float* eval_sum;          // [B] sum of rewards per environment (:48-50)
+    int* eval_iters;          // [1] max over the workgroups of their iteration counts = the trip count of the reference's while_loop
+    int* eval_wg_iters;       // [workgroups] iterations of each workgroup
 };
 
 struct PersistArgs {

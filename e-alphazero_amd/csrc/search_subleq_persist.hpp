@@ -84,6 +84,8 @@ struct QpMisc {
                                                 // byte, 0x38 = 1.0 or 0 (inputs 240..255: 0) -- lane (row, kq) reads its 64 k-steps as four 16-byte words and
                                                 // one v_cvt_pk_f32_fp8 makes the operands of TWO k-steps (subleq.py:88-98)
     uint8_t words[kQpTrees][48];        // row-words of the 16 observations in flight, 5 observation bits each (subleq.py:88-98)
+    float sum_reward[kQpTrees];         // evaluate mode: sum of the real steps' rewards (evaluate.py:48-50)
+    uint8_t real_term[kQpTrees];        // evaluate mode: `terminated` of the environments' current states
     uint8_t l1var[kQpTrees];            // layer-1 mode 1: which start vector the observation in flight chains from (0: the task's example rows, 1: the root blob's)
 };
 constexpr int kQpPartLd = 20;  // quarter sums [4 waves][16 rows][kQpPartLd]: slot 0 value, 1 ube, 2..17 policy logits
@@ -584,6 +586,15 @@ __global__ void __launch_bounds__(256) sq16_roots_fit_kernel(const char* __restr
     if (!ok) *misfit = 1;
 }
 
+// evaluate (PersistSelfplay::on == 2), after the launch: the reference's while_loop (evaluate.py:13-57) steps EVERY environment until the last
+// one has terminated; a workgroup stops when its own 16 have.  For an environment that is already terminal a further env.step returns the
+// same state with zero rewards (pgx wrapper A.1), so the only trace of the iterations a workgroup did not run is the blob's reward field.
+__global__ void __launch_bounds__(256) sq16_eval_finalize_kernel(char* states, int B, const int* wg_iters, const int* iters) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    if (wg_iters[b / kQpTrees] < *iters) reinterpret_cast<eaz_subleq_state*>(states + static_cast<long>(b) * sizeof(eaz_subleq_state))->reward = 0.0f;
+}
+
 // The kernel's arguments live in the kernarg segment and every phase reads them through a pointer the compiler cannot see through (an
 // empty asm redefines it per phase): a by-value struct has all its loads hoisted to the kernel entry as loop invariants, and the SGPRs
 // the phases need between them then spill through VGPR lanes (first build: 193 SGPR spills).  Re-issued scalar loads hit the scalar
@@ -601,11 +612,12 @@ __device__ __forceinline__ QpArgsPtr qp_args() {
 __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16SelfplayArgs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     int N, S, B, n_steps, max_depth;
-    bool search_only;
+    bool search_only, evaluate;
     float* logits_base;
     {
         EAZ_QP_ARGS;
         search_only = a.sp.on == 0;
+        evaluate = a.sp.on == 2;   // src/evaluate.py:13-57 as a device-side loop (PersistSelfplay)
         N = t.N; S = t.S; B = t.B; n_steps = search_only ? 1 : a.sp.T; max_depth = t.max_depth;
         logits_base = a.logits;
     }
@@ -688,6 +700,8 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             M.root_ex[j][0] = static_cast<uint32_t>(exin); M.root_ex[j][1] = static_cast<uint32_t>(exin >> 32);
             M.root_ex[j][2] = static_cast<uint32_t>(exout); M.root_ex[j][3] = static_cast<uint32_t>(exout >> 32);
             M.l1var[j] = 1;  // the root's example rows are the blob's
+            M.sum_reward[j] = 0.0f;
+            M.real_term[j] = static_cast<uint8_t>(hv.w & 0xFF);
         }
         qp_emit_obs(M.words[j], M.obytes[j], mem, exin, inaf, exout, outaf, lane, a.net.l1q_mode);
     }
@@ -701,7 +715,8 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
         uint32_t* T = trees + ti * L.tstride;
         if (!search_only) {
             if (tl == 0) {
-                M.beta[ti] = a.sp.sbeta * (B > 1 ? static_cast<float>(gb) / static_cast<float>(B - 1) : 0.0f);  // selfplay.py:105
+                M.beta[ti] = evaluate ? a.sp.sbeta * 1.0f  // evaluate.py:34 beta * ones
+                                      : a.sp.sbeta * (B > 1 ? static_cast<float>(gb) / static_cast<float>(B - 1) : 0.0f);  // selfplay.py:105
                 M.nc[ti] = kQpA < t.max_considered ? kQpA : t.max_considered;  // every action is legal (subleq.py:626)
             }
             if (tl < 16) M.invalid[ti][tl] = 0;
@@ -756,10 +771,18 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
         return ((c0 + c1) + (c2 + c3)) + M.b3[slot];
     };
     const int n_iter = n_steps * (S + 1);
+    // evaluate: cond_fn (evaluate.py:18-20) for this workgroup's environments -- every thread reads the same 16 flags
+    auto all_terminated = [&]() {
+        bool all = true;
+        for (int j = 0; j < kQpTrees; ++j) all = all && (b0 + j >= B || M.real_term[j] != 0);
+        return all;
+    };
+    int steps_done = n_steps;  // real steps this workgroup ran (evaluate: its trip count)
+    if (evaluate && (all_terminated() || n_steps <= 0)) steps_done = 0;
     floatx4 pre_lg = floatx4{0.0f, 0.0f, 0.0f, 0.0f}, pre_pr = floatx4{0.0f, 0.0f, 0.0f, 0.0f};  // prefetched logits / probabilities of path level `slot`
     int pre_node = -1;
 #pragma unroll 1
-    for (int it = search_only ? 1 : 0; it <= n_iter; ++it) {  // search only: no root forward, the caller evaluated the root
+    for (int it = search_only ? 1 : 0; it <= n_iter && steps_done > 0; ++it) {  // search only: no root forward, the caller evaluated the root
         const int step = it / (S + 1), s = it - step * (S + 1);  // s = 0: root of real step `step`; s >= 1: simulation s - 1
         int env_mode = 0;
         Key env_key{0u, 0u};
@@ -1107,15 +1130,21 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                         const int action = __builtin_amdgcn_readfirstlane(M.real_action[j]);
                         const long o = static_cast<long>(step - 1) * B + bj;
                         char* blob0 = (jlive && a.sp.out_states) ? a.sp.out_states + o * sizeof(eaz_subleq_state) : nullptr;
-                        char* blob1 = (jlive && step == n_steps) ? a.sp.states + static_cast<long>(bj) * sizeof(eaz_subleq_state) : nullptr;
-                        qp_env_step(a.e, M.root_state[j], M.root_state[j], M.root_ex[j], M.words[j], M.obytes[j], action, 1, env_key, bj, lane, blob0, blob1,
-                                    rew, term, &M.task[j], a.net.l1q_mode, &M.l1var[j]);
+                        // the caller's state batch gets the final states; evaluate: after every step (which one is the last is not known ahead)
+                        char* blob1 = (jlive && (step == n_steps || evaluate)) ? a.sp.states + static_cast<long>(bj) * sizeof(eaz_subleq_state) : nullptr;
+                        qp_env_step(a.e, M.root_state[j], M.root_state[j], M.root_ex[j], M.words[j], M.obytes[j], action, evaluate ? 2 : 1, env_key, bj, lane,
+                                    blob0, blob1, rew, term, &M.task[j], a.net.l1q_mode, &M.l1var[j]);
+                        if (evaluate && lane == 0) {  // evaluate.py:47-50: plain env.step, rewards[b, current_player] summed (single player)
+                            M.sum_reward[j] = M.sum_reward[j] + rew;
+                            M.real_term[j] = static_cast<uint8_t>(term);
+                        }
                     }
                     j = env_at(claim());
                 }
             }
             EAZ_QPSTAMP(5);
             __syncthreads();
+            if (evaluate && env_mode != 0 && all_terminated()) { steps_done = step; break; }  // cond_fn, evaluate.py:18-20 (the cap: it == n_iter)
             if (it == n_iter) break;
         }
         if (s == 0) {
@@ -1303,7 +1332,7 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             EAZ_QP_ARGS;
             EAZ_QP_TREE_LANES;
             const Key kt = fold(a.sp.key, kTagStep + static_cast<uint32_t>(step));
-            const Key gkey = fold(kt, kTagGumbel);
+            const Key gkey = evaluate ? Key{0u, 0u} : fold(kt, kTagGumbel);  // evaluate: gumbel_scale = 0 (evaluate.py:44), the noise of the host driver's key
             const float z = tl < 18 ? head_out(ti, tl < 16 ? 2 + tl : tl - 16) : 0.0f;
             if (tl == 16) M.o_value[ti] = det_tanh(z);                                // fully_connected.py:55
             if (tl == 17) M.o_ube[ti] = (0.5f * (det_tanh(z) + 1.0f)) * a.net.max_u;  // :64, :93
@@ -1335,6 +1364,12 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             if (tl < QS_WORDS) ST[tl] = M.root_state[ti][tl];
             ps_wave_sync();
         }
+    }
+    if (evaluate) {
+        EAZ_QP_ARGS;
+        if (tid < kQpTrees && b0 + tid < B) a.sp.eval_sum[b0 + tid] = M.sum_reward[tid];
+        if (tid == 0) { a.sp.eval_wg_iters[blockIdx.x] = steps_done; atomicMax(a.sp.eval_iters, steps_done); }
+        return;
     }
     if (!search_only) return;  // self-play never reads the tree arrays
     // ---------------------------------------------------------------- search only: the trees back to the mctx arrays -----------------------

@@ -467,19 +467,65 @@ def test_fc_forward_subleq_shapes(oracle, eaz, torch, W, binary, B):
 
 @pytest.mark.parametrize("kind,size,B,S,beta", [("deepsea", 8, 64, 16, 0.0), ("subleq", 16, 48, 16, -0.5), ("subleq", 16, 1, 8, 0.0),
                                                 ("subleq", 32, 3, 8, 0.0)])
-def test_evaluate_matches_oracle(oracle, eaz, torch, kind, size, B, S, beta):
-    """N2: evaluate driver (src/evaluate.py:13-57): greedy search episodes, per-episode returns and loop trip count."""
+def test_evaluate_matches_oracle(oracle, eaz, torch, kind, size, B, S, beta, kernel_variant):
+    """N2: evaluate driver (src/evaluate.py:13-57): greedy search episodes, per-episode returns and loop trip count.  Subleq-16 under the
+    default variant: the whole while_loop is ONE launch of the one-launch kernel in its evaluate mode (a device-side loop, like the
+    reference's lax.while_loop) -- asserted through the launch counters: one search-class launch, no tree / network / env launches, i.e. no
+    host round trip between the first and the last step."""
     engine, env, net, discount = _build_engine(eaz, kind, size, 7, 0.3)
     oenv, onet, _ = MG.build(kind, size, 7, 0.3)
     search = engine.Search(env, net, B, S, discount=discount, gumbel_scale=0.0)
     st = env.init(B, key=3)
     ost = oenv.init(B, key=(3, 0))
     max_len = 10 if kind == "subleq" else 1000  # config.py:123 max_episode_length for subleq
+    search.profile(True)
+    search.profile_read()
     ret, it = search.evaluate(st, exploitation_beta=beta, max_episode_length=max_len)
+    torch.cuda.synchronize()
+    prof = search.profile_read()
+    search.profile(False)
     oret, oit = oracle.evaluate(oenv, onet, ost, S, discount=discount, exploitation_beta=beta, max_episode_length=max_len)
     assert it == oit and it >= (size - 1 if kind == "deepsea" else 1)
     assert np.array_equal(ret.cpu().numpy(), oret)
     assert np.array_equal(_to_oracle_states(kind, size, st), ost)
+    if kind == "subleq" and size == 16 and kernel_variant == "persist":
+        assert prof["search"]["launches"] == 1 and prof["tree"]["launches"] == 0 and prof["net"]["launches"] == 0 and prof["gather"]["launches"] == 0, prof
+    if kind == "subleq":
+        # a second call from the (now terminal or capped) states: nothing left to do for terminated environments, trip count from the rest
+        ret2, it2 = search.evaluate(st, exploitation_beta=beta, max_episode_length=max_len)
+        oret2, oit2 = oracle.evaluate(oenv, onet, ost, S, discount=discount, exploitation_beta=beta, max_episode_length=max_len)
+        assert it2 == oit2 and np.array_equal(ret2.cpu().numpy(), oret2) and np.array_equal(_to_oracle_states(kind, size, st), ost)
+
+
+def test_evaluate_from_staggered_subleq_states(oracle, eaz, torch, kernel_variant):
+    """evaluate (src/evaluate.py:13-57) from states whose episodes end at different times -- one workgroup of the one-launch kernel is one
+    step from the end, one needs ten, a ragged third is in between, two environments start terminal: every workgroup stops at its own trip
+    count, the reference's loop runs until the last environment has terminated (the earlier ones take no-op steps that zero their rewards
+    field: sq16_eval_finalize_kernel).  Returns, trip count and every byte of the final states against the oracle."""
+    from e_alphazero_amd import engine
+
+    W, B, S = 16, 40, 12
+    dims, params, state = subleq_setup(eaz, W, seed=13, fill=0.4)
+    env = engine.EnvHandle.subleq(W, (1, 2), True, device=0)
+    net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
+    oenv = oracle.OracleEnv.subleq(W, (1, 2), True)
+    onet = oracle.OracleNet(dims["in_dim"], 256, W, eaz.params.fc_weight_list(params), hash_off=dims["hash_off"],
+                            hash_len=dims["hash_len"], bitset=state[eaz.params.HASH_MODULE]["binary_set"])
+    ost = oenv.init(B, key=(41, 0))
+    rng = np.random.default_rng(41)
+    steps = np.r_[np.full(16, 12), np.full(16, 3), np.full(8, 7)]
+    steps[[5, 20]] = 13   # two environments are already terminal (step_count >= W - 3, subleq.py:671-673)
+    for t in range(13):
+        a = rng.integers(0, W, B).astype(np.int32)
+        nxt = oenv.step(ost.copy(), a, key=(t, 0))
+        ost = np.where((t < steps)[:, None], nxt, ost)
+    search = engine.Search(env, net, B, S, discount=0.97, gumbel_scale=0.0)
+    st = torch.from_numpy(subleq_oracle_to_device(ost)).cuda()
+    ret, it = search.evaluate(st, exploitation_beta=0.0, max_episode_length=1000)
+    oret, oit = oracle.evaluate(oenv, onet, ost, S, discount=0.97, exploitation_beta=0.0, max_episode_length=1000)
+    assert it == oit == 10, (it, oit)
+    assert np.array_equal(ret.cpu().numpy(), oret)
+    assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost)
 
 
 @pytest.mark.parametrize("kind,size,B,S,kw", [

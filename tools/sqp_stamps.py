@@ -22,7 +22,9 @@ cols, rows = 5, W + 32
 in_dim, hash_off = rows * cols, W * cols
 params = eaz.params.init_fc_params(in_dim, 256, W, seed=0)
 env = engine.EnvHandle.subleq(W, (1,), True, device=0)
-net = engine.FCNet(env.ctx, in_dim, 256, W, params, eaz.params.init_hash_state(fill=0.5), hash_off=hash_off, hash_len=in_dim - hash_off)
+ORDER = os.environ.get("ORDER", "constants-first")   # layer-1 input order (bench.py --l1-order): constants-first = 5 half-rounds of layer 1, ascending = 7
+order = eaz.params.subleq_constants_first(W, True) if ORDER == "constants-first" else None
+net = engine.FCNet(env.ctx, in_dim, 256, W, params, eaz.params.init_hash_state(fill=0.5), hash_off=hash_off, hash_len=in_dim - hash_off, input_order=order)
 search = engine.Search(env, net, B, S, discount=0.97, exploration=BETA != 0.0)
 states = env.init(B, key=0)
 kw = dict(directed_exploration=True, exploration_beta=BETA) if BETA else {}
@@ -86,14 +88,21 @@ lib.eaz_diag_qp_rounds.argtypes = [C.c_void_p]
 rb = np.zeros(2048 * 64, np.uint64)
 lib.eaz_diag_qp_rounds(rb.ctypes.data)
 rr = rb.reshape(256, 8, 64).astype(np.int64)[:, 0, :]
-N1 = int(os.environ.get("N1", 7))  # half-rounds of layer 1 (sq16_l1_halves): slots head * 16 + 0 .. N1 - 1; layer 2: head * 16 + 8 .. 15
-if (fw[:, :7] > 0).all():
+N1 = 5 if order else 7  # half-rounds of layer 1 (sq16_l1_halves); stamps sit behind PAIRS of half-rounds: slots head * 16 + 1, 3, .., N1 - 2, N1 - 1
+if (fw[:, :7] > 0).all():   # (layer 1) and head * 16 + 9, 11, 13, 15 (layer 2); a stamp per half-round cost ~100 clocks each in the diagnostic build
     for h in range(3):
         prev = fw[:, 2 * h]  # F start / end of layer 2 of the head before
-        l1 = [np.median(rr[:, h * 16] - prev)] + [np.median(rr[:, h * 16 + r] - rr[:, h * 16 + r - 1]) for r in range(1, N1)]
-        l2 = [np.median(rr[:, h * 16 + 8] - fw[:, 1 + 2 * h])] + [np.median(rr[:, h * 16 + 8 + r] - rr[:, h * 16 + 7 + r]) for r in range(1, 8)]
-        print(f"   head {h}, wave 0, clocks per half-round of 8 k-steps (floor 1024): layer 1 " + " ".join(f"{x:.0f}" for x in l1) +
-              "   | H1 tile + barrier + layer 2 " + " ".join(f"{x:.0f}" for x in l2))
+        l1_slots = [1] + list(range(3, N1 - 2, 2)) + [N1 - 2, N1 - 1]
+        l1, last = [], prev
+        for sl in l1_slots:
+            l1.append(np.median(rr[:, h * 16 + sl] - last))
+            last = rr[:, h * 16 + sl]
+        l2, last = [], fw[:, 1 + 2 * h]
+        for sl in (9, 11, 13, 15):
+            l2.append(np.median(rr[:, h * 16 + sl] - last))
+            last = rr[:, h * 16 + sl]
+        print(f"   head {h}, wave 0, clocks (floor 1024 per half-round of 8 k-steps): layer 1 by stamps behind half-rounds {l1_slots}: " + " ".join(f"{x:.0f}" for x in l1) +
+              "   | H1 tile + barrier + layer 2 by pairs: " + " ".join(f"{x:.0f}" for x in l2))
 t0 = st[:, :, 0].min(axis=1)
 seg("T (first wave in -> last wave at the T/E barrier)", st[:, :, 4].max(axis=1) - t0)
 seg("E (barrier to barrier)", st[:, :, 6].max(axis=1) - st[:, :, 4].max(axis=1))
