@@ -1079,8 +1079,12 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
         s->persist_ok = s->fuse_leaf && A == kPsA && s->N < 32768 && env->dev.G < 4096 && net->dev.in_dim == env->dev.G * env->dev.G &&
                         mc >= 1 && L.total <= 160 * 1024;
         if (s->persist_ok)
-            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(search_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+            {
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(search_persist_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(search_persist_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+        }
         if (s->persist_ok) DALLOC(s->d_replay_states, static_cast<size_t>(B) * env->dev.state_bytes);
+        if (s->persist_ok) DALLOC(s->d_eval_wg, static_cast<size_t>(1 + cdiv(B, kPsTrees)));
         // Subleq-16 one-launch search (search_subleq.hpp): two forward tile sets = 76 KB of dynamic LDS (eligibility is re-checked per run)
         if (env->dev.kind == EAZ_ENV_SUBLEQ && env->dev.W == 16 && net->kind == 0 && net->dev.H == kFcH && fp_eligible(net->dev.in_dim, net->dev.A)) {
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(subleq16_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1090,7 +1094,8 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
             const QpLds QL = qp_lds(s->N, s->S);
             if (net->dev.in_dim == 240 && A == kQpA && s->N <= 250 && QL.total <= 160 * 1024) {
                 s->sqp_lds = QL.total;
-                HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(subleq16_selfplay_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, QL.total));
+                HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(subleq16_selfplay_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QL.total));
+                HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(subleq16_selfplay_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QL.total));
                 DALLOC(s->d_sq_logits, static_cast<size_t>(cdiv(B, kQpTrees)) * kQpTrees * s->N * (2 * kQpA));
                 DALLOC(s->d_sq_l1init, static_cast<size_t>(kQpL1Tab) + static_cast<size_t>(cdiv(B, kQpTrees)) * kQpTrees * 3 * kFcH);
                 DALLOC(s->d_eval_wg, static_cast<size_t>(1 + cdiv(B, kQpTrees)));
@@ -1203,7 +1208,8 @@ static int persist_launch(eaz_search* s, hipStream_t st, const PersistSelfplay* 
     pa.head[0] = 0; pa.head[1] = 1; pa.head[2] = s->opts.exploration ? 3 : 2;  // context.py:132
     pa.amap_lds = s->env->dev.G * s->env->dev.G <= kPsAmapMax;
     pa.stamps = s->d_stamps;
-    search_persist_kernel<<<cdiv(s->B, kPsTrees), kPsThreads, s->persist_lds, st>>>(pa);
+    if (pa.sp.on == 2) search_persist_kernel<true><<<cdiv(s->B, kPsTrees), kPsThreads, s->persist_lds, st>>>(pa);
+    else search_persist_kernel<false><<<cdiv(s->B, kPsTrees), kPsThreads, s->persist_lds, st>>>(pa);
     LAUNCH_OK();
     return 0;
 }
@@ -1302,7 +1308,8 @@ static int sqp_launch(eaz_search* s, const PersistSelfplay& sp, hipStream_t st) 
         sq16_l1_table_kernel<<<dim3(6, 3), 256, 0, st>>>(a.net, a.heads, a.l1init);
         LAUNCH_OK();
     }
-    subleq16_selfplay_kernel<<<cdiv(s->B, kQpTrees), kQpThreads, s->sqp_lds, st>>>(a);
+    if (a.sp.on == 2) subleq16_selfplay_kernel<true><<<cdiv(s->B, kQpTrees), kQpThreads, s->sqp_lds, st>>>(a);
+    else subleq16_selfplay_kernel<false><<<cdiv(s->B, kQpTrees), kQpThreads, s->sqp_lds, st>>>(a);
     LAUNCH_OK();
     return 0;
 }
@@ -1926,6 +1933,32 @@ extern "C" int eaz_evaluate_run(eaz_search* s, float exploitation_beta, int max_
     HIP_OK(hipSetDevice(s->ctx->device));
     hipStream_t st = S(stream);
     const int B = s->B;
+    if (s->persist_ok && g_persist && max_episode_length >= 0 && max_episode_length < (1 << 24)) {
+        // DeepSea: the whole while_loop (evaluate.py:13-57) as ONE launch of search_persist_kernel in its evaluate mode (search_persist.hpp)
+        PersistSelfplay sp;
+        std::memset(&sp, 0, sizeof sp);
+        sp.on = 2; sp.T = max_episode_length + 1;  // cond_fn: counter <= max_episode_length
+        sp.sbeta = exploitation_beta; sp.gumbel_scale = s->opts.gumbel_scale;
+        sp.states = static_cast<char*>(d_states);
+        sp.eval_sum = d_sum_rewards; sp.eval_iters = s->d_eval_wg; sp.eval_wg_iters = s->d_eval_wg + 1;
+        HIP_OK(hipMemsetAsync(s->d_eval_wg, 0, sizeof(int) * (1 + cdiv(B, kPsTrees)), st));
+        {
+            ProfScope ps(s, EAZ_K_SEARCH, st);
+            const int rc = persist_launch(s, st, &sp);
+            if (rc) return rc;
+        }
+        {
+            ProfScope ps(s, EAZ_K_MISC, st);
+            eval_finalize_kernel<<<cdiv(B, 256), 256, 0, st>>>(static_cast<char*>(d_states), static_cast<long>(sizeof(eaz_deepsea_state)), B, kPsTrees,
+                                                               s->d_eval_wg + 1, s->d_eval_wg);
+            LAUNCH_OK();
+        }
+        if (h_iterations) {
+            HIP_OK(hipMemcpyAsync(h_iterations, s->d_eval_wg, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+        }
+        return 0;
+    }
     if (g_persist == 1 && sqp_eligible(s) && max_episode_length >= 0 && max_episode_length < (1 << 24)) {
         // Subleq-16: the whole while_loop (evaluate.py:13-57) as ONE launch of the one-launch kernel in its evaluate mode -- no host round trip
         // between the first and the last step (the host driver below copies a counter back and synchronises after every real step)
@@ -1947,7 +1980,8 @@ extern "C" int eaz_evaluate_run(eaz_search* s, float exploitation_beta, int max_
             }
             {
                 ProfScope ps(s, EAZ_K_MISC, st);
-                sq16_eval_finalize_kernel<<<cdiv(B, 256), 256, 0, st>>>(static_cast<char*>(d_states), B, s->d_eval_wg + 1, s->d_eval_wg);
+                eval_finalize_kernel<<<cdiv(B, 256), 256, 0, st>>>(static_cast<char*>(d_states), static_cast<long>(sizeof(eaz_subleq_state)), B, kQpTrees,
+                                                                   s->d_eval_wg + 1, s->d_eval_wg);
                 LAUNCH_OK();
             }
             if (h_iterations) {

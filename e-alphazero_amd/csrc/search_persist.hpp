@@ -128,6 +128,8 @@ struct PersistMisc {
     float edge[kPsTrees][16][2];  // backward: (reward, discount) of the 16 path levels of the chunk being folded
     float root_v[kPsTrees], root_u[kPsTrees];  // fused self-play: value / ube prediction of the root (SelfplayOutput)
     uint32_t root_state[kPsTrees];             // fused self-play: the environment's current state, packed
+    float sum_reward[kPsTrees];                // evaluate mode (PersistSelfplay::on == 2): sum of the real steps' rewards (evaluate.py:48-50)
+    int real_term[kPsTrees];                   // evaluate mode: `terminated` of the environments' current states (1 for trees beyond the batch)
 };
 static_assert(sizeof(PersistMisc) <= kPsMiscBytes, "misc block too small");
 
@@ -251,6 +253,9 @@ __device__ __forceinline__ void ps_round(floatx4 (&acc)[4], floatx4 (&Bq)[kPsDep
     }
 }
 
+// EVAL: the evaluate mode (PersistSelfplay::on == 2) is its own instantiation, so that self-play and search pay nothing for it (as a run-time
+// flag it cost the C2 launch 1.8 %: 34.1 -> 34.7 ms)
+template <bool EVAL>
 __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const TreeDev& t = a.t;
@@ -292,8 +297,20 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
 #pragma unroll
         for (int c = 0; c < 4; ++c) W3s[(h * 4 + c) * kFcH + k] = c < No ? W3[k * No + c] : 0.0f;
     }
-    __syncthreads();
     const bool fused = a.sp.on != 0;
+    constexpr bool evaluate = EVAL;  // src/evaluate.py:13-57 as a device-side loop (PersistSelfplay::on == 2)
+    if (evaluate && tid < kPsTrees) {
+        M.sum_reward[tid] = 0.0f;
+        M.real_term[tid] = tree0 + tid < B ? ds_load(a.sp.states + static_cast<long>(tree0 + tid) * sizeof(eaz_deepsea_state)).terminated != 0 : 1;
+    }
+    __syncthreads();
+    // evaluate: cond_fn (evaluate.py:18-20) for this workgroup's environments -- every thread reads the same 16 flags behind a barrier
+    auto all_terminated = [&]() {
+        bool all = true;
+        for (int j = 0; j < kPsTrees; ++j) all = all && M.real_term[j] != 0;
+        return all;
+    };
+    const bool ev_skip = evaluate && (all_terminated() || a.sp.T <= 0);  // nothing to do: trip count 0
     if (tid < kPsTrees && !fused) {
         const int i = tid, b = tree0 + i < B ? tree0 + i : B - 1;  // trees beyond the batch mirror the last one and are never written back
         uint32_t* R = trees + i * L.tstride;
@@ -335,8 +352,12 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
         const float* W1g[2] = {a.net.w[hidv[1] * 3] + 4 * lane, a.net.w[hidv[2] * 3] + 4 * lane};
         __builtin_amdgcn_s_setprio(3);  // the youngest wave of the workgroup loses every issue arbitration against its SIMD partner otherwise
         const int n_fwd = (fused ? a.sp.T : 1) * (S + (fused ? 1 : 0));  // fused: every real step starts with the root's forward
-        for (int f = 0; f < n_fwd; ++f) {
+        for (int f = 0; f < n_fwd && !ev_skip; ++f) {
             const int sim = fused ? f % (S + 1) - 1 : f;
+            if (evaluate && sim == -1 && f > 0) {
+                __syncthreads();  // S0 (evaluate): the real step before wrote its `terminated` flags
+                if (all_terminated()) break;
+            }
             EAZ_PSTAMP(0);
             __syncthreads();  // S1
             EAZ_PSTAMP(4);
@@ -424,7 +445,8 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
         const Group<1, kPsA> g = make_group<1, kPsA>(gb, 0, kPsA);
         const bool tree_live = tree0 + ti < B;  // trees beyond the batch mirror the last one; they never store outside LDS
         // fused self-play: beta * linspace(0, 1, B)[b] (selfplay.py:105, root_prep_kernel); search only: the caller's per-tree beta
-        const float beta = fused ? a.sp.sbeta * (B > 1 ? static_cast<float>(gb) / static_cast<float>(B - 1) : 0.0f) : M.beta[ti];
+        const float beta = evaluate ? a.sp.sbeta * 1.0f  // evaluate.py:34 beta * ones
+                           : (fused ? a.sp.sbeta * (B > 1 ? static_cast<float>(gb) / static_cast<float>(B - 1) : 0.0f) : M.beta[ti]);
         const bool need_var = beta != 0.0f;
         auto amap_flip = [&](const eaz_deepsea_state& st) -> int {
             const int idx = ps_ds_row(st, env.G) * env.G + st.pos;                                         // deep_sea.py:62
@@ -432,7 +454,8 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
         };
 
         const int n_steps = fused ? a.sp.T : 1;
-        for (int step = 0; step < n_steps; ++step) {
+        int steps_done = ev_skip ? 0 : n_steps;  // evaluate: this workgroup's trip count
+        for (int step = 0; step < n_steps && !ev_skip; ++step) {
         Key kt{0u, 0u};
         if (fused) {
             // ---- a new real step: empty trees (mctx instantiate_tree_from_root, A.3: ints -1 / 0, floats 0), the root's observation ----
@@ -699,7 +722,7 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
                 if (tj == 0) {
                     const float root_v = M.o_value[ti];
                     const float root_u = ube_combine(M.o_ube[ti], M.o_nov[ti], t.max_u);                  // fully_connected.py:92-96
-                    const Key gkey = fold(kt, kTagGumbel);
+                    const Key gkey = evaluate ? Key{0u, 0u} : fold(kt, kTagGumbel);  // evaluate: gumbel_scale = 0 (evaluate.py:44), the host driver's key
                     float lg[kPsA], gum[kPsA];
 #pragma unroll
                     for (int c = 0; c < kPsA; ++c) {
@@ -778,8 +801,13 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
             }
             // vmap(auto_reset(env.step, env.init)) (selfplay.py:26-75,135): a finished episode restarts, anything else steps
             const eaz_deepsea_state cur = ps_unpack(M.root_state[ti]);
-            const eaz_deepsea_state nxt = (cur.terminated | cur.truncated) ? ds_init() : ps_ds_step(cur, act, amap_flip(cur), env.G);
+            // evaluate: a plain env.step (evaluate.py:47; a finished episode takes no-op steps with zero rewards), rewards summed (:48-50)
+            const eaz_deepsea_state nxt = (!evaluate && (cur.terminated | cur.truncated)) ? ds_init() : ps_ds_step(cur, act, amap_flip(cur), env.G);
             M.root_state[ti] = ps_pack(nxt);
+            if (evaluate) {
+                M.sum_reward[ti] = M.sum_reward[ti] + nxt.reward;
+                if (tree_live) M.real_term[ti] = nxt.terminated != 0;
+            }
             if (tree_live) {
                 const long o = static_cast<long>(step) * B + gb;
                 if (a.sp.out_value_pred) a.sp.out_value_pred[o] = M.root_v[ti];
@@ -789,11 +817,19 @@ __global__ void __launch_bounds__(kPsThreads) search_persist_kernel(PersistArgs 
                 if (a.sp.out_action) a.sp.out_action[o] = act;
                 if (a.sp.out_qvar) { a.sp.out_qvar[o * kPsA] = qvar[0]; a.sp.out_qvar[o * kPsA + 1] = qvar[1]; }
                 if (a.sp.out_states) ds_store(a.sp.out_states + o * sizeof(eaz_deepsea_state), nxt);
-                if (step == n_steps - 1) ds_store(a.sp.states + static_cast<long>(gb) * sizeof(eaz_deepsea_state), nxt);
+                if (step == n_steps - 1 || evaluate) ds_store(a.sp.states + static_cast<long>(gb) * sizeof(eaz_deepsea_state), nxt);
             }
         }
         if (fused) ps_wave_sync();
+        if (evaluate && step + 1 < n_steps) {
+            __syncthreads();  // S0 (the helper waves hold the same barrier in front of the next root forward)
+            if (all_terminated()) { steps_done = step + 1; break; }  // cond_fn, evaluate.py:18-20
+        }
         }  // real steps
+        if (evaluate) {
+            if (tj == 0 && tree_live) a.sp.eval_sum[gb] = M.sum_reward[ti];
+            if (tid == 0) { a.sp.eval_wg_iters[blockIdx.x] = steps_done; atomicMax(a.sp.eval_iters, steps_done); }
+        }
     }
 
     if (fused) return;  // self-play never reads the tree arrays

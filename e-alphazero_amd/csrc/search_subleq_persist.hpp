@@ -588,11 +588,12 @@ __global__ void __launch_bounds__(256) sq16_roots_fit_kernel(const char* __restr
 
 // evaluate (PersistSelfplay::on == 2), after the launch: the reference's while_loop (evaluate.py:13-57) steps EVERY environment until the last
 // one has terminated; a workgroup stops when its own 16 have.  For an environment that is already terminal a further env.step returns the
-// same state with zero rewards (pgx wrapper A.1), so the only trace of the iterations a workgroup did not run is the blob's reward field.
-__global__ void __launch_bounds__(256) sq16_eval_finalize_kernel(char* states, int B, const int* wg_iters, const int* iters) {
+// same state with zero rewards (pgx wrapper A.1), so the only trace of the iterations a workgroup did not run is the blob's reward field
+// (every state blob starts with {int32 step_count; int32 aux; float reward0; ...}, envs.hpp StateHeader).
+__global__ void __launch_bounds__(256) eval_finalize_kernel(char* states, long stride, int B, int trees_per_wg, const int* wg_iters, const int* iters) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
-    if (wg_iters[b / kQpTrees] < *iters) reinterpret_cast<eaz_subleq_state*>(states + static_cast<long>(b) * sizeof(eaz_subleq_state))->reward = 0.0f;
+    if (wg_iters[b / trees_per_wg] < *iters) reinterpret_cast<StateHeader*>(states + static_cast<long>(b) * stride)->reward0 = 0.0f;
 }
 
 // The kernel's arguments live in the kernarg segment and every phase reads them through a pointer the compiler cannot see through (an
@@ -609,15 +610,18 @@ __device__ __forceinline__ QpArgsPtr qp_args() {
     const Sq16SelfplayArgs& a = *qp_args();  \
     const TreeDev& t = a.t
 
+// EVAL: the evaluate mode (PersistSelfplay::on == 2) is its own instantiation, so that self-play and search pay nothing for it (as a run-time
+// flag it cost the C3 launch 1.7 %)
+template <bool EVAL>
 __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16SelfplayArgs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     int N, S, B, n_steps, max_depth;
-    bool search_only, evaluate;
+    bool search_only;
+    constexpr bool evaluate = EVAL;   // src/evaluate.py:13-57 as a device-side loop (PersistSelfplay::on == 2)
     float* logits_base;
     {
         EAZ_QP_ARGS;
         search_only = a.sp.on == 0;
-        evaluate = a.sp.on == 2;   // src/evaluate.py:13-57 as a device-side loop (PersistSelfplay)
         N = t.N; S = t.S; B = t.B; n_steps = search_only ? 1 : a.sp.T; max_depth = t.max_depth;
         logits_base = a.logits;
     }

@@ -5,7 +5,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import subleq_device_to_oracle, subleq_oracle_to_device, subleq_setup, deepsea_setup
+from helpers import subleq_device_to_oracle, subleq_oracle_to_device, subleq_setup, deepsea_setup, random_states_deepsea
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("kernel_variant")]
 ATOL = 1e-5
@@ -488,13 +488,22 @@ def test_evaluate_matches_oracle(oracle, eaz, torch, kind, size, B, S, beta, ker
     assert it == oit and it >= (size - 1 if kind == "deepsea" else 1)
     assert np.array_equal(ret.cpu().numpy(), oret)
     assert np.array_equal(_to_oracle_states(kind, size, st), ost)
-    if kind == "subleq" and size == 16 and kernel_variant == "persist":
+    if (kind == "deepsea" and kernel_variant in ("persist", "persist-step")) or (kind == "subleq" and size == 16 and kernel_variant == "persist"):
         assert prof["search"]["launches"] == 1 and prof["tree"]["launches"] == 0 and prof["net"]["launches"] == 0 and prof["gather"]["launches"] == 0, prof
-    if kind == "subleq":
+    if kind in ("subleq", "deepsea"):
         # a second call from the (now terminal or capped) states: nothing left to do for terminated environments, trip count from the rest
         ret2, it2 = search.evaluate(st, exploitation_beta=beta, max_episode_length=max_len)
         oret2, oit2 = oracle.evaluate(oenv, onet, ost, S, discount=discount, exploitation_beta=beta, max_episode_length=max_len)
         assert it2 == oit2 and np.array_equal(ret2.cpu().numpy(), oret2) and np.array_equal(_to_oracle_states(kind, size, st), ost)
+    if kind == "deepsea":
+        # staggered starts: environments at different depths (and a cap below the episode length) end at different times per workgroup
+        st3 = torch.from_numpy(random_states_deepsea(size, B, seed=5)).cuda()
+        ost3 = st3.cpu().numpy().copy()
+        for cap in (1000, 2):
+            a, b = st3.clone(), ost3.copy()
+            ret3, it3 = search.evaluate(a, exploitation_beta=beta, max_episode_length=cap)
+            oret3, oit3 = oracle.evaluate(oenv, onet, b, S, discount=discount, exploitation_beta=beta, max_episode_length=cap)
+            assert it3 == oit3 and np.array_equal(ret3.cpu().numpy(), oret3) and np.array_equal(a.cpu().numpy(), b), cap
 
 
 def test_evaluate_from_staggered_subleq_states(oracle, eaz, torch, kernel_variant):
