@@ -648,7 +648,8 @@ def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
             "why": "DeepSea's env.step is a few integer operations on a 16-byte state: the search kernel steps the chosen edge itself (child state "
                    "stays in LDS) and hands the forward the flat index of the one-hot observation -- no leaf-gather launch and no observation row "
                    "exists in the timed path.  At this batch size the standalone kernel of the unfused variant moves 4.3 MB per launch, below "
-                   "launch latency (0.16 of the HBM roof, profiles/r01_f_*); the target is meaningful only for C3 / C4 (extra.c3, extra.c4)"}
+                   "launch latency (4.3 MB per launch: 0.06-0.07 of the HBM roof); with enough trees per launch to be bandwidth-bound the same kernel "
+                   "reaches 0.43-0.44 of the 8 TB/s peak (>= 64 k trees, tools/gather_sweep.py, profiles/r04_d_gather_sweep.txt, DESIGN.md 5)"}
     else:
         sims = max(T_instr * n_instr * S, 1)
         g_ms = prof["gather"]["ms"] / sims

@@ -1376,7 +1376,7 @@ static int recurrent_launch(eaz_search* s, hipStream_t st) {
     {
         ProfScope ps(s, EAZ_K_GATHER, st);
         if (env->dev.kind == EAZ_ENV_DEEPSEA) {
-            leaf_gather_deepsea_kernel<<<cdiv(static_cast<long>(B) * 64, 256), 256, 0, st>>>(
+            leaf_gather_deepsea_kernel<<<cdiv(static_cast<long>(cdiv(B, kLgTrees)) * 64, 256), 256, 0, st>>>(
                 env->dev, s->tree, s->d_obs, s->d_next_reward, s->d_next_term, s->d_next_legal);
             LAUNCH_OK();
         } else if (env->dev.kind == EAZ_ENV_CONNECT4) {
@@ -2206,7 +2206,7 @@ extern "C" int eaz_profile_replay(eaz_search* s, int cls, int iters, double* ms_
             return persist_launch(s, st, &sp);
         }
         if (cls == EAZ_K_NET) return fused ? fc_onehot_launch(s->net, s->B, s->d_leaf_hot, s->d_novelty, o, hl, st) : fc_launch(s->net, s->B, s->d_obs, o, hl, st, s->d_obs_perm);
-        leaf_gather_deepsea_kernel<<<cdiv(static_cast<long>(s->B) * 64, 256), 256, 0, st>>>(s->env->dev, s->tree, s->d_obs, s->d_next_reward,
+        leaf_gather_deepsea_kernel<<<cdiv(static_cast<long>(cdiv(s->B, kLgTrees)) * 64, 256), 256, 0, st>>>(s->env->dev, s->tree, s->d_obs, s->d_next_reward,
                                                                                           s->d_next_term, s->d_next_legal);
         LAUNCH_OK();
         return 0;

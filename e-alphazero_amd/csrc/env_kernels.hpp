@@ -84,34 +84,50 @@ __global__ void __launch_bounds__(256) deepsea_step_kernel(EnvDev e, const char*
     if (out_copy) ds_store(out_copy + static_cast<long>(b) * sizeof(eaz_deepsea_state), s);
 }
 
-// leaf gather + env.step + observation emit: one wavefront per tree (the UNFUSED DeepSea path; by default the tree kernel steps
-// the environment itself and no observation row is written, tree.hpp TreeDev::fuse_env)
+// leaf gather + env.step + observation emit (the UNFUSED DeepSea path; by default the tree kernel steps the environment itself and no
+// observation row is written, tree.hpp TreeDev::fuse_env).  One wavefront handles kLgTrees consecutive trees: the scalar-sized loads of the
+// (parent, action, child slot) triples and parent states of all of them are in flight together, then every lane writes 16 bytes of each
+// tree's 1 KiB observation row (one fully coalesced 1 KiB store instruction per tree).  Round 4: with ONE tree per wavefront the launch
+// topped out at 0.37 of the HBM roof however large the batch (tools/gather_sweep.py: a quarter of a million wavefronts of one store
+// instruction each are bound by the rate at which wavefronts start, not by the memory system).
+constexpr int kLgTrees = 4;
 __global__ void __launch_bounds__(256) leaf_gather_deepsea_kernel(EnvDev e, TreeDev t, uint8_t* obs, float* next_reward,
                                                                   uint8_t* next_term, uint8_t* next_legal) {
-    const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (b >= t.B) return;
-    const int parent = t.sim_parent[b], action = t.sim_action[b], nxt = t.sim_next[b];
-    char* base = t.embeddings + static_cast<long>(b) * t.N * sizeof(eaz_deepsea_state);
-    const eaz_deepsea_state s = ds_step(e, ds_load(base + static_cast<long>(parent) * sizeof(eaz_deepsea_state)), action);
-    if (lane == 0) {
-        ds_store(base + static_cast<long>(nxt) * sizeof(eaz_deepsea_state), s);
-        next_reward[b] = s.reward;          // rewards[b, current_player], single player (deep_sea.py:100-102)
-        next_term[b] = s.terminated;
-    }
-    if (lane < e.A) next_legal[static_cast<long>(b) * e.A + lane] = 1;  // legal_action_mask all true (deep_sea.py:19)
-    // observation row (deep_sea.py:66-70) -> contiguous inference batch
-    const int D = e.obs_dim;
-    uint8_t* row = obs + static_cast<long>(b) * D;
-    const int hot = ds_hot_index(e, s);
-    if (D % 16 == 0) {
-        for (int o0 = lane * 16; o0 < D; o0 += 64 * 16) {
-            uint32_t w[4] = {0u, 0u, 0u, 0u};
-            const int o = hot - o0;
-            if (o >= 0 && o < 16) w[o >> 2] = 1u << (8 * (o & 3));
-            *reinterpret_cast<uint4*>(row + o0) = make_uint4(w[0], w[1], w[2], w[3]);
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int b0 = w * kLgTrees;
+    if (b0 >= t.B) return;
+    int hot[kLgTrees];
+#pragma unroll
+    for (int k = 0; k < kLgTrees; ++k) {
+        const bool live = b0 + k < t.B;
+        const int b = live ? b0 + k : t.B - 1;
+        const int parent = t.sim_parent[b], action = t.sim_action[b], nxt = t.sim_next[b];
+        char* base = t.embeddings + static_cast<long>(b) * t.N * sizeof(eaz_deepsea_state);
+        const eaz_deepsea_state s = ds_step(e, ds_load(base + static_cast<long>(parent) * sizeof(eaz_deepsea_state)), action);
+        if (lane == 0 && live) {
+            ds_store(base + static_cast<long>(nxt) * sizeof(eaz_deepsea_state), s);
+            next_reward[b] = s.reward;          // rewards[b, current_player], single player (deep_sea.py:100-102)
+            next_term[b] = s.terminated;
         }
-    } else {
-        for (int i = lane; i < D; i += 64) row[i] = static_cast<uint8_t>(i == hot);
+        if (lane < e.A && live) next_legal[static_cast<long>(b) * e.A + lane] = 1;  // legal_action_mask all true (deep_sea.py:19)
+        hot[k] = live ? ds_hot_index(e, s) : -1;
+    }
+    // observation rows (deep_sea.py:66-70) -> contiguous inference batch
+    const int D = e.obs_dim;
+#pragma unroll
+    for (int k = 0; k < kLgTrees; ++k) {
+        if (b0 + k >= t.B) break;
+        uint8_t* row = obs + static_cast<long>(b0 + k) * D;
+        if (D % 16 == 0) {
+            for (int o0 = lane * 16; o0 < D; o0 += 64 * 16) {
+                uint32_t wv[4] = {0u, 0u, 0u, 0u};
+                const int o = hot[k] - o0;
+                if (o >= 0 && o < 16) wv[o >> 2] = 1u << (8 * (o & 3));
+                *reinterpret_cast<uint4*>(row + o0) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+            }
+        } else {
+            for (int i = lane; i < D; i += 64) row[i] = static_cast<uint8_t>(i == hot[k]);
+        }
     }
 }
 

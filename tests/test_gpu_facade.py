@@ -145,6 +145,36 @@ def test_subleq_facade_and_uniformrandomplay(eaz, torch):
         api.Subleq(tasks=[1], word_size=8)
 
 
+def test_subleq_facade_layer1_constants_first_switch(oracle, eaz, torch):
+    """Config.layer1_constants_first (NOT a field of the reference: the numerics switch of include/eaz.h eaz_net_set_input_order) through the
+    reference-named surface: api.selfplay on Subleq-16 with the switch on equals the oracle under eazo_net_set_input_order, forward.apply
+    follows the same order, and the switch off gives the oracle's default-order result."""
+    from e_alphazero_amd import api, engine
+    from helpers import subleq_device_to_oracle
+
+    W, B, S, T = 16, 24, 16, 4
+    env = api.Subleq(tasks=[api.SubleqTask.NEGATION_POSITIVE], word_size=W, use_binary_encoding=True)
+    for switch in (True, False):
+        config, forward, model, context = _setup(api, env, B, S, T, env_id="subleq-16", discount=0.97, layer1_constants_first=switch)
+        states0 = api.vmap(env.init)(api.random.split(api.random.PRNGKey(5), B))
+        ost = subleq_device_to_oracle(states0.data.cpu().numpy(), W)
+        _, out = api.selfplay(model, config, context, states0, api.random.PRNGKey(11))
+        oenv = oracle.OracleEnv.subleq(W, (1,), True)
+        onet = oracle.OracleNet(forward.in_dim, 256, W, eaz.params.fc_weight_list(model[0]), hash_off=forward.hash_off,
+                                hash_len=forward.in_dim - forward.hash_off, bitset=model[1][eaz.params.HASH_MODULE]["binary_set"])
+        if switch:
+            onet.set_input_order(eaz.params.subleq_constants_first(W, True))
+        assert (forward.net(model).input_order is not None) == switch
+        # forward.apply on the initial observations
+        obs = oenv.observe(ost)
+        (ex, xp, v, u, nov), _ = forward.apply(model[0], model[1], torch.from_numpy(obs).cuda().reshape(B, 48, 5))
+        oex, oxp, ov, ou, onov = onet.forward(obs)
+        assert np.array_equal(ex.cpu().numpy(), oex) and np.array_equal(v.cpu().numpy(), ov) and np.array_equal(u.cpu().numpy(), ou)
+        ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=engine.key_pair(api.random.PRNGKey(11)), discount=0.97)
+        assert np.array_equal(subleq_device_to_oracle(out.state.data.cpu().numpy(), W), ref["state"]), switch
+        assert np.array_equal(out.root_value.cpu().numpy(), ref["root_value"]), switch
+
+
 def test_reanalyze_and_evaluate_facade(eaz, torch):
     from e_alphazero_amd import api
 

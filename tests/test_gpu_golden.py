@@ -22,6 +22,17 @@ def torch():
     return t
 
 
+# The oracle's answer for a test case does not depend on the kernel variant the device runs (tests/conftest.py): computed once per case and
+# reused by the other variants -- the CPU oracle is most of this file's run time (and the GPU box of the driver has fewer host cores to spare).
+_ORACLE_CACHE = {}
+
+
+def _cached(key, fn):
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = fn()
+    return _ORACLE_CACHE[key]
+
+
 def _build_engine(eaz, kind, size, seed, fill, constants_first=False):
     from e_alphazero_amd import engine
 
@@ -198,7 +209,10 @@ def test_subleq16_selfplay_crosses_episode_boundaries(oracle, eaz, torch, flags,
     ost = oenv.init(B, key=(13, 0))
     assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost)
     out = search.selfplay(st, T, key=57, **flags)
-    ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(57, 0), discount=0.97, **flags)
+    ost_in = ost.copy()
+    ref, ost = _cached(("sq16_crossing", tuple(sorted(flags.items())), full_obs_hash, constants_first),
+                       lambda: (oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(57, 0), discount=0.97, **flags), ost))
+    assert ost_in.shape == ost.shape
     assert np.array_equal(out["action"].cpu().numpy(), ref["action"])
     assert np.array_equal(subleq_device_to_oracle(out["state"].cpu().numpy(), W), ref["state"])
     assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost)
@@ -622,13 +636,15 @@ def test_connect4_selfplay_matches_oracle(oracle, eaz, torch, flags):
     st = env.init(B, key=2)
     ost = oenv.init(B, key=(2, 0))
     out = search.selfplay(st, T, key=31, **flags)
-    ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(31, 0), two_player=True, **flags)
+    ref = _cached(("c4_selfplay", tuple(sorted(flags.items()))),
+                  lambda: oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(31, 0), two_player=True, **flags))
     assert np.array_equal(out["action"].cpu().numpy(), ref["action"])
     assert np.array_equal(out["state"].cpu().numpy(), ref["state"])
     for k in ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction", "q_values_epistemic_variance"):
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
     ret, it = engine.Search(env, net, B, S, discount=0.997, two_players_game=True, gumbel_scale=0.0).evaluate(env.init(B, key=5), max_episode_length=50)
-    oret, oit = oracle.evaluate(oenv, onet, oenv.init(B, key=(5, 0)), S, discount=0.997, two_player=True, max_episode_length=50)
+    oret, oit = _cached(("c4_selfplay_eval",), lambda: oracle.evaluate(oenv, onet, oenv.init(B, key=(5, 0)), S, discount=0.997, two_player=True,
+                                                                      max_episode_length=50))
     assert it == oit and np.array_equal(ret.cpu().numpy(), oret)
 
 
@@ -641,7 +657,8 @@ def test_connect4_evaluate_matches_oracle(oracle, eaz, torch):
     st = env.init(B, key=4)
     ost = oenv.init(B, key=(4, 0))
     ret, it = search.evaluate(st, exploitation_beta=0.0, max_episode_length=50)
-    oret, oit = oracle.evaluate(oenv, onet, ost, S, discount=0.997, two_player=True, exploitation_beta=0.0, max_episode_length=50)
+    (oret, oit), ost = _cached(("c4_evaluate",), lambda: (oracle.evaluate(oenv, onet, ost, S, discount=0.997, two_player=True, exploitation_beta=0.0,
+                                                                         max_episode_length=50), ost))
     assert it == oit and 7 <= it <= 42
     assert np.array_equal(ret.cpu().numpy(), oret)
     assert np.array_equal(st.cpu().numpy(), ost)
