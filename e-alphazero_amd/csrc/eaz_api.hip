@@ -1198,6 +1198,7 @@ static int ensure_cleared(eaz_search* s, hipStream_t st) {
 }
 
 static int persist_launch(eaz_search* s, hipStream_t st, const PersistSelfplay* sp = nullptr) {
+    if (s->net->dev.in_perm) return fail("a layer-1 input order (eaz_net_set_input_order) is meaningless for one-hot observations: not supported with DeepSea");
     PersistArgs pa;
     if (sp) pa.sp = *sp;
     else std::memset(&pa.sp, 0, sizeof pa.sp);

@@ -90,7 +90,10 @@ __global__ void __launch_bounds__(256) deepsea_step_kernel(EnvDev e, const char*
 // tree's 1 KiB observation row (one fully coalesced 1 KiB store instruction per tree).  Round 4: with ONE tree per wavefront the launch
 // topped out at 0.37 of the HBM roof however large the batch (tools/gather_sweep.py: a quarter of a million wavefronts of one store
 // instruction each are bound by the rate at which wavefronts start, not by the memory system).
-constexpr int kLgTrees = 4;
+#ifndef EAZ_LG_TREES
+#define EAZ_LG_TREES 4
+#endif
+constexpr int kLgTrees = EAZ_LG_TREES;
 __global__ void __launch_bounds__(256) leaf_gather_deepsea_kernel(EnvDev e, TreeDev t, uint8_t* obs, float* next_reward,
                                                                   uint8_t* next_term, uint8_t* next_legal) {
     const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;

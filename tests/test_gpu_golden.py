@@ -942,7 +942,16 @@ def test_unsupported_shapes_fail_loudly(eaz, torch):
         engine.FCNet(env.ctx, 64, 256, 2, eaz.params.init_fc_params(64, 256, 2, seed=0), hash_off=2, hash_len=61)
     net = engine.FCNet(env.ctx, 64, 256, 2, eaz.params.init_fc_params(64, 256, 2, seed=0))
     with pytest.raises(eaz.EazError, match="observation size"):
-        engine.Search(engine.EnvHandle.deepsea(4, np.zeros((4, 4), np.uint8), device=0), net, 8, 4)@pytest.mark.gpu
+        engine.Search(engine.EnvHandle.deepsea(4, np.zeros((4, 4), np.uint8), device=0), net, 8, 4)
+    # a layer-1 input order is meaningless for one-hot observations: the DeepSea paths refuse a network that carries one
+    net.set_input_order([(32, 32), (0, 32)])
+    search = engine.Search(env, net, 8, 4)
+    with pytest.raises(eaz.EazError, match="one-hot"):
+        search.selfplay(env.init(8), 1, key=0)
+    net.set_input_order(None)
+    search.selfplay(env.init(8), 1, key=0)
+
+
 @pytest.mark.parametrize("W", [16, 32])
 def test_subleq_lowest_bytes_reward(oracle, eaz, torch, W):
     """Subleq(reward_fn=lowest_bytes) (subleq.py:540-542) on both step kernels (one wavefront per environment at word_size 16, one lane
