@@ -227,7 +227,10 @@ enum {
     EAZ_F_CHILDREN_VALUES_VAR = 13, EAZ_F_CHILDREN_REWARDS_VAR = 14, EAZ_F_EMBEDDINGS = 15, EAZ_F_ROOT_GUMBEL = 16,
     EAZ_F_BETA = 17, EAZ_F_COUNT = 18
 };
-/* device pointer + shape ([B,N], [B,N,A], [B,N,state_bytes], [B,A] or [B]; unused dims = 0) + element size */
+/* device pointer + shape ([B,N], [B,N,A], [B,N,state_bytes], [B,A] or [B]; unused dims = 0) + element size.  The arrays hold the tree of the
+ * last eaz_search_begin / _simulate / _run / _expand sequence (every field of every node slot, mctx's initial values where a slot was never
+ * expanded).  After eaz_selfplay_run / eaz_evaluate_run they are SCRATCH (the one-launch kernels never touch them; the per-step driver leaves
+ * the tree of its last real step). */
 EAZ_API int eaz_search_tree_view(eaz_search* s, int field_id, void** d_ptr, int64_t shape[3], int* elem_bytes);
 
 /* TEST HOOK (no reference counterpart): fills the search's select scratch (the recorded root-to-leaf paths, their lengths, the

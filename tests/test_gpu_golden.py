@@ -928,7 +928,7 @@ def test_other_linear_layer_sizes(oracle, eaz, torch, kind, H):
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
 
 
-def test_unsupported_shapes_fail_loudly(eaz, torch):
+def test_unsupported_shapes_fail_loudly(eaz, torch, kernel_variant):
     """linear_layer_size is 1..1024 (256, config.py:24, runs the MFMA kernels; any other size the plain kernel); Subleq word sizes are
     16..256 (subleq.py:606): anything else must be refused with a message, never computed on some fallback."""
     from e_alphazero_amd import engine
@@ -943,10 +943,14 @@ def test_unsupported_shapes_fail_loudly(eaz, torch):
     net = engine.FCNet(env.ctx, 64, 256, 2, eaz.params.init_fc_params(64, 256, 2, seed=0))
     with pytest.raises(eaz.EazError, match="observation size"):
         engine.Search(engine.EnvHandle.deepsea(4, np.zeros((4, 4), np.uint8), device=0), net, 8, 4)
-    # a layer-1 input order is meaningless for one-hot observations: the DeepSea paths refuse a network that carries one
+    # a layer-1 input order is meaningless for one-hot observations: the DeepSea paths that feed the network an index instead of a row (the
+    # one-launch kernel, the fused leaf step) refuse a network that carries one; the unfused variants run dense rows and simply follow it
     net.set_input_order([(32, 32), (0, 32)])
     search = engine.Search(env, net, 8, 4)
-    with pytest.raises(eaz.EazError, match="one-hot"):
+    if kernel_variant in ("persist", "persist-step", "auto-fused"):
+        with pytest.raises(eaz.EazError, match="one-hot"):
+            search.selfplay(env.init(8), 1, key=0)
+    else:
         search.selfplay(env.init(8), 1, key=0)
     net.set_input_order(None)
     search.selfplay(env.init(8), 1, key=0)
