@@ -78,7 +78,7 @@ SIGNATURES = {
     "eaz_search_expand": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eaz_search_tree_view": [_vp, _i, _pp, C.POINTER(C.c_int64), C.POINTER(_i)],
     "eaz_search_launch_info": [_vp, C.POINTER(_i), C.POINTER(_i)],
-    "eaz_search_debug_poison": [_vp, _i, _vp],
+    "eaz_search_debug_poison": [_vp, _i, _i, _vp],
     "eaz_selfplay_run": [_vp, C.POINTER(SelfplayCfg), _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eaz_random_play": [_vp, _i, _i, _u64, _vp, _vp, _vp],
     "eaz_evaluate_run": [_vp, _f, _i, _vp, _vp, C.POINTER(_i), _vp],

@@ -154,7 +154,7 @@ struct eaz_search {
     // Subleq-16 fused self-play (search_subleq_persist.hpp): one launch per selfplay() call, trees and states in LDS
     int sqp_lds;               // dynamic LDS bytes of that launch (0: the trees of a workgroup do not fit)
     float* d_sq_logits;        // [ceil16(B), N, 32] scratch rows: prior logits | their softmax
-    float* d_sq_l1init;        // [ceil16(B), 2, 3, 256]: start of the layer-1 chains per tree (Sq16SelfplayArgs::l1init)
+    float* d_sq_l1init;        // [6 task branches, 3, 256] + [ceil16(B), 3, 256]: start vectors of the layer-1 chains (Sq16SelfplayArgs::l1init)
     int sqp_roots_fit;         // the roots of the search begun last fit the one-launch kernel's compact state (sq16_roots_fit)
     int* d_eval_wg;            // [1 + workgroups]: evaluate's trip count, then the workgroups' own (PersistSelfplay::eval_iters / eval_wg_iters)
 };
@@ -728,6 +728,7 @@ static int g_tree_block = [] { const char* e = std::getenv("EAZ_TREE_BLOCK"); re
 static int g_tree_spread = [] { const char* e = std::getenv("EAZ_TREE_SPREAD"); return e ? std::atoi(e) : 0; }();  // 0 = automatic
 static int g_persist = [] { const char* e = std::getenv("EAZ_PERSIST"); return e ? std::atoi(e) : 1; }();
 static int g_shards = [] { const char* e = std::getenv("EAZ_SHARDS"); return e ? std::atoi(e) : 0; }();  // 0 = automatic
+static int g_lazy_rows = [] { const char* e = std::getenv("EAZ_LAZY_ROWS"); return e ? std::atoi(e) : 1; }();  // 1 = automatic
 
 extern "C" int eaz_tune_set(int knob, int value) {
     if (knob == EAZ_TUNE_TREE_BLOCK) {
@@ -753,6 +754,11 @@ extern "C" int eaz_tune_set(int knob, int value) {
     if (knob == EAZ_TUNE_SUBLEQ_WAVE) {
         ARG_OK(value == 0 || value == 1);
         g_subleq_wave = value;
+        return 0;
+    }
+    if (knob == EAZ_TUNE_LAZY_ROWS) {
+        ARG_OK(value == 0 || value == 1 || value == 2);
+        g_lazy_rows = value;
         return 0;
     }
     if (knob == EAZ_TUNE_FC_TILE) {
@@ -1048,6 +1054,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     t.value_scale = opts->value_scale; t.maxvisit_init = opts->maxvisit_init;
     t.discount = opts->discount; t.two_player = opts->two_players_game;
     t.bonus_after = opts->epistemic_bonus_after_rescale != 0; t.var_backup = opts->epistemic_variance_backup != 0;
+    t.lazy_rows = 0;  // set per real step by the self-play driver (LazyRows)
     // per-simulation workspace
     DALLOC(s->d_obs, static_cast<size_t>(B) * env->dev.obs_dim + 16);
     DALLOC(s->d_obs_perm, static_cast<size_t>(B) * env->dev.obs_dim + 16);
@@ -1471,7 +1478,7 @@ extern "C" int eaz_search_simulate(eaz_search* s, int sim, void* stream) {
     }
     static const int wide_tree_leaf = [] { const char* e = std::getenv("EAZ_SUBLEQ_TREE_LEAF"); return e ? std::atoi(e) : 1; }();
     if (wide_tree_leaf && g_fused_leaf && g_subleq_wave && ed.kind == EAZ_ENV_SUBLEQ && ed.W != 16 && ed.binary && s->lpt == 64 && s->net->kind == 0 &&
-        (s->apl == 1 || s->apl == 4)) {  // (APL = 2, word sizes 65..128: the fused instantiation spills 20 bytes into scratch memory -- left on the two-launch path)
+        (s->apl == 1 || s->apl == 2 || s->apl == 4)) {
         // word sizes 64..256 (256: the reference's code default): tree step + leaf step + observation row (+ novelty over the IO rows) in one
         // launch of one wavefront per tree (search_kernels.hpp subleq_tree_leaf_kernel), then the forward
         const NetDev& nd = s->net->dev;
@@ -1483,6 +1490,7 @@ extern "C" int eaz_search_simulate(eaz_search* s, int sim, void* stream) {
             ta.next_reward = s->d_next_reward; ta.next_term = s->d_next_term; ta.next_legal = s->d_next_legal; ta.obs_out = s->d_obs;
             ta.nf = NoveltyFuse{nd.bitset, novelty_done ? s->d_novelty : nullptr, nd.hash_bits, nd.nov_scale};
             if (s->apl == 1) subleq_tree_leaf_kernel<1><<<s->B, 64, 0, st>>>(ta);
+            else if (s->apl == 2) subleq_tree_leaf_kernel<2><<<s->B, 64, 0, st>>>(ta);  // word sizes 65..128
             else subleq_tree_leaf_kernel<4><<<s->B, 64, 0, st>>>(ta);
             LAUNCH_OK();
         }
@@ -1510,11 +1518,18 @@ static int flush_expand(eaz_search* s, hipStream_t st) {
     return rc;
 }
 
-extern "C" int eaz_search_debug_poison(eaz_search* s, int byte_value, void* stream) {
-    ARG_OK(s != nullptr && byte_value >= 0 && byte_value <= 255);
+extern "C" int eaz_search_debug_poison(eaz_search* s, int what, int byte_value, void* stream) {
+    ARG_OK(s != nullptr && byte_value >= 0 && byte_value <= 255 && (what == 0 || what == 1));
     hipStream_t st = S(stream);
     const TreeDev& t = s->tree;
     const size_t B = static_cast<size_t>(s->B), BS = B * s->S;
+    if (what == 1) {  // the eight [B,N,A] child arrays: what lazy rows (TreeDev::lazy_rows) must never depend on
+        const size_t bytes = sizeof(float) * B * s->N * s->A;
+        void* rows[8] = {t.children_index, t.children_visits, t.children_prior_logits, t.children_values,
+                         t.children_rewards, t.children_discounts, t.children_var, t.children_reward_var};
+        for (void* r : rows) HIP_OK(hipMemsetAsync(r, byte_value, bytes, st));
+        return 0;
+    }
     HIP_OK(hipMemsetAsync(t.sim_parent, byte_value, sizeof(int32_t) * B, st)); HIP_OK(hipMemsetAsync(t.sim_action, byte_value, sizeof(int32_t) * B, st));
     HIP_OK(hipMemsetAsync(t.sim_next, byte_value, sizeof(int32_t) * B, st)); HIP_OK(hipMemsetAsync(t.path_len, byte_value, sizeof(int32_t) * B, st));
     HIP_OK(hipMemsetAsync(t.path_node, byte_value, sizeof(int32_t) * BS, st)); HIP_OK(hipMemsetAsync(t.path_action, byte_value, sizeof(int32_t) * BS, st));
@@ -1737,10 +1752,24 @@ enum : int { kFlagUniform = 1, kFlagSampleVisits = 2, kFlagSampleImproved = 4, k
 // root noise, output slots) is read from / written to staging buffers, so the launch sequence can be captured ONCE into a
 // hipGraph and replayed (S+1 network forwards, S+1 tree kernels, ...: 2S+13 launches per real step on the fused DeepSea path,
 // 3S-4S+14 otherwise).
+// Lazy child rows (tree.hpp TreeDev::lazy_rows) for the searches of the per-step self-play driver, whose trees nobody reads back (include/eaz.h:
+// after eaz_selfplay_run the tree arrays are scratch): Subleq word_size 256 clears 2.2 GB of [B,N,A] arrays per real step at B = 4096 otherwise
+// (0.39 ms of 8.5).  Off for narrow trees, where the clear is a few MB and the expand's extra row store is not free.
+struct LazyRows {
+    eaz_search* s;
+    explicit LazyRows(eaz_search* q) : s(q) { set(g_lazy_rows == 2 || (g_lazy_rows == 1 && q->A >= 64)); }
+    ~LazyRows() { set(false); }
+    void set(bool on) const {
+        s->tree.lazy_rows = on;
+        for (eaz_search* c : s->shards) c->tree.lazy_rows = on;
+    }
+};
+
 static int selfplay_step_body(eaz_search* s, const eaz_selfplay_cfg* cfg, int flags, void* d_states, hipStream_t st) {
     eaz_env* env = s->env;
     const int B = s->B, A = s->A;
     int rc;
+    const LazyRows lazy(s);  // from here to the summary below: every tree kernel of this real step
     // root inference (selfplay.py:89-91): observation -> {novelty lookup || value / ube / policy heads}
     {
         ProfScope ps(s, EAZ_K_MISC, st);

@@ -16,17 +16,20 @@ namespace eaz {
 __global__ void __launch_bounds__(256) tree_clear_kernel(TreeDev t, int keep_root) {
     const long bn = static_cast<long>(t.B) * t.N, bna = bn * t.A;
     const long stride = static_cast<long>(gridDim.x) * blockDim.x;
-    for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < bna; i += stride) {
+    const bool rows = t.lazy_rows == 0;  // lazy rows (tree.hpp): the [B,N,A] arrays are left as they are
+    for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < (rows ? bna : bn); i += stride) {
         // i indexes the [B,N,A] arrays, and (while i < B*N) the [B,N] arrays as well
-        const bool root_row = keep_root && (i / t.A) % t.N == 0;
-        t.children_index[i] = -1;
-        t.children_visits[i] = 0;
-        if (!root_row) t.children_prior_logits[i] = 0.0f;
-        t.children_values[i] = 0.0f;
-        t.children_rewards[i] = 0.0f;
-        t.children_discounts[i] = 0.0f;
-        t.children_var[i] = 0.0f;
-        t.children_reward_var[i] = 0.0f;
+        if (rows) {
+            const bool root_row = keep_root && (i / t.A) % t.N == 0;
+            t.children_index[i] = -1;
+            t.children_visits[i] = 0;
+            if (!root_row) t.children_prior_logits[i] = 0.0f;
+            t.children_values[i] = 0.0f;
+            t.children_rewards[i] = 0.0f;
+            t.children_discounts[i] = 0.0f;
+            t.children_var[i] = 0.0f;
+            t.children_reward_var[i] = 0.0f;
+        }
         if (i < bn) {
             t.parents[i] = -1;
             t.action_from_parent[i] = -1;
@@ -66,6 +69,7 @@ __global__ void __launch_bounds__(256) tree_root_kernel(TreeDev t, const float* 
         if (!(live && g.ok[j])) continue;
         const long o = static_cast<long>(g.b) * A + g.act[j];
         t.children_prior_logits[nb * A + g.act[j]] = inv[j] ? kF32Min : lg[j] - m;
+        if (t.lazy_rows) t.children_visits[nb * A + g.act[j]] = 0;  // the root's row of the one array lazy rows keep initialised (tree.hpp)
         t.root_invalid[o] = inv[j] ? 1 : 0;
         t.root_gumbel[o] = gumbel[o];
     }
@@ -139,12 +143,15 @@ __global__ void __launch_bounds__(256) tree_summary_kernel(TreeDev t, float* val
         if (value) value[b] = t.node_values[nb];
         if (value_std) value_std[b] = __builtin_sqrtf(t.node_var[nb]);
     }
-    int tot = 0;
-    for (int k = 0; k < t.A; ++k) tot += t.children_visits[o + k];
-    const float d = t.children_discounts[o + a];
-    if (qvalues) qvalues[i] = t.children_rewards[o + a] + d * t.children_values[o + a];
-    if (qvalues_var) qvalues_var[i] = t.children_reward_var[o + a] + (d * d) * t.children_var[o + a];
-    const float vc = static_cast<float>(t.children_visits[o + a]);
+    // sum of the root's children_visits: every backward counts the root and exactly one of its edges (A.6), and the root starts at 1 (A.3),
+    // so the sum is node_visits[root] - 1 (round 3 added the A counts up per thread: 65 536 loads per tree at 256 actions, 68 us per call)
+    const int tot = t.node_visits[nb] - 1;
+    const int vis = t.children_visits[o + a];
+    const bool linked = !t.lazy_rows || vis > 0;  // lazy rows (tree.hpp): an edge never taken reads as mctx's initial values
+    const float d = linked ? t.children_discounts[o + a] : 0.0f;
+    if (qvalues) qvalues[i] = (linked ? t.children_rewards[o + a] : 0.0f) + d * (linked ? t.children_values[o + a] : 0.0f);
+    if (qvalues_var) qvalues_var[i] = (linked ? t.children_reward_var[o + a] : 0.0f) + (d * d) * (linked ? t.children_var[o + a] : 0.0f);
+    const float vc = static_cast<float>(vis);
     const float ftot = static_cast<float>(tot);
     if (visit_counts) visit_counts[i] = vc;
     // mctx Tree.summary [EXT]: visit_counts / max(total, 1) -- all zeros for a root that has not been searched

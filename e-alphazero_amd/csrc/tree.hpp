@@ -55,6 +55,12 @@ struct TreeDev {
     int rescale, use_mixed, max_considered, max_depth;
     float value_scale, maxvisit_init;
     int bonus_after, var_backup;  // eaz_search_opts::epistemic_bonus_after_rescale / epistemic_variance_backup
+    // lazy child rows (the per-simulation self-play driver on wide trees, eaz_api.hip selfplay_lazy_rows): of the eight [B,N,A] arrays only
+    // the children_visits row of a node is initialised -- by the kernel that creates the node (tree_root_kernel / the expand) -- and every
+    // reader takes mctx's initial value (index -1, floats 0) for an edge whose visit count is 0.  children_index[p,a] != -1 <=> visits > 0
+    // between two simulations (the expand links the edge, the backward of the same launch counts it), so the results are those of cleared
+    // arrays, bit for bit, without the 532 KB per tree (A = 256, N = 65) that tree_clear_kernel writes per search.
+    int lazy_rows;
 };
 
 // running statistic of the variance backup (A.6 twin; include/eaz.h epistemic_variance_backup)
@@ -235,6 +241,10 @@ __device__ __forceinline__ void load_rows(const TreeDev& t, const Group<LPT, APL
             r.index[j] = t.children_index[o];
             r.var[j] = need_var ? t.children_var[o] : 0.0f;
             r.rvar[j] = need_var ? t.children_reward_var[o] : 0.0f;
+            if (t.lazy_rows && r.visits[j] == 0) {  // never linked since the node was created: the other rows hold whatever the allocation held
+                r.values[j] = 0.0f; r.rewards[j] = 0.0f; r.discounts[j] = 0.0f;
+                r.index[j] = -1; r.var[j] = 0.0f; r.rvar[j] = 0.0f;
+            }
         } else {
             r.logits[j] = 0.0f; r.values[j] = 0.0f; r.rewards[j] = 0.0f; r.discounts[j] = 0.0f;
             r.visits[j] = 0; r.index[j] = -1; r.var[j] = 0.0f; r.rvar[j] = 0.0f;
@@ -431,7 +441,11 @@ __device__ __forceinline__ TreeSel tree_step_body(const TreeDev& t, int sim, int
         }
 #pragma unroll
         for (int j = 0; j < APL; ++j)
-            if (live && g.ok[j]) t.children_prior_logits[(nb + nxt) * A + g.act[j]] = lg[j];
+            if (live && g.ok[j]) {
+                t.children_prior_logits[(nb + nxt) * A + g.act[j]] = lg[j];
+                // lazy rows: a NEW node (the expand of simulation sim - 1 creates node `sim`; a node re-expanded at max_depth keeps its counts)
+                if (t.lazy_rows && nxt == sim) t.children_visits[(nb + nxt) * A + g.act[j]] = 0;
+            }
         const long ca0 = (nb + parent) * A + action;
         if (lead) {
             t.raw_values[nb + nxt] = value;

@@ -74,9 +74,10 @@ def fingerprint(arrays) -> bytes:
 
 def tune(fc_tile: Optional[int] = None, fused_leaf: Optional[int] = None, tree_block: Optional[int] = None,
          tree_spread: Optional[int] = None, persist: Optional[int] = None, shards: Optional[int] = None,
-         subleq_wave: Optional[int] = None) -> None:
+         subleq_wave: Optional[int] = None, lazy_rows: Optional[int] = None) -> None:
     """Kernel-selection knobs (include/eaz.h eaz_tune_set); results are identical for every setting."""
-    for knob, v in ((0, fc_tile), (1, fused_leaf), (2, tree_block), (3, tree_spread), (4, persist), (5, shards), (6, subleq_wave)):
+    for knob, v in ((0, fc_tile), (1, fused_leaf), (2, tree_block), (3, tree_spread), (4, persist), (5, shards), (6, subleq_wave),
+                    (7, lazy_rows)):
         if v is not None:
             check(_lib.load().eaz_tune_set(knob, int(v)))
 
@@ -392,9 +393,10 @@ class Search:
     def run(self):
         check(_lib.load().eaz_search_run(self.h, _stream()))
 
-    def debug_poison(self, byte_value: int = 0x7F):
-        """Test hook (include/eaz.h eaz_search_debug_poison): fill the select scratch arrays with a byte pattern."""
-        check(_lib.load().eaz_search_debug_poison(self.h, byte_value, _stream()))
+    def debug_poison(self, byte_value: int = 0x7F, child_rows: bool = False):
+        """Test hook (include/eaz.h eaz_search_debug_poison): fill the select scratch arrays -- or, `child_rows`, the eight [B,N,A] arrays of
+        the tree -- with a byte pattern."""
+        check(_lib.load().eaz_search_debug_poison(self.h, 1 if child_rows else 0, byte_value, _stream()))
 
     def launch_info(self) -> dict:
         """one_launch: selfplay() / run() are ONE kernel launch on LDS-resident trees for this search under the current tuning; lds_bytes of it."""

@@ -233,11 +233,13 @@ enum {
  * the tree of its last real step). */
 EAZ_API int eaz_search_tree_view(eaz_search* s, int field_id, void** d_ptr, int64_t shape[3], int* elem_bytes);
 
-/* TEST HOOK (no reference counterpart): fills the search's select scratch (the recorded root-to-leaf paths, their lengths, the
- * selected (parent, action, next) triples) with `byte_value` -- the content a freed allocation may leave behind.  Between eaz_search_begin
- * and eaz_search_run it reproduces the precondition of round 3's 257-second launch (a lane group beyond a ragged batch read another
- * workgroup's path length before it was written): the search must finish in its normal time with unchanged results. */
-EAZ_API int eaz_search_debug_poison(eaz_search* s, int byte_value, void* stream);
+/* TEST HOOK (no reference counterpart): fills scratch of the search with `byte_value` -- the content a freed allocation may leave behind.
+ * what = 0: the select scratch (the recorded root-to-leaf paths, their lengths, the selected (parent, action, next) triples).  Between
+ *   eaz_search_begin and eaz_search_run it reproduces the precondition of round 3's 257-second launch (a lane group beyond a ragged batch read
+ *   another workgroup's path length before it was written): the search must finish in its normal time with unchanged results.
+ * what = 1: the eight [B,N,A] child arrays of the tree.  In front of eaz_selfplay_run with lazy child rows (EAZ_TUNE_LAZY_ROWS) the call's
+ *   results must not change: a search that never clears those arrays may not read an entry it has not written. */
+EAZ_API int eaz_search_debug_poison(eaz_search* s, int what, int byte_value, void* stream);
 /* Launch structure the library will use for this search under the current tuning (EAZ_TUNE_PERSIST): *one_launch = 1 when eaz_selfplay_run
  * (the whole call) and eaz_search_run (all simulations) each run as ONE kernel launch on LDS-resident trees -- DeepSea + FC network with two
  * actions (csrc/search_persist.hpp) or Subleq word_size 16, binary observations, FC network, XXHash novelty over the IO rows
@@ -343,6 +345,11 @@ EAZ_API int eaz_profile_replay(eaz_search* s, int kernel_class, int iters, doubl
  *                        (subleq_wave_kernel, program in the lanes of one VGPR), 0 = one lane per environment (subleq_step_kernel, program in LDS);
  *                        initial value from the environment variable EAZ_SUBLEQ_WAVE */
 #define EAZ_TUNE_SUBLEQ_WAVE 6
+/*   EAZ_TUNE_LAZY_ROWS   the per-step driver of eaz_selfplay_run (not the one-launch kernels): 1 (default) = searches over >= 64 actions do not
+ *                        clear the eight [B,N,A] tree arrays per real step; a node's children_visits row is zeroed by the kernel that creates the
+ *                        node and an edge with no visits reads as mctx's initial values (csrc/tree.hpp TreeDev::lazy_rows: same results);
+ *                        2 = for every action count, 0 = off.  Initial value from the environment variable EAZ_LAZY_ROWS */
+#define EAZ_TUNE_LAZY_ROWS 7
 EAZ_API int eaz_tune_set(int knob, int value);
 
 #ifdef __cplusplus

@@ -152,12 +152,17 @@ def test_subleq_interpreter_on_random_programs(oracle, eaz, torch, W, tasks, B):
     print(f"W={W}: {int(solved.sum())} of {B} random programs solved their task")
 
 
-@pytest.mark.parametrize("W,B,S", [(32, 12, 12), (64, 10, 10), (128, 9, 8), (256, 8, 8)])
-def test_wide_action_sets_selfplay_matches_oracle(oracle, eaz, torch, W, B, S):
+@pytest.mark.parametrize("lazy_rows", [0, 2], ids=["cleared-rows", "lazy-rows"])
+@pytest.mark.parametrize("W,B,S", [(32, 12, 12), (64, 10, 10), (64, 5, 48), (128, 9, 8), (256, 8, 8), (256, 3, 40)])
+def test_wide_action_sets_selfplay_matches_oracle(oracle, eaz, torch, W, B, S, lazy_rows):
     """Every lanes-per-tree / actions-per-lane instantiation of the tree kernels (32x1, 64x1, 64x2, 64x4) with the matching FC
-    output widths (VALU fallback, 256-column layer 3) and LDS-resident Subleq memory: Subleq word_size 32 .. 256 self-play."""
+    output widths (VALU fallback, 256-column layer 3) and LDS-resident Subleq memory: Subleq word_size 32 .. 256 self-play (64 .. 256:
+    tree step + leaf step in one launch, subleq_tree_leaf_kernel<1 / 2 / 4>).  Each with the [B,N,A] tree arrays cleared per real step and
+    with lazy child rows (EAZ_TUNE_LAZY_ROWS: the arrays are never cleared, TreeDev::lazy_rows); the S = 40 / 48 cases revisit edges of
+    deep trees many times."""
     from e_alphazero_amd import engine
 
+    engine.tune(lazy_rows=lazy_rows)
     dims, params, state = subleq_setup(eaz, W, seed=W + 1, fill=0.4)
     env = engine.EnvHandle.subleq(W, (1, 3), True, device=0)
     net = engine.FCNet(env.ctx, dims["in_dim"], 256, W, params, state, hash_off=dims["hash_off"], hash_len=dims["hash_len"])
@@ -169,8 +174,13 @@ def test_wide_action_sets_selfplay_matches_oracle(oracle, eaz, torch, W, B, S):
     ost = oenv.init(B, key=(7, 0))
     assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost)
     T = 3
-    out = search.selfplay(st, T, key=41)
-    ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(41, 0), discount=0.97)
+    try:
+        if lazy_rows:  # what the arrays held before must not matter: fill every [B,N,A] array with 0xFF bytes first (NaN, index / visits -1)
+            search.debug_poison(0xFF, child_rows=True)
+        out = search.selfplay(st, T, key=41)
+    finally:
+        engine.tune(lazy_rows=1)
+    ref = _cached(("wide_selfplay", W, B, S), lambda: oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(41, 0), discount=0.97))
     assert np.array_equal(out["action"].cpu().numpy(), ref["action"])
     assert np.array_equal(subleq_device_to_oracle(out["state"].cpu().numpy(), W), ref["state"])
     for k in ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction", "q_values_epistemic_variance"):
