@@ -41,6 +41,27 @@ def test_library_carries_the_hash_of_the_sources_it_was_built_from():
     assert _lib.build_hash() == _lib.source_hash(), "libeaz.so was not rebuilt after the last source change (run __graft_entry__.build())"
 
 
+def test_every_tuning_knob_of_the_header_is_bound_and_validated(eaz):
+    """include/eaz.h EAZ_TUNE_*: ids are dense, engine.tune() has a keyword per knob, the library accepts each knob's default and refuses values
+    outside its list and unknown knobs (eaz_tune_set only stores the value: no device needed)."""
+    import inspect
+
+    from e_alphazero_amd import engine
+
+    text = open(os.path.join(ROOT, "include", "eaz.h")).read()
+    knobs = {name: int(v) for name, v in re.findall(r"#define (EAZ_TUNE_\w+) (\d+)", text)}
+    assert sorted(knobs.values()) == list(range(len(knobs))) and len(knobs) == 8
+    kw = list(inspect.signature(engine.tune).parameters)
+    assert [k.upper() for k in kw] == [n[len("EAZ_TUNE_"):] for n, _ in sorted(knobs.items(), key=lambda kv: kv[1])]
+    lib = eaz.load_library()
+    defaults = dict(fc_tile=0, fused_leaf=1, tree_block=64, tree_spread=0, persist=1, shards=0, subleq_wave=1, lazy_rows=1)
+    bad = dict(fc_tile=7, tree_block=96, tree_spread=3, persist=5, shards=8, subleq_wave=2, lazy_rows=3)
+    for name, value in bad.items():
+        assert lib.eaz_tune_set(kw.index(name), value) != 0, f"{name}={value} must be refused"
+    assert lib.eaz_tune_set(len(knobs), 0) != 0 and b"unknown knob" in lib.eaz_last_error()
+    engine.tune(**defaults)
+
+
 def test_state_struct_sizes_match_header():
     from helpers import DEVICE_SUBLEQ
 

@@ -33,6 +33,6 @@ if want w256; then
   cd $R
 fi
 if want w256t; then
-  for t in 2 32; do timeout -k 10 300 python3 bench.py --workload c3 --word-size 256 --selfplay-steps $t --steps 3 --no-extra --no-cpu-baseline > $OUT/${TAG}_bench_subleq256_T$t.json.log 2>&1; echo "w256 T=$t rc=$?"; done
+  for t in 2 32; do timeout -k 10 300 python3 bench.py --workload c3 --word-size 256 --selfplay-steps $t --steps 2 --no-extra --no-cpu-baseline > $OUT/${TAG}_bench_subleq256_T$t.json.log 2>&1; echo "w256 T=$t rc=$?"; done
   timeout -k 10 300 bash tools/w256_sweep.sh > $OUT/${TAG}_subleq256_knob_sweep.txt 2>&1; echo "w256 sweep rc=$?"
 fi
