@@ -14,6 +14,11 @@ import torch  # noqa: E402
 
 import e_alphazero_amd as eaz  # noqa: E402
 from e_alphazero_amd import engine  # noqa: E402
+from e_alphazero_amd import _lib  # noqa: E402
+
+if _lib.build_hash() != _lib.source_hash():  # the stamps must describe the kernels of THIS tree (make -C e-alphazero_amd/csrc diag)
+    sys.exit(f"the diagnostic build is stale: {os.environ['EAZ_LIB']} was built from sources {_lib.build_hash()}, the tree is {_lib.source_hash()}")
+print(f"diagnostic build of sources {_lib.build_hash()}")
 
 G, B, S = 32, int(os.environ.get("B", 4096)), 64
 am = (np.random.default_rng(0).random((G, G)) < 0.5).astype(np.uint8)

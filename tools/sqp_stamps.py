@@ -15,6 +15,11 @@ import torch  # noqa: E402
 
 import e_alphazero_amd as eaz  # noqa: E402
 from e_alphazero_amd import engine  # noqa: E402
+from e_alphazero_amd import _lib  # noqa: E402
+
+if _lib.build_hash() != _lib.source_hash():  # the stamps must describe the kernels of THIS tree (make -C e-alphazero_amd/csrc diag)
+    sys.exit(f"the diagnostic build is stale: {os.environ['EAZ_LIB']} was built from sources {_lib.build_hash()}, the tree is {_lib.source_hash()}")
+print(f"diagnostic build of sources {_lib.build_hash()}")
 
 W, B, S, T = 16, int(os.environ.get("B", 4096)), 64, int(os.environ.get("T", 8))
 BETA = float(os.environ.get("BETA", 0.0))
