@@ -273,6 +273,8 @@ def test_subleq_word_sizes_that_are_not_multiples_of_four(oracle, eaz, torch, W,
     dict(B=33, S=16, T=15, rescale=False, gumbel_scale=0.5, max_considered=4),  # qtransform / root-selection options
     dict(B=20, S=12, T=14, two_player=True),                                    # negated discount (context.py:143) in the node records
     dict(B=24, S=16, T=15, reward_fn="lowest_bytes", explicit_gumbel=True, tasks=(1, 5)),
+    dict(B=18, S=1, T=14),                                                      # the smallest searches: one / two simulations per real step
+    dict(B=18, S=2, T=14, max_considered=2),
 ], ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items() if k not in ("tasks",)))
 def test_subleq16_one_launch_selfplay_edges(oracle, eaz, torch, case, kernel_variant):
     """Edges of subleq16_selfplay_kernel's eligibility and options (the other variants run the same inputs through their own kernels): batch

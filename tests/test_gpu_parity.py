@@ -169,6 +169,10 @@ def test_search_depth_limited_and_qtransform_options(oracle, eaz, torch, max_dep
     (8, 50, 24, 2.0, dict(bonus_after_rescale=True), False),
     (8, 50, 24, 1.0, dict(var_backup=1), False),
     (32, 40, 64, 1.5, dict(bonus_after_rescale=True, var_backup=1, max_depth=9), False),
+    # the smallest searches: one, two and three simulations (trees of 2-4 nodes, one-entry considered-visit sequences)
+    (8, 20, 1, 0.0, {}, False),
+    (8, 20, 2, 0.5, {}, True),
+    (8, 20, 3, 0.0, dict(max_considered=1), False),
 ])
 def test_search_run_whole_tree(oracle, eaz, torch, kernel_variant, G, B, S, beta_max, opts, masked):
     """begin -> run (all S simulations in one call) -> finish: every tree field, the embeddings, action and weights against the
