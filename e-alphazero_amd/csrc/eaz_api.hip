@@ -156,6 +156,7 @@ struct eaz_search {
     float* d_sq_logits;        // [ceil16(B), N, 32] scratch rows: prior logits | their softmax
     float* d_sq_l1init;        // [6 task branches, 3, 256] + [ceil16(B), 3, 256]: start vectors of the layer-1 chains (Sq16SelfplayArgs::l1init)
     int sqp_roots_fit;         // the roots of the search begun last fit the one-launch kernel's compact state (sq16_roots_fit)
+    int ds_roots_fit;          // likewise for DeepSea (ds_roots_fit): the packed state word of search_persist.hpp
     int* d_eval_wg;            // [1 + workgroups]: evaluate's trip count, then the workgroups' own (PersistSelfplay::eval_iters / eval_wg_iters)
 };
 
@@ -1158,6 +1159,7 @@ static int tree_grid(const eaz_search* s) { return cdiv(static_cast<long>(s->B) 
 static bool sqp_eligible(const eaz_search* s);
 static int sqp_launch(eaz_search* s, const PersistSelfplay& sp, hipStream_t st);
 static int sq16_roots_fit(eaz_search* s, const void* d_states, hipStream_t st, bool* fit);
+static int ds_roots_fit(eaz_search* s, const void* d_states, hipStream_t st, bool* fit);
 
 extern "C" int eaz_search_begin(eaz_search* s, const float* d_prior_logits, const float* d_value, const float* d_value_var,
                                 const void* d_root_states, const float* d_beta, const uint8_t* d_invalid, const float* d_gumbel,
@@ -1170,13 +1172,20 @@ extern "C" int eaz_search_begin(eaz_search* s, const float* d_prior_logits, cons
         // simulation by simulation instead gets the (root-preserving) clear from ensure_cleared() before its first tree kernel.
         // (likewise the Subleq-16 one-launch kernel, search_subleq_persist.hpp)
         s->sqp_roots_fit = 0;
+        s->ds_roots_fit = 0;
+        if (s->persist_ok && g_persist) {
+            bool fit = false;
+            const int rc = ds_roots_fit(s, d_root_states, st, &fit);
+            if (rc) return rc;
+            s->ds_roots_fit = fit ? 1 : 0;
+        }
         if (!(s->persist_ok && g_persist) && g_persist == 1 && sqp_eligible(s)) {
             bool fit = false;
             const int rc = sq16_roots_fit(s, d_root_states, st, &fit);
             if (rc) return rc;
             s->sqp_roots_fit = fit ? 1 : 0;
         }
-        s->clear_pending = (s->persist_ok && g_persist) || s->sqp_roots_fit;
+        s->clear_pending = s->ds_roots_fit || s->sqp_roots_fit;
         if (!s->clear_pending) {
             const long bna = static_cast<long>(s->B) * s->N * s->A;
             tree_clear_kernel<<<cdiv(bna, 256) < 4096 ? cdiv(bna, 256) : 4096, 256, 0, st>>>(s->tree, 0);
@@ -1273,6 +1282,20 @@ static bool sqp_eligible(const eaz_search* s) {
 // Do the blobs a call starts from fit the one-launch kernel's compact state (search_subleq_persist.hpp sq16_roots_fit_kernel)?  One small
 // launch, a 4-byte copy and a stream synchronisation; while the stream is being captured the question cannot be answered and the answer
 // is "no" (the per-simulation kernels keep whole blobs and are always right).
+// roots a DeepSea one-launch call may start from (search_persist.hpp ds_roots_fit_kernel); inside a stream capture: "no" (the per-step kernels)
+static int ds_roots_fit(eaz_search* s, const void* d_states, hipStream_t st, bool* fit) {
+    *fit = false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 0;
+    HIP_OK(hipMemsetAsync(s->d_alive, 0, sizeof(int), st));
+    ds_roots_fit_kernel<<<cdiv(s->B, 256), 256, 0, st>>>(static_cast<const char*>(d_states), s->B, s->env->dev.G, s->d_alive);
+    LAUNCH_OK();
+    int misfit = 1;
+    HIP_OK(hipMemcpyAsync(&misfit, s->d_alive, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    *fit = misfit == 0;
+    return 0;
+}
 static int sq16_roots_fit(eaz_search* s, const void* d_states, hipStream_t st, bool* fit) {
     *fit = false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -1547,7 +1570,7 @@ extern "C" int eaz_search_launch_info(const eaz_search* s, int* one_launch, int*
 
 extern "C" int eaz_search_run(eaz_search* s, void* stream) {
     ARG_OK(s != nullptr);
-    if (s->persist_ok && g_persist && s->clear_pending && s->sims_done == 0 && s->pending_expand < 0) {
+    if (s->persist_ok && g_persist && s->clear_pending && s->ds_roots_fit && s->sims_done == 0 && s->pending_expand < 0) {
         // all S simulations of every tree in one launch, trees resident in LDS (search_persist.hpp)
         ProfScope ps(s, EAZ_K_SEARCH, S(stream));
         int rc = persist_launch(s, S(stream));
@@ -1853,7 +1876,13 @@ extern "C" int eaz_selfplay_run(eaz_search* s, const eaz_selfplay_cfg* cfg, uint
     const int flags = (cfg->uniform_search_policy ? kFlagUniform : 0) | (cfg->sample_actions ? kFlagSampleVisits : 0) |
                       (cfg->sample_from_improved_policy ? kFlagSampleImproved : 0) | (d_gumbel ? kFlagExplicitGumbel : 0) |
                       (cfg->directed_exploration ? 16 : 0) | (static_cast<int>(cfg->exploration_beta != 0.0f) << 5);
-    if (s->persist_ok && g_persist) {
+    bool ds_fit = false;
+    if (s->persist_ok && g_persist && cfg->selfplay_steps > 0) {
+        // a hand-made state the kernel's packed state word cannot hold sends the call to the per-step kernels (search_persist.hpp ds_roots_fit_kernel)
+        const int rc = ds_roots_fit(s, d_states, S(stream), &ds_fit);
+        if (rc) return rc;
+    }
+    if (s->persist_ok && g_persist && (ds_fit || cfg->selfplay_steps == 0)) {
         // DeepSea + FC network: the WHOLE call -- T real steps of root inference, search, action choice, auto-reset step and output -- is ONE
         // launch of the persistent kernel (csrc/search_persist.hpp); nothing is captured, staged or copied
         if (cfg->selfplay_steps == 0) return 0;
@@ -1963,7 +1992,12 @@ extern "C" int eaz_evaluate_run(eaz_search* s, float exploitation_beta, int max_
     HIP_OK(hipSetDevice(s->ctx->device));
     hipStream_t st = S(stream);
     const int B = s->B;
+    bool ds_fit = false;
     if (s->persist_ok && g_persist && max_episode_length >= 0 && max_episode_length < (1 << 24)) {
+        const int rc = ds_roots_fit(s, d_states, st, &ds_fit);
+        if (rc) return rc;
+    }
+    if (ds_fit) {
         // DeepSea: the whole while_loop (evaluate.py:13-57) as ONE launch of search_persist_kernel in its evaluate mode (search_persist.hpp)
         PersistSelfplay sp;
         std::memset(&sp, 0, sizeof sp);

@@ -76,7 +76,9 @@ __device__ __forceinline__ eaz_deepsea_state ds_step(const EnvDev& e, eaz_deepse
     s.step_count += 1;
     int r = s.step_count - 1;
     r = r < 0 ? 0 : (r > G - 1 ? G - 1 : r);
-    const int flip = e.action_map[r * G + s.pos] != 0;          // :62
+    // (the column of a hand-made blob may be anything: clamped like the row -- jnp clamps an out-of-range index, and this read stays inside the map)
+    const int pc = s.pos < 0 ? 0 : (s.pos > G - 1 ? G - 1 : s.pos);
+    const int flip = e.action_map[r * G + pc] != 0;             // :62
     const int shift = ((action == 0) ^ flip) ? -1 : 1;          // :63
     int pos = s.pos + shift;
     pos = pos < 0 ? 0 : (pos > G - 1 ? G - 1 : pos);            // :64
@@ -88,9 +90,11 @@ __device__ __forceinline__ eaz_deepsea_state ds_step(const EnvDev& e, eaz_deepse
 }
 
 // flat index of the single True cell, deep_sea.py:66-70
+// (-1 = no cell: a hand-made blob with a negative step count or a column off the grid observes all zeros -- an index outside the array
+// addresses nothing; states the environment produced are always on the grid)
 __device__ __forceinline__ int ds_hot_index(const EnvDev& e, const eaz_deepsea_state& s) {
     const int r = s.step_count < e.G - 1 ? s.step_count : e.G - 1;
-    return r * e.G + s.pos;
+    return (r >= 0 && s.pos >= 0 && s.pos < e.G) ? r * e.G + s.pos : -1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

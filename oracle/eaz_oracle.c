@@ -86,11 +86,12 @@ static void o_deepsea_init(const OEnv* e, ODeepSeaState* s) {
 /* src/envs/deep_sea.py:59-81 (_step); step_count has already been incremented by the pgx wrapper */
 static void o_deepsea_step(const OEnv* e, ODeepSeaState* s, int action) {
     const int G = e->G;
-    /* jnp indexing clamps out-of-range indices; step_count-1 and pos are always in range here */
+    /* jnp indexing clamps out-of-range indices; step_count-1 and pos are always in range for states the environment produced */
     int r = s->step_count - 1;
     if (r < 0) r = 0;
     if (r > G - 1) r = G - 1;
-    int flip = e->action_map[r * G + s->pos] != 0;
+    int pc = s->pos < 0 ? 0 : (s->pos > G - 1 ? G - 1 : s->pos); /* a hand-made blob's column: clamped like the row */
+    int flip = e->action_map[r * G + pc] != 0;
     int shift = ((action == 0) ^ flip) ? -1 : 1;
     int pos = s->pos + shift;
     if (pos < 0) pos = 0;
@@ -106,7 +107,7 @@ static void o_deepsea_observe(const OEnv* e, const ODeepSeaState* s, uint8_t* ob
     const int G = e->G;
     memset(obs, 0, (size_t)G * G);
     int r = s->step_count < G - 1 ? s->step_count : G - 1;
-    obs[r * G + s->pos] = 1;
+    if (r >= 0 && s->pos >= 0 && s->pos < G) obs[r * G + s->pos] = 1; /* (a hand-made blob off the grid addresses no cell) */
 }
 
 /* ---- Subleq ----------------------------------------------------------------------------------------- */

@@ -5,7 +5,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import subleq_device_to_oracle, subleq_oracle_to_device, subleq_setup, deepsea_setup, random_states_deepsea
+from helpers import subleq_device_to_oracle, subleq_oracle_to_device, subleq_setup, deepsea_setup, random_states_deepsea, oracle_deepsea
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("kernel_variant")]
 ATOL = 1e-5
@@ -308,6 +308,57 @@ def test_subleq16_one_launch_selfplay_edges(oracle, eaz, torch, case, kernel_var
     assert np.array_equal(subleq_device_to_oracle(st.cpu().numpy(), W), ost)
     for k in ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction", "q_values_epistemic_variance"):
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
+
+
+def test_deepsea_states_beyond_the_packed_form_take_the_per_simulation_path(oracle, eaz, torch, kernel_variant):
+    """The one-launch DeepSea kernel keeps a state as one word (step count and column in 12 bits each, two flag bits, "reward is 1.0").
+    Everything the environment produces fits; a caller's hand-made blob may not.  eaz_selfplay_run / eaz_search_begin / eaz_evaluate_run check
+    the blobs a call starts from (ds_roots_fit_kernel) and send a batch with a misfit to the per-simulation kernels instead of truncating it:
+    every variant, the default one included, gives the oracle's result.  (A column off the grid or a negative step count is outside the
+    contract -- the reference would index with it -- but stays memory-safe: second half of the test.)"""
+    from e_alphazero_amd import engine
+
+    G, B, S, T = 8, 20, 12, 3
+    am, params, state = deepsea_setup(eaz, G, seed=31, fill=0.4)
+    env = engine.EnvHandle.deepsea(G, am, device=0)
+    net = engine.FCNet(env.ctx, G * G, 256, 2, params, state)
+    oenv, onet = oracle_deepsea(oracle, eaz, G, am, params, state)
+    blobs = random_states_deepsea(G, B, seed=32)
+    i32 = blobs.view(np.int32).reshape(B, 4)
+    f32 = blobs.view(np.float32).reshape(B, 4)
+    i32[2, 0] = 5000        # a step count beyond 12 bits (the row read is clamped, the episode is over)
+    f32[9, 2] = 0.5         # a reward that is neither 0 nor 1
+    blobs[11, 12] = 7       # `terminated` as a byte other than 0 / 1
+    search = engine.Search(env, net, B, S, discount=0.997)
+    if kernel_variant in ("persist", "persist-step"):
+        assert search.launch_info()["one_launch"], "eligible by shape: only the blobs' content routes this call"
+    st = torch.from_numpy(blobs.copy()).cuda()
+    ost = blobs.copy()
+    out = search.selfplay(st, T, key=83)
+    ref = oracle.selfplay(oenv, onet, ost, T=T, S=S, key=(83, 0), discount=0.997)
+    assert np.array_equal(out["action"].cpu().numpy(), ref["action"])
+    assert np.array_equal(out["state"].cpu().numpy(), ref["state"])
+    assert np.array_equal(st.cpu().numpy(), ost)
+    for k in ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction", "q_values_epistemic_variance"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=ATOL, err_msg=k)
+    # the same blobs through evaluate (greedy search, plain env.step until every environment has terminated)
+    ev = engine.Search(env, net, B, S, discount=0.997, gumbel_scale=0.0)
+    st2, ost2 = torch.from_numpy(blobs.copy()).cuda(), blobs.copy()
+    ret, iters = ev.evaluate(st2, exploitation_beta=0.0, max_episode_length=G + 2)
+    oret, oiters = oracle.evaluate(oenv, onet, ost2, S=S, exploitation_beta=0.0, max_episode_length=G + 2, discount=0.997)
+    assert iters == oiters and np.array_equal(st2.cpu().numpy(), ost2)
+    np.testing.assert_allclose(ret.cpu().numpy(), oret, rtol=0, atol=ATOL)
+    # off the grid: no parity claim (jnp would wrap / clamp the indices its own way), but the call must come back, with finite numbers and
+    # every environment on the grid after its first real step (the action-map read is clamped, the observation has no set cell)
+    wild = blobs.copy()
+    w32 = wild.view(np.int32).reshape(B, 4)
+    w32[4, 0], w32[6, 1], w32[7, 1], w32[8, 1] = -3, G + 5, -2, 2 ** 31 - 1
+    st3 = torch.from_numpy(wild).cuda()
+    out3 = search.selfplay(st3, T, key=84)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(out3[k]).all() for k in ("root_value", "root_epistemic_std", "value_prediction", "ube_prediction"))
+    pos3 = st3.cpu().numpy().view(np.int32).reshape(B, 4)[:, 1]
+    assert ((pos3 >= 0) & (pos3 < G)).all()
 
 
 def test_subleq16_states_beyond_the_compact_form_take_the_per_simulation_path(oracle, eaz, torch, kernel_variant):

@@ -364,6 +364,7 @@ def test_search_begin_then_stepwise_after_persist_default(oracle, eaz, torch):
     (32, 256, 64, 3, {}),
     (8, 1, 8, 9, {}),      # a single environment
     (6, 17, 8, 6, {}),     # ragged: B not a multiple of any tile, observation size 36 (not a multiple of 16: byte staging path)
+    (66, 20, 12, 3, {}),   # a grid whose action map (4 356 bytes) does not fit the one-launch kernel's LDS copy: read from global memory
 ])
 def test_selfplay_matches_oracle(oracle, eaz, torch, G, B, S, T, flags):
     am, params, state = deepsea_setup(eaz, G, seed=5, fill=0.25)
