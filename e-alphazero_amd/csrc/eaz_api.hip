@@ -157,6 +157,9 @@ struct eaz_search {
     float* d_sq_l1init;        // [6 task branches, 3, 256] + [ceil16(B), 3, 256]: start vectors of the layer-1 chains (Sq16SelfplayArgs::l1init)
     int sqp_roots_fit;         // the roots of the search begun last fit the one-launch kernel's compact state (sq16_roots_fit)
     int ds_roots_fit;          // likewise for DeepSea (ds_roots_fit): the packed state word of search_persist.hpp
+    int* h_fit_flag;           // pinned host word the two root checks write through its device mapping (no copy: launch + stream synchronisation)
+    int* d_fit_flag;           // its device address
+    int fit_epoch;             // value a misfit writes in the current check (no clear between checks)
     int* d_eval_wg;            // [1 + workgroups]: evaluate's trip count, then the workgroups' own (PersistSelfplay::eval_iters / eval_wg_iters)
 };
 
@@ -968,6 +971,7 @@ static int make_shard(eaz_search* p, int b0, int Bs, eaz_search** out) {
     c->allocs.clear(); c->spans.clear(); c->ev_pool.clear(); c->shards.clear();
     c->step_graph = nullptr; c->graph_states = nullptr; c->graph_flags = -1; c->pending_expand = -1; c->prof_on = 0;
     c->persist_ok = 0; c->clear_pending = 0; c->d_replay_states = nullptr; c->d_stamps = nullptr;
+    c->h_fit_flag = nullptr; c->d_fit_flag = nullptr;
     c->B = Bs;
     c->side = c->main = nullptr;
     c->ev_fork = c->ev_join = c->ev_in = c->ev_out = c->ev_shard_fork = c->ev_shard_join = nullptr;
@@ -1010,6 +1014,7 @@ extern "C" int eaz_search_create(eaz_ctx* ctx, eaz_env* env, eaz_net* net, int B
     s->B = B; s->S = opts->num_simulations; s->N = s->S + 1; s->A = env->dev.A;
     s->prof_on = 0; s->step_graph = nullptr; s->graph_states = nullptr; s->graph_flags = -1; s->pending_expand = -1;
     s->persist_ok = 0; s->persist_lds = 0; s->clear_pending = 0; s->sims_done = 0; s->d_stamps = nullptr;
+    s->h_fit_flag = nullptr; s->d_fit_flag = nullptr; s->fit_epoch = 0;
     std::memset(&s->last_sp, 0, sizeof s->last_sp); s->d_replay_states = nullptr;
     s->sqp_lds = 0; s->d_sq_logits = nullptr; s->d_sq_l1init = nullptr; s->d_eval_wg = nullptr;
     HIP_OK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
@@ -1145,6 +1150,7 @@ extern "C" int eaz_search_destroy(eaz_search* s) {
     for (auto& sp : s->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto& e : s->ev_pool) (void)hipEventDestroy(e);
     if (s->step_graph) (void)hipGraphExecDestroy(s->step_graph);
+    if (s->h_fit_flag) (void)hipHostFree(s->h_fit_flag);
     if (s->side) (void)hipStreamDestroy(s->side);
     if (s->main) (void)hipStreamDestroy(s->main);
     if (s->ev_in) (void)hipEventDestroy(s->ev_in);
@@ -1283,30 +1289,40 @@ static bool sqp_eligible(const eaz_search* s) {
 // launch, a 4-byte copy and a stream synchronisation; while the stream is being captured the question cannot be answered and the answer
 // is "no" (the per-simulation kernels keep whole blobs and are always right).
 // roots a DeepSea one-launch call may start from (search_persist.hpp ds_roots_fit_kernel); inside a stream capture: "no" (the per-step kernels)
+// one launch that stores this call's epoch into a pinned host word if any root does not fit, then a stream synchronisation: ~30 us per call
+// (the first version -- memset, kernel, 4-byte copy into pageable memory, synchronisation -- cost 130 us, 0.4 % of a C2 launch)
+static int roots_fit_flag(eaz_search* s) {
+    if (s->h_fit_flag) return 0;
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&s->h_fit_flag), sizeof(int), hipHostMallocMapped));
+    *s->h_fit_flag = 0;
+    s->fit_epoch = 0;
+    HIP_OK(hipHostGetDevicePointer(reinterpret_cast<void**>(&s->d_fit_flag), s->h_fit_flag, 0));
+    return 0;
+}
 static int ds_roots_fit(eaz_search* s, const void* d_states, hipStream_t st, bool* fit) {
     *fit = false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 0;
-    HIP_OK(hipMemsetAsync(s->d_alive, 0, sizeof(int), st));
-    ds_roots_fit_kernel<<<cdiv(s->B, 256), 256, 0, st>>>(static_cast<const char*>(d_states), s->B, s->env->dev.G, s->d_alive);
+    int rc = roots_fit_flag(s);
+    if (rc) return rc;
+    const int epoch = ++s->fit_epoch;
+    ds_roots_fit_kernel<<<cdiv(s->B, 256), 256, 0, st>>>(static_cast<const char*>(d_states), s->B, s->env->dev.G, s->d_fit_flag, epoch);
     LAUNCH_OK();
-    int misfit = 1;
-    HIP_OK(hipMemcpyAsync(&misfit, s->d_alive, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    *fit = misfit == 0;
+    *fit = *static_cast<volatile int*>(s->h_fit_flag) != epoch;
     return 0;
 }
 static int sq16_roots_fit(eaz_search* s, const void* d_states, hipStream_t st, bool* fit) {
     *fit = false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 0;
-    HIP_OK(hipMemsetAsync(s->d_alive, 0, sizeof(int), st));
-    sq16_roots_fit_kernel<<<cdiv(s->B, 256), 256, 0, st>>>(static_cast<const char*>(d_states), static_cast<long>(sizeof(eaz_subleq_state)), s->B, s->d_alive);
+    int rc = roots_fit_flag(s);
+    if (rc) return rc;
+    const int epoch = ++s->fit_epoch;
+    sq16_roots_fit_kernel<<<cdiv(s->B, 256), 256, 0, st>>>(static_cast<const char*>(d_states), static_cast<long>(sizeof(eaz_subleq_state)), s->B, s->d_fit_flag, epoch);
     LAUNCH_OK();
-    int misfit = 1;
-    HIP_OK(hipMemcpyAsync(&misfit, s->d_alive, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    *fit = misfit == 0;
+    *fit = *static_cast<volatile int*>(s->h_fit_flag) != epoch;
     return 0;
 }
 // layer-1 weights in the one-launch kernel's packed input order (sq16_l1_src), rebuilt on the launch stream after every weight upload

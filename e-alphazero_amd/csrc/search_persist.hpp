@@ -154,14 +154,14 @@ __device__ __forceinline__ eaz_deepsea_state ps_unpack(uint32_t w) {
 // the two flags as bits, the reward as "is 1.0".  A caller's hand-made blob may hold anything; the host runs this check on the blobs a call
 // starts from and sends a batch with any misfit to the per-simulation kernels, which keep whole blobs (the Subleq-16 kernel does the same:
 // sq16_roots_fit_kernel).
-__global__ void __launch_bounds__(256) ds_roots_fit_kernel(const char* __restrict__ states, int B, int G, int* misfit) {
+__global__ void __launch_bounds__(256) ds_roots_fit_kernel(const char* __restrict__ states, int B, int G, int* misfit, int epoch) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
     const uint4 w = *reinterpret_cast<const uint4*>(states + static_cast<long>(b) * sizeof(eaz_deepsea_state));
     const int step = static_cast<int>(w.x), pos = static_cast<int>(w.y);
     const bool ok = step >= 0 && step <= 0xFFF && pos >= 0 && pos < G && (w.z == 0u || w.z == 0x3F800000u) &&  // a column on the grid; reward +0.0f or 1.0f
                     (w.w & 0x0000FEFEu) == 0u;  // flags 0 / 1 (the two padding bytes are nobody's: every step kernel writes them as zero)
-    if (!ok) *misfit = 1;
+    if (!ok) *misfit = epoch;  // `misfit` is host memory mapped into the device's address space; the host compares it with this call's epoch
 }
 
 // LDS traffic between the lanes of one wavefront: DS operations of a wave execute in issue order, so only the compiler has to be

@@ -564,7 +564,7 @@ __device__ __forceinline__ void qp_l1_start_roots(const NetDev& net, const HeadL
 // sixteenth), IO values as bytes with 16 as "beyond the valid ones", the step count in 8 bits, the task in 16.  Every state the environment
 // itself produces fits (subleq.py:88-98,648-677); a caller's hand-made blob may not, and would be truncated silently.  The host runs this
 // check on the blobs a call starts from and sends a batch with any misfit to the per-simulation kernels, which keep whole blobs.
-__global__ void __launch_bounds__(256) sq16_roots_fit_kernel(const char* __restrict__ states, long stride, int B, int* misfit) {
+__global__ void __launch_bounds__(256) sq16_roots_fit_kernel(const char* __restrict__ states, long stride, int B, int* misfit, int epoch) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
     const uint4* p = reinterpret_cast<const uint4*>(states + static_cast<long>(b) * stride);
@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(256) sq16_roots_fit_kernel(const char* __restr
     uint32_t tail = 0u;
     for (int i = 6; i < 21; ++i) { const uint4 m = p[i]; tail |= m.x | m.y | m.z | m.w; }  // bytes 16..255 of the memory: zero
     ok = ok && tail == 0u;
-    if (!ok) *misfit = 1;
+    if (!ok) *misfit = epoch;  // `misfit` is host memory mapped into the device's address space; the host compares it with this call's epoch
 }
 
 // evaluate (PersistSelfplay::on == 2), after the launch: the reference's while_loop (evaluate.py:13-57) steps EVERY environment until the last
