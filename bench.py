@@ -99,6 +99,19 @@ def cpu_share():
     return max(1, min(n, 16))
 
 
+
+def oracle_module():
+    """The CPU oracle (checker only: parity gates and the cpu_baseline leg), its OpenMP team cut to the cores this process may use.  On a
+    1-GPU box the process sees every hardware thread of the host but owns a 16-core quota: a default-sized team's idle workers spin through
+    that quota after each parallel region and the cgroup then throttles the whole process -- the launching thread included (a 1.4 ms
+    reanalyze() call measured 31 ms right behind a parity gate)."""
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # read by libgomp when it is loaded
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import eaz_oracle as O
+
+    O.lib().eazo_set_num_threads(cpu_share())
+    return O
+
 def build_workload(name, args, device, rank, beta=0.0):
     """-> dict(env, net, search, selfplay kwargs, description strings, oracle factory for the CPU baseline).
     beta != 0: directed exploration (config.py:38,172): exploration policy head in the search, beta * linspace(0, 1, B) per environment."""
@@ -416,12 +429,24 @@ def run_rank(args):
             except (Exception, SystemExit) as exc:  # noqa: BLE001
                 result["extra"][tag] = {"error": f"{type(exc).__name__}: {exc}"}
         wl = meas = None
+        # ---- reanalyze() and evaluate() on C2's and C3's inputs (own parity gates; never at the headline's cost) ----
+        for tag, name in (("next_c2", "c2"), ("next_c3", "c3")):
+            if args.no_cpu_baseline:
+                break
+            xargs = argparse.Namespace(**vars(args))
+            xargs.workload, xargs.selfplay_steps = name, 0
+            torch.cuda.empty_cache()
+            try:
+                wl = build_workload(name, xargs, device, rank)
+                wl["search"] = None
+                result["extra"][tag] = next_rows(wl, xargs)
+            except (Exception, SystemExit) as exc:  # noqa: BLE001
+                result["extra"][tag] = {"error": f"{type(exc).__name__}: {exc}"}
+            wl = None
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload, rank 0 at N = 1 only -------------------
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import eaz_oracle as O
-
+        O = oracle_module()
         cb = args.cpu_sample_batch or main_cpu[0]
         ct = args.cpu_sample_steps or main_cpu[1]
         ncores = cpu_share()
@@ -443,9 +468,7 @@ def run_rank(args):
 def parity_gate(wl, args):
     """16 environments of the benchmark's inputs through the engine and through the CPU oracle: actions and states must be bit-identical,
     values within 1e-5 (the north-star tolerance).  Raises before anything is timed if they are not."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import eaz_oracle as O
-
+    O = oracle_module()
     nb, nt = 16, 2 if wl["name"] != "c4" else 1
     S = wl["S"] if wl["name"] != "c4" else 32      # connect_four on the CPU: a shorter search keeps the gate at a few seconds
     kw = dict(discount=wl["discount"], two_players_game=wl["two_player"], exploration=wl["beta"] != 0.0)
@@ -469,6 +492,83 @@ def parity_gate(wl, args):
         oname += f", directed exploration beta={wl['beta']:g}"
     return {"checked": f"{oname}: {nb} environments x {nt} real steps x {S} simulations, engine vs CPU oracle (in-repo restatement; emctx parity unpinned)",
             "actions_states_bit_identical": ok_int, "max_abs_float_error": err, "tolerance": 1e-5}
+
+
+def next_rows(wl, args, calls=3):
+    """SURVEY 8(f) N1 / N2 on the workload's inputs, each parity-gated on 16 environments first: `reanalyze()` (src/reanalyze.py:52-131: one
+    search per sampled state with beta = reanalyze_beta, then the target post-processing) as searched states per second, `evaluate()`
+    (src/evaluate.py:13-57: greedy episodes until every environment has terminated) as real env-steps per second.  -> dict"""
+    O = oracle_module()
+    env, net, B, S, A = wl["env"], wl["net"], wl["B"], wl["S"], wl["A"]
+    kw = dict(discount=wl["discount"], two_players_game=wl["two_player"])
+    oenv, onet, okw, oname = wl["oracle"](O)
+    conv = (lambda a: O.subleq_device_to_oracle(a, A)) if wl["name"] == "c3" else (lambda a: a)
+    back = (lambda a: O.subleq_oracle_to_device(a)) if wl["name"] == "c3" else (lambda a: a)
+    out = {}
+
+    # ---- N1 reanalyze: mid-episode states (5 random real steps from init) and their successors under a random action --------------------
+    def sample(n):
+        ost, _ = O.random_play(oenv, n, 5, key=(11, 0))
+        act = np.random.default_rng(3).integers(0, A, n).astype(np.int32)
+        onxt = oenv.step(ost.copy(), act, key=(12, 0), autoreset=False)
+        return ost, onxt
+    nb = 16
+    ost, onxt = sample(nb)
+    g = O.gumbel((21, 0), nb * A).reshape(nb, A)
+    rs = engine.Search(env, net, nb, S, **kw)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    got = rs.reanalyze(cu(back(ost)), cu(back(onxt)), key=5, gumbel=cu(g), reanalyze_beta=0.5)
+    torch.cuda.synchronize()
+    ref = O.reanalyze(oenv, onet, ost, onxt, S, g, reanalyze_beta=0.5, **okw)
+    ok_int = bool(np.array_equal(got["action"].cpu().numpy(), ref["action"]))
+    err = max(float(np.max(np.abs(got[k].cpu().numpy() - ref[k]))) for k in
+              ("value_target", "ube_target", "exploration_policy_target", "exploitation_policy_target"))
+    if not ok_int or not err <= 1e-5:
+        raise SystemExit(f"reanalyze parity gate FAILED on {oname}: actions identical = {ok_int}, max float error = {err:.3g}")
+    gate = {"checked": f"{oname}: {nb} sampled states x {S} simulations, reanalyze() engine vs CPU oracle", "actions_bit_identical": ok_int,
+            "max_abs_float_error": err, "tolerance": 1e-5}
+    del rs
+    ost, onxt = sample(B)
+    st, nx = cu(back(ost)), cu(back(onxt))
+    rs = engine.Search(env, net, B, S, **kw)
+    rs.reanalyze(st, nx, key=0, reanalyze_beta=0.5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(calls):
+        rs.reanalyze(st, nx, key=1 + i, reanalyze_beta=0.5)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["reanalyze"] = {"metric": f"reanalyzed states/s ({oname}, batch={B}, {S} sims, reanalyze_beta=0.5)", "value": B * calls / dt, "unit": "states/s",
+                        "calls": calls, "ms_per_call": 1e3 * dt / calls, "launch_structure": rs.launch_info(), "parity_gate": gate,
+                        "reference": "src/reanalyze.py:52-131 (SURVEY 8f N1)"}
+    del rs
+
+    # ---- N2 evaluate: greedy episodes from init; the gate stops after four iterations (a whole episode on the CPU takes too long here) -----
+    es = engine.Search(env, net, nb, S, gumbel_scale=0.0, **kw)
+    st16, ost16 = env.init(nb, key=0), oenv.init(nb)
+    ret, it = es.evaluate(st16, exploitation_beta=0.0, max_episode_length=3)
+    oret, oit = O.evaluate(oenv, onet, ost16, S=S, exploitation_beta=0.0, max_episode_length=3, **okw)
+    ok_int = bool(it == oit and np.array_equal(conv(st16.cpu().numpy()), ost16))
+    err = float(np.max(np.abs(ret.cpu().numpy() - oret)))
+    if not ok_int or not err <= 1e-5:
+        raise SystemExit(f"evaluate parity gate FAILED on {oname}: states / trip count identical = {ok_int}, max float error = {err:.3g}")
+    gate = {"checked": f"{oname}: {nb} environments x {it} iterations x {S} simulations, evaluate() engine vs CPU oracle", "states_bit_identical": ok_int,
+            "max_abs_float_error": err, "tolerance": 1e-5}
+    del es
+    es = engine.Search(env, net, B, S, gumbel_scale=0.0, **kw)
+    es.evaluate(env.init(B, key=0), exploitation_beta=0.0, max_episode_length=1000)
+    torch.cuda.synchronize()
+    steps = 0
+    t0 = time.perf_counter()
+    for i in range(calls):
+        _, it = es.evaluate(env.init(B, key=0), exploitation_beta=0.0, max_episode_length=1000)
+        steps += it
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["evaluate"] = {"metric": f"evaluate env-steps/s ({oname}, batch={B}, {S} sims, greedy search, whole episodes)", "value": B * steps / dt,
+                       "unit": "env-steps/s", "calls": calls, "iterations_per_call": steps / calls, "ms_per_call": 1e3 * dt / calls,
+                       "launch_structure": es.launch_info(), "parity_gate": gate, "reference": "src/evaluate.py:13-57 (SURVEY 8f N2)"}
+    return out
 
 
 def measure(wl, args, rank, dist, rehearsal, dev, steps, warmup):
