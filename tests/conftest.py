@@ -13,11 +13,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def _cpu_share():
+    """Cores this process may use (affinity mask and cgroup quota): the oracle's OpenMP team is cut to it -- on a GPU box the process sees every
+    hardware thread of the host but owns a 16-core quota, and a default-sized team's idle workers spin the quota away (bench.py oracle_module)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 @pytest.fixture(scope="session")
 def oracle():
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # read by libgomp when it is loaded
     import eaz_oracle as O
 
     O.build()
+    O.lib().eazo_set_num_threads(_cpu_share())
     return O
 
 
