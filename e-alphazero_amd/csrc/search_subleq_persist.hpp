@@ -799,8 +799,10 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             {
                 // epistemic_recurrent_fn (src/context.py:132-153) on the forward's outputs; mctx update_tree_node + topology (A.3)
                 const float z = tl < 18 ? head_out(ti, tl < 16 ? 2 + tl : tl - 16) : 0.0f;
-                if (tl == 16) M.o_value[ti] = det_tanh(z);                                        // fully_connected.py:55
-                if (tl == 17) M.o_ube[ti] = (0.5f * (det_tanh(z) + 1.0f)) * a.net.max_u;          // :64, :93
+                // one det_tanh region for the two one-output heads (lanes 16 and 17): as two `if`s the wave ran the sequence twice
+                const float th = (tl == 16 || tl == 17) ? det_tanh(z) : 0.0f;
+                if (tl == 16) M.o_value[ti] = th;                                                 // fully_connected.py:55
+                if (tl == 17) M.o_ube[ti] = (0.5f * (th + 1.0f)) * a.net.max_u;                   // :64, :93
                 float lgv = tl < 16 ? z : -kInf;
                 const float m = gmax<16>(lgv);                                                    // :135
                 ps_wave_sync();
@@ -847,13 +849,22 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
                     const int cnt_i = static_cast<int>(R[QN_META] & 0xFFu);
                     const float nv = u2f(R[QN_NODE_VALUE]), nvar = u2f(R[QN_NODE_VAR]);
                     const int top = (D - c * 16 < 16 ? D - c * 16 : 16) - 1;  // deepest level of this chunk
+                    // deepest level of the two trees of this wavefront: levels beyond it are skipped by a scalar branch (search_persist.hpp)
+                    int wtop = __builtin_amdgcn_readlane(top, 0);
+                    { const int t1 = __builtin_amdgcn_readlane(top, 32); wtop = wtop > t1 ? wtop : t1; }
                     *reinterpret_cast<float2*>(&M.edge[ti][tj][0]) = make_float2(er, ed);
                     ps_wave_sync();
+                    float ers[16], eds[16];
+#pragma unroll
+                    for (int s4 = 0; s4 < 8; ++s4) {
+                        const floatx4 v = *reinterpret_cast<const floatx4*>(&M.edge[ti][2 * s4][0]);  // wide broadcast reads
+                        ers[2 * s4] = v[0]; eds[2 * s4] = v[1]; ers[2 * s4 + 1] = v[2]; eds[2 * s4 + 1] = v[3];
+                    }
                     float G = Gin, U = Uin;
-#pragma unroll 4
+#pragma unroll
                     for (int lv = 15; lv >= 0; --lv) {
-                        const float2 ev = *reinterpret_cast<const float2*>(&M.edge[ti][lv][0]);  // broadcast read
-                        const float rs = ev.x, dd = ev.y;
+                        if (lv > wtop) continue;
+                        const float rs = ers[lv], dd = eds[lv];
                         if (lv <= top && lv >= tj) {
                             G = rs + dd * G;
                             U = 0.0f + (dd * dd) * U;  // children_rewards_epistemic_variance == 0 (context.py:149)
@@ -1338,8 +1349,9 @@ __global__ void __launch_bounds__(kQpThreads) subleq16_selfplay_kernel(Sq16Selfp
             const Key kt = fold(a.sp.key, kTagStep + static_cast<uint32_t>(step));
             const Key gkey = evaluate ? Key{0u, 0u} : fold(kt, kTagGumbel);  // evaluate: gumbel_scale = 0 (evaluate.py:44), the noise of the host driver's key
             const float z = tl < 18 ? head_out(ti, tl < 16 ? 2 + tl : tl - 16) : 0.0f;
-            if (tl == 16) M.o_value[ti] = det_tanh(z);                                // fully_connected.py:55
-            if (tl == 17) M.o_ube[ti] = (0.5f * (det_tanh(z) + 1.0f)) * a.net.max_u;  // :64, :93
+            const float th = (tl == 16 || tl == 17) ? det_tanh(z) : 0.0f;
+            if (tl == 16) M.o_value[ti] = th;                                         // fully_connected.py:55
+            if (tl == 17) M.o_ube[ti] = (0.5f * (th + 1.0f)) * a.net.max_u;           // :64, :93
             ps_wave_sync();
             float lgv = -kInf;
             if (tl < 16) {
