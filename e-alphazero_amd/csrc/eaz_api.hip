@@ -504,10 +504,19 @@ static void resnet_pack(const float* const* a, int H, int W, int Cin, int C, int
     r.cin_log2 = 0;
     while ((1 << r.cin_log2) < Cin) r.cin_log2++;
     int i = 0, ci = 0, bi = 0;
-    auto take_conv = [&](int taps, int cin, int cout, int& w_off, int& b_off, int* kpad) {
+    auto take_conv = [&](int taps, int cin, int cout, int& w_off, int& b_off, int* kpad, bool tower = false) {
         const int K = taps * cin, Kp = (K + 3) & ~3;
         w_off = push(a[i], static_cast<size_t>(K) * cout);
         pk.resize(static_cast<size_t>(w_off) + static_cast<size_t>(Kp) * cout, 0.0f);  // zero rows up to the padded K
+        if (tower) {
+            // the tower's 64 -> 64 convolutions in the kernel's operand order (net_resnet.hpp): four consecutive k-steps of a lane side by side
+            const float* W0 = a[i];
+            float* Wp = pk.data() + w_off;
+            for (int ks4 = 0; ks4 < K / 16; ++ks4)
+                for (int kq = 0; kq < 4; ++kq)
+                    for (int c = 0; c < cout; ++c)
+                        for (int q = 0; q < 4; ++q) Wp[((ks4 * 4 + kq) * cout + c) * 4 + q] = W0[static_cast<size_t>(4 * (4 * ks4 + q) + kq) * cout + c];
+        }
         while (pk.size() % 4) pk.push_back(0.0f);
         b_off = push(a[i + 1], cout);
         if (kpad) *kpad = Kp;
@@ -523,9 +532,9 @@ static void resnet_pack(const float* const* a, int H, int W, int Cin, int C, int
     ci = 1;
     for (int k = 0; k < nb; ++k) {
         take_bn(C, r.bn_mean[bi], r.bn_inv[bi], r.bn_off[bi]); bi++;
-        take_conv(9, C, C, r.conv_w[ci], r.conv_b[ci], &r.conv_k[ci]); ci++;
+        take_conv(9, C, C, r.conv_w[ci], r.conv_b[ci], &r.conv_k[ci], C == kRnC); ci++;
         take_bn(C, r.bn_mean[bi], r.bn_inv[bi], r.bn_off[bi]); bi++;
-        take_conv(9, C, C, r.conv_w[ci], r.conv_b[ci], &r.conv_k[ci]); ci++;
+        take_conv(9, C, C, r.conv_w[ci], r.conv_b[ci], &r.conv_k[ci], C == kRnC); ci++;
     }
     take_bn(C, r.bn_mean[bi], r.bn_inv[bi], r.bn_off[bi]);  // final batch norm at index 2*nb
     auto take_lin = [&](int in, int outn, int& w_off, int& b_off) { w_off = push(a[i], static_cast<size_t>(in) * outn); b_off = push(a[i + 1], outn); i += 2; };

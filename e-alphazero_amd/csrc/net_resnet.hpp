@@ -6,27 +6,38 @@
 //   hk.BatchNorm (eval): y = (x - mean) * inv + offset, inv = scale / sqrt(var + 1e-5) precomputed on the host
 //   hk.Linear / 1x1 conv: k-ascending fmaf chain, then + b
 //
-// Kernel shape: one 256-thread workgroup carries THREE samples (3 x 42 = 126 board cells = rows of the implicit GEMM, padded to
-// 128) through the WHOLE tower without touching HBM: the residual stream X and the activated conv input U live in LDS
-// ([128][65] f32 each + one zero row, 67 KB -> two workgroups per CU, so one workgroup's MFMAs fill the other's barriers and
-// epilogues), weights (147 KB per 3x3 conv, shared by every workgroup) stream from L2 one group of 8 k-steps ahead.  Each wave
-// owns 32 rows x all 64 output channels = 2x4 tiles of v_mfma_f32_16x16x4_f32; the A operand is gathered from U through
-// per-tap neighbour-row pointers (2 ds_read_b32 per k-step), so no im2col buffer exists.  (Six samples / 4x4 tiles per wave, one
-// workgroup per CU, measured 2.87 ms at B = 8192: 81 % MFMA issue in the tower, 11 % lost to the last partial round of 1366
-// workgroups on 256 CUs.)
+// Kernel shape (round 4): one 256-thread workgroup carries FOUR samples (4 x 42 = 168 board cells = rows of the implicit GEMM, padded to
+// 176 = 11 tiles of 16) through the WHOLE tower without touching HBM.  B = 8192 is then 2048 workgroups = exactly four rounds on the 512
+// slots of two workgroups per CU (three samples per workgroup: 2731 workgroups = 5.33 rounds, six paid -- 11 % of the launch).  Wave w owns
+// output channels 16 w .. 16 w + 15 for ALL rows: 11 x 1 tiles of v_mfma_f32_16x16x4_f32 per k-step on one B operand, so a wave streams a
+// quarter of the weights (147 KB per 3x3 conv, shared by every workgroup, from L2 one group of 8 k-steps ahead: two 16-byte buffer loads,
+// the host packs four consecutive k-steps of a lane side by side).  The residual stream X never leaves the accumulator layout (44
+// registers per lane); only the activated conv input U lives in LDS ([176][65] f32 + one zero row, 46 KB) beside a 27 KB table of the
+// neighbour rows per tap (78 KB in all: two workgroups per CU).  The A operand is gathered from U through the table's per-tap row
+// addresses (11 ds_read_b32 per k-step, paired by the compiler), so no im2col buffer exists.
+// (Before: three samples, 2 x 4 tiles per wave, X and U in LDS, 1.996 ms at B = 8192; six samples / 4 x 4 tiles, one workgroup per CU: 2.87 ms.)
 #pragma once
 #include "net_fc.hpp"
 
 namespace eaz {
 
-constexpr int kRnSamples = 3;   // samples per workgroup
-constexpr int kRnRows = 128;    // GEMM rows per workgroup (126 used)
-constexpr int kRnMT = kRnRows / 64;  // 16-row MFMA tiles per wave
+constexpr int kRnSamples = 4;   // samples per workgroup
+constexpr int kRnMT = 11;       // 16-row MFMA tiles of a workgroup's rows; every wave walks all of them for its own 16 channels
+constexpr int kRnRows = 16 * kRnMT;  // GEMM rows per workgroup (168 used)
 constexpr int kRnLD = 65;       // LDS leading dimension (floats)
 constexpr int kRnC = 64;        // channels the kernel is specialised for (resnet.py:48)
 constexpr int kRnMaxConv = 33;  // conv0 + 2 * 16 blocks
-constexpr int kRnZeroRow = 2 * kRnRows;  // one all-zero row behind the X and U tiles: the source of every off-board tap
-constexpr int kRnLdsBytes = (2 * kRnRows + 1) * kRnLD * 4;
+constexpr int kRnZeroRow = kRnRows;  // one all-zero row behind the U tile: the source of every off-board tap
+constexpr int kRnHdFloats = kRnSamples * (84 * 2 + 42 * 2);  // the heads' per-cell outputs, behind the zero row (before the tower: the rows' tap masks)
+static_assert(kRnHdFloats >= kRnRows, "tap masks fit the heads' region");
+constexpr int kRnHdOff = (((kRnRows + 1) * kRnLD * 4 + 15) / 16) * 16;  // byte offsets into the workgroup's LDS
+constexpr int kRnTabOff = kRnHdOff + kRnHdFloats * 4;
+// neighbour-row table [9 taps][64 lanes][12]: LDS address of (row of the lane's tile row s under the tap, or the zero row) + the lane's k
+// quarter, built once per workgroup -- resolving the 11 rows of a lane per tap in registers cost ~55 VALU instructions per tap, each beside
+// the MFMA stream
+constexpr int kRnTabBytes = 9 * 64 * 12 * 4;
+constexpr int kRnLdsBytes = kRnTabOff + kRnTabBytes;  // 77.7 KB: two workgroups per CU (2048 workgroups on 768 slots would be 2.67 rounds)
+static_assert(kRnTabOff % 16 == 0 && 2 * kRnLdsBytes <= 160 * 1024 && 3 * kRnLdsBytes > 160 * 1024, "ResNet LDS layout");
 
 struct ResNetDev {
     int H, W, Cin, cin_log2, nb, A, P;
@@ -37,158 +48,170 @@ struct ResNetDev {
     int lin_w[6], lin_b[6];                                            // policy, exploration, value fc1, value fc2, ube fc1, ube fc2
 };
 
-// rows of this lane: m_s = 16*MT*wave + MT*i + s  (i = lane & 15, s < MT); cell (h, w) of the row and a 9-bit mask of the taps
-// that stay on the board
+// Device layout of a 64 -> 64 3x3 convolution's weights (host: resnet_pack_tower_conv in eaz_api.hip): the B operand of k-step ks for lane
+// (kq = lane >> 4, channel c) is W[4 ks + kq][c]; four consecutive k-steps of one lane sit side by side, so one 16-byte load serves four:
+//   Wp[((ks4 * 4 + kq) * 64 + c) * 4 + q] = W[(4 * (4 * ks4 + q) + kq) * 64 + c]
+constexpr int kRnPackBytes = 4 * kRnC * 4 * 4;  // one group of four k-steps
+
+// rows of this lane as an A operand: m_s = MT*i + s  (i = lane & 15, s < MT); a 9-bit mask of the taps of the row's cell (h, w) that stay
+// on the board
 struct RnLane {
     int m[kRnMT];
     unsigned tapmask[kRnMT];
 };
 
-__device__ __forceinline__ RnLane rn_lane(const ResNetDev& n, int wave, int lane, int rows_valid) {
+// The tap mask of ONE row (thread t < kRnRows computes row t's; the division by the board's width is not cheap, and a lane needs eleven)
+__device__ __forceinline__ unsigned rn_row_mask(const ResNetDev& n, int m, int rows_valid) {
+    unsigned mask = 0;
+    if (m < rows_valid) {
+        const int cell = m % n.P, h = cell / n.W, w = cell - h * n.W;
+        for (int t = 0; t < 9; ++t) {
+            const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+            if (hh >= 0 && hh < n.H && ww >= 0 && ww < n.W) mask |= 1u << t;
+        }
+    }
+    return mask;
+}
+
+__device__ __forceinline__ RnLane rn_lane(const uint32_t* row_mask /* LDS, [kRnRows] */, int lane) {
     RnLane L;
 #pragma unroll
     for (int s = 0; s < kRnMT; ++s) {
-        const int m = 16 * kRnMT * wave + kRnMT * (lane & 15) + s;
-        L.m[s] = m;
-        unsigned mask = 0;
-        if (m < rows_valid) {
-            const int cell = m % n.P, h = cell / n.W, w = cell - h * n.W;
-            for (int t = 0; t < 9; ++t) {
-                const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
-                if (hh >= 0 && hh < n.H && ww >= 0 && ww < n.W) mask |= 1u << t;
-            }
-        }
-        L.tapmask[s] = mask;
+        L.m[s] = kRnMT * (lane & 15) + s;
+        L.tapmask[s] = row_mask[L.m[s]];
     }
     return L;
 }
 
-// one 3x3 (or input) convolution as an implicit GEMM: acc[s][t] += gather(U)[rows][k] * Wc[k][cols]
-typedef float rn_avec __attribute__((ext_vector_type(kRnMT)));
-#define EAZ_RN_MFMA(acc, a, b)                                                                 \
-    _Pragma("unroll") for (int s_ = 0; s_ < kRnMT; ++s_) _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) \
-        acc[s_][t_] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_], b[t_], acc[s_][t_], 0, 0, 0)
+#define EAZ_RN_MFMA(acc, a, b) \
+    _Pragma("unroll") for (int s_ = 0; s_ < kRnMT; ++s_) acc[s_] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_], b, acc[s_], 0, 0, 0)
 
-__device__ __forceinline__ void rn_conv(floatx4 (&acc)[kRnMT][4], const ResNetDev& n, const float* U, const float* Wc, int K, int cin_log2,
-                                        const RnLane& L, int lane) {
-    const int r = lane & 15, kq = lane >> 4, col = 4 * r;
+// the input convolution (any Cin, K = 9 * Cin padded to 4) as an implicit GEMM: acc[s] += gather(U)[rows][k] * Wc[k][16 wave + j]; weights in
+// the plain [K][64] layout.  k-steps past the end use an all-zero weight fragment (exact, see net_fc.hpp)
+__device__ __forceinline__ void rn_conv(floatx4 (&acc)[kRnMT], const ResNetDev& n, const float* U, const float* Wc, int K, int cin_log2,
+                                        const RnLane& L, int wave, int lane) {
+    const int kq = lane >> 4, col = 16 * wave + (lane & 15);
     const int nsteps = K >> 2;
-    BGroup bc, bn;
-    auto load_b = [&](BGroup& b, int ks0) {
+    for (int ks = 0; ks < nsteps; ++ks) {
+        const int k = 4 * ks + kq;
+        const float b = Wc[static_cast<long>(k) * kRnC + col];
+        const int tap = k >> cin_log2, ci = k & ((1 << cin_log2) - 1);
+        const int off = (tap / 3 - 1) * n.W + (tap % 3 - 1);
+        float a[kRnMT];
 #pragma unroll
-        for (int i = 0; i < kFcG; ++i) {
-            const int k = 4 * (ks0 + i) + kq;
-            const bool ok = ks0 + i < nsteps;
-            const floatx4 v = *reinterpret_cast<const floatx4*>(Wc + static_cast<long>(ok ? k : kq) * kRnC + col);
-            b.v[i] = floatx4{ok ? v[0] : 0.0f, ok ? v[1] : 0.0f, ok ? v[2] : 0.0f, ok ? v[3] : 0.0f};
+        for (int s = 0; s < kRnMT; ++s) {
+            const bool ok = tap < 9 && ((L.tapmask[s] >> tap) & 1u);
+            const int row = ok ? L.m[s] + off : L.m[s];
+            const float v = U[row * kRnLD + ci];
+            a[s] = ok ? v : 0.0f;
         }
-    };
-    load_b(bc, 0);
-#pragma clang loop unroll(disable)
-    for (int ks0 = 0; ks0 < nsteps; ks0 += kFcG) {
-        load_b(bn, ks0 + kFcG);  // past the end: row kq, zeroed
-#pragma unroll
-        for (int i = 0; i < kFcG; ++i) {
-            // k-steps past the end reuse the last valid one with an all-zero weight fragment (exact, see net_fc.hpp)
-            const int ks = ks0 + i < nsteps ? ks0 + i : nsteps - 1;
-            const int k = 4 * ks + kq;
-            const int tap = k >> cin_log2, ci = k & ((1 << cin_log2) - 1);
-            const int off = (tap / 3 - 1) * n.W + (tap % 3 - 1);
-            rn_avec a;
-#pragma unroll
-            for (int s = 0; s < kRnMT; ++s) {
-                const bool ok = tap < 9 && ((L.tapmask[s] >> tap) & 1u);
-                const int row = ok ? L.m[s] + off : L.m[s];
-                const float v = U[row * kRnLD + ci];
-                a[s] = ok ? v : 0.0f;
-            }
-            EAZ_RN_MFMA(acc, a, bc.v[i]);
-        }
-        bc = bn;
+        EAZ_RN_MFMA(acc, a, b);
     }
 }
 
 // 3x3 convolution over 64 input channels: the tap of a k-step is wave-uniform (k = 4*ks + kq, 64 channels per tap -> tap = ks / 16),
-// so the neighbour row of every lane is resolved ONCE per tap -- off-board taps point at the all-zero row -- and the 16 k-steps
-// of the tap are nothing but 4 ds_read_b32 with immediate offsets + 16 MFMAs each.
-__device__ __forceinline__ void rn_conv64(floatx4 (&acc)[kRnMT][4], const ResNetDev& n, const float* U, const float* Wc, const RnLane& L, int lane) {
-    const int r = lane & 15, kq = lane >> 4, col = 4 * r;
-    BGroup b0, b1;
-    // weights through a buffer resource: the lane's part of the address (row kq, columns col .. col + 3) never changes and the k-step goes into
-    // the scalar offset -- a global_load needs three 64-bit VALU instructions per refill, and every VALU instruction between the MFMAs of this
-    // loop costs the matrix pipe ~18 clocks
+// so the neighbour rows of a lane change ONCE per tap -- three 16-byte reads of the table, requested a tap ahead; off-board taps point at
+// the all-zero row -- and the 16 k-steps of the tap are nothing but 11 ds_read_b32 with immediate offsets + 11 MFMAs each.
+__device__ __forceinline__ void rn_conv64(floatx4 (&acc)[kRnMT], const uint8_t* lds, const float* Wc, int wave, int lane) {
+    const int kq = lane >> 4;
+    floatx4 b0[2], b1[2];
+    // weights through a buffer resource: the lane's part of the address never changes and the k-step group goes into the scalar offset -- a
+    // global_load needs three 64-bit VALU instructions per refill, and every VALU instruction between the MFMAs of this loop costs the
+    // matrix pipe ~18 clocks
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wc), 0, 9 * kRnC * kRnC * 4, 0x00020000);
-    const int wvoff = (kq * kRnC + col) * 4;
-    auto load_b = [&](BGroup& b, int ks0) {
+    const int wvoff = (kq * kRnC + 16 * wave + (lane & 15)) * 16;
+    auto load_b = [&](floatx4 (&b)[2], int ks0) {  // the 8 k-steps ks0 .. ks0 + 7 (ks0 a multiple of 8)
 #pragma unroll
-        for (int i = 0; i < kFcG; ++i) b.v[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff, (ks0 + i) * (4 * kRnC * 4), 0));
+        for (int g = 0; g < 2; ++g) b[g] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff, ((ks0 >> 2) + g) * kRnPackBytes, 0));
     };
-    auto compute = [&](const BGroup& b, const float* const (&src)[kRnMT], int half) {
+    const uint4* tab = reinterpret_cast<const uint4*>(lds + kRnTabOff) + lane * 3;
+    auto load_t = [&](uint4 (&t)[3], int tap) {
 #pragma unroll
-        for (int i = 0; i < kFcG; ++i) {
+        for (int g = 0; g < 3; ++g) t[g] = tab[tap * (64 * 3) + g];
+    };
+    auto compute = [&](const floatx4 (&b)[2], const uint4 (&t)[3], int half) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
             const int ci0 = 4 * (half * 8 + i);
-            rn_avec a;
+            float a[kRnMT];
 #pragma unroll
-            for (int s = 0; s < kRnMT; ++s) a[s] = src[s][ci0];
-            EAZ_RN_MFMA(acc, a, b.v[i]);
+            for (int s = 0; s < kRnMT; ++s) {
+                const uint32_t o = s & 3 ? (s & 3) == 1 ? t[s >> 2].y : (s & 3) == 2 ? t[s >> 2].z : t[s >> 2].w : t[s >> 2].x;
+                a[s] = ((const __attribute__((address_space(3))) float*)o)[ci0];  // `o` is the LDS address itself: no add per row and tap
+            }
+            EAZ_RN_MFMA(acc, a, b[i >> 2][i & 3]);
         }
     };
-    load_b(b0, 0);
-#pragma clang loop unroll(disable)
-    for (int tap = 0; tap < 9; ++tap) {
-        const int off = (tap / 3 - 1) * n.W + (tap % 3 - 1);
-        const float* src[kRnMT];
-#pragma unroll
-        for (int s = 0; s < kRnMT; ++s) {
-            const bool ok = (L.tapmask[s] >> tap) & 1u;
-            // U is the second tile: the all-zero row sits kRnRows rows behind U's first row
-            src[s] = U + (ok ? L.m[s] + off : kRnZeroRow - kRnRows) * kRnLD + kq;
-        }
-        // weights of the next 8 k-steps are requested before the MFMAs of the current 8 and consumed after them (two register sets,
-        // scheduling barriers pin the order; the very last request re-reads the last group: unconditional loads keep the
-        // compiler's outstanding-load count exact, so it waits with vmcnt(8..1) instead of vmcnt(0))
+    // weights of the next 8 k-steps are requested before the MFMAs of the current 8 and consumed after them (two register sets,
+    // scheduling barriers pin the order; the very last request re-reads the last group: unconditional loads keep the
+    // compiler's outstanding-load count exact, so it waits with a counted vmcnt instead of vmcnt(0)); the row addresses likewise: two sets,
+    // the taps taken in pairs so that no set is ever copied
+    auto one_tap = [&](int tap, const uint4 (&tc)[3], uint4 (&tn)[3]) {
+        load_t(tn, tap < 8 ? tap + 1 : tap);
         load_b(b1, tap * 16 + 8);
         __builtin_amdgcn_sched_barrier(kSchedPin);
-        compute(b0, src, 0);
+        compute(b0, tc, 0);
         __builtin_amdgcn_sched_barrier(kSchedPin);
         load_b(b0, tap < 8 ? tap * 16 + 16 : tap * 16 + 8);
         __builtin_amdgcn_sched_barrier(kSchedPin);
-        compute(b1, src, 1);
+        compute(b1, tc, 1);
         __builtin_amdgcn_sched_barrier(kSchedPin);
+    };
+    uint4 t0[3], t1[3];
+    load_b(b0, 0);
+    load_t(t0, 0);
+#pragma clang loop unroll(disable)
+    for (int tap = 0; tap < 8; tap += 2) {
+        one_tap(tap, t0, t1);
+        one_tap(tap + 1, t1, t0);
     }
+    one_tap(8, t0, t1);
 }
 
-__device__ __forceinline__ void rn_zero(floatx4 (&acc)[kRnMT][4]) {
+__device__ __forceinline__ void rn_zero(floatx4 (&acc)[kRnMT]) {
 #pragma unroll
-    for (int s = 0; s < kRnMT; ++s)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[s][t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s = 0; s < kRnMT; ++s) acc[s] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
 }
 
-// accumulator element (s, t, reg) of lane (j = lane & 15, kq = lane >> 4) is row 16*MT*wave + MT*(4*kq + reg) + s, channel 4*j + t
-#define EAZ_RN_FOREACH(BODY)                                                      \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                               \
-        const int ch = 4 * (lane & 15) + t;                                       \
-        _Pragma("unroll") for (int reg = 0; reg < 4; ++reg)                       \
-            _Pragma("unroll") for (int s = 0; s < kRnMT; ++s) {                   \
-                const int row = 16 * kRnMT * wave + kRnMT * (4 * (lane >> 4) + reg) + s; \
-                BODY                                                              \
-            }                                                                     \
-    }
+// accumulator element (s, reg) of lane (j = lane & 15, kq = lane >> 4) is row MT*(4*kq + reg) + s, channel `ch` = 16*wave + j
+#define EAZ_RN_FOREACH(BODY)                                              \
+    _Pragma("unroll") for (int reg = 0; reg < 4; ++reg)                   \
+        _Pragma("unroll") for (int s = 0; s < kRnMT; ++s) {               \
+            const int row = kRnMT * (4 * (lane >> 4) + reg) + s;          \
+            BODY                                                          \
+        }
 
 __global__ void __launch_bounds__(256, 2) resnet_forward_kernel(ResNetDev n, const uint8_t* __restrict__ obs, int B, NetOut out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    float* X = reinterpret_cast<float*>(lds);
-    float* U = X + kRnRows * kRnLD;
+    float* U = reinterpret_cast<float*>(lds);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ch = 16 * wave + (lane & 15);  // the channel of this lane's accumulator elements
     const int s0 = blockIdx.x * kRnSamples;
     const int nsamp = B - s0 < kRnSamples ? B - s0 : kRnSamples;
     const int rows_valid = nsamp * n.P;
     const float* p = n.p;
-    const RnLane L = rn_lane(n, wave, lane, rows_valid);
+    // the rows' tap masks, one row per thread, through the (still unused) heads' region
+    uint32_t* row_mask = reinterpret_cast<uint32_t*>(lds + kRnHdOff);
+    if (tid < kRnRows) row_mask[tid] = rn_row_mask(n, tid, rows_valid);
+    __syncthreads();
+    const RnLane L = rn_lane(row_mask, lane);
     const int D = n.P * n.Cin;
     EAZ_STAMP(0);
-    if (tid < kRnLD) X[kRnZeroRow * kRnLD + tid] = 0.0f;
+    if (tid < kRnLD) U[kRnZeroRow * kRnLD + tid] = 0.0f;
+    {
+        // the neighbour-row table of rn_conv64 (the same for the four waves: wave w fills taps w, w + 4, w + 8)
+        uint32_t* T = reinterpret_cast<uint32_t*>(lds + kRnTabOff);
+        for (int t = wave; t < 9; t += 4) {
+            const int off = (t / 3 - 1) * n.W + (t % 3 - 1);
+#pragma unroll
+            for (int s = 0; s < kRnMT; ++s) {
+                const bool ok = (L.tapmask[s] >> t) & 1u;
+                // the low half of an LDS location's flat address is its LDS address
+                T[(t * 64 + lane) * 12 + s] = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(U + (ok ? L.m[s] + off : kRnZeroRow) * kRnLD + (lane >> 4)));
+            }
+            T[(t * 64 + lane) * 12 + 11] = 0u;
+        }
+    }
 
     // ---- input: observation bytes -> U[row][ci] as f32 (resnet.py:69) ----
     for (int i = tid; i < kRnRows * n.Cin; i += 256) {
@@ -199,15 +222,18 @@ __global__ void __launch_bounds__(256, 2) resnet_forward_kernel(ResNetDev n, con
     }
     __syncthreads();
 
-    floatx4 acc[kRnMT][4];
+    floatx4 acc[kRnMT], xr[kRnMT];  // xr: the residual stream X, in the accumulator layout for the whole tower
     // ---- input conv (resnet.py:70): X = conv0(U) + b ----
     rn_zero(acc);
-    rn_conv(acc, n, U, p + n.conv_w[0], n.conv_k[0], n.cin_log2, L, lane);
+    rn_conv(acc, n, U, p + n.conv_w[0], n.conv_k[0], n.cin_log2, L, wave, lane);
     {
-        const float* b = p + n.conv_b[0];
-        EAZ_RN_FOREACH(X[row * kRnLD + ch] = acc[s][t][reg] + b[ch];)
+        const float b = p[n.conv_b[0] + ch];
+#pragma unroll
+        for (int s = 0; s < kRnMT; ++s)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) xr[s][reg] = acc[s][reg] + b;
     }
-    __syncthreads();
+    __syncthreads();  // every wave has read the observation out of U
 
     EAZ_STAMP(1);
     // ---- residual tower: BlockV2 (resnet.py:31-39) ----
@@ -215,85 +241,155 @@ __global__ void __launch_bounds__(256, 2) resnet_forward_kernel(ResNetDev n, con
         // U = relu(bn(X)) with bn = bn1 of this block, or the final batch norm (resnet.py:79-81) when blk == nb
         {
             const int bi = 2 * blk;
-            const float *mean = p + n.bn_mean[bi], *inv = p + n.bn_inv[bi], *off = p + n.bn_off[bi];
-            for (int i = tid; i < kRnRows * kRnC; i += 256) {
-                const int row = i >> 6, ch = i & 63;
-                const float v = (X[row * kRnLD + ch] - mean[ch]) * inv[ch] + off[ch];
+            const float mean = p[n.bn_mean[bi] + ch], inv = p[n.bn_inv[bi] + ch], off = p[n.bn_off[bi] + ch];
+            EAZ_RN_FOREACH({
+                const float v = (xr[s][reg] - mean) * inv + off;
                 U[row * kRnLD + ch] = v > 0.0f ? v : 0.0f;
-            }
+            })
         }
         __syncthreads();
         if (blk == n.nb) break;
         // conv1, then U = relu(bn2(conv1 + b)) written in place once every wave has finished reading U
         rn_zero(acc);
-        rn_conv64(acc, n, U, p + n.conv_w[1 + 2 * blk], L, lane);
+        rn_conv64(acc, lds, p + n.conv_w[1 + 2 * blk], wave, lane);
         __syncthreads();
         {
-            const float* b = p + n.conv_b[1 + 2 * blk];
-            const float *mean = p + n.bn_mean[2 * blk + 1], *inv = p + n.bn_inv[2 * blk + 1], *off = p + n.bn_off[2 * blk + 1];
+            const float b = p[n.conv_b[1 + 2 * blk] + ch];
+            const float mean = p[n.bn_mean[2 * blk + 1] + ch], inv = p[n.bn_inv[2 * blk + 1] + ch], off = p[n.bn_off[2 * blk + 1] + ch];
             EAZ_RN_FOREACH({
-                const float v = ((acc[s][t][reg] + b[ch]) - mean[ch]) * inv[ch] + off[ch];
+                const float v = ((acc[s][reg] + b) - mean) * inv + off;
                 U[row * kRnLD + ch] = v > 0.0f ? v : 0.0f;
             })
         }
         __syncthreads();
-        // conv2 + skip: X = (conv2 + b) + X   (only this wave touches these rows of X)
+        // conv2 + skip: X = (conv2 + b) + X, in registers
         rn_zero(acc);
-        rn_conv64(acc, n, U, p + n.conv_w[2 + 2 * blk], L, lane);
+        rn_conv64(acc, lds, p + n.conv_w[2 + 2 * blk], wave, lane);
         {
-            const float* b = p + n.conv_b[2 + 2 * blk];
-            EAZ_RN_FOREACH(X[row * kRnLD + ch] = (acc[s][t][reg] + b[ch]) + X[row * kRnLD + ch];)
+            const float b = p[n.conv_b[2 + 2 * blk] + ch];
+#pragma unroll
+            for (int s = 0; s < kRnMT; ++s)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) xr[s][reg] = (acc[s][reg] + b) + xr[s][reg];
         }
-        __syncthreads();
+        __syncthreads();  // every wave has finished reading U before the next block's bn1 overwrites it
     }
 
     EAZ_STAMP(2);
-    // ---- heads: 1x1 conv -> bn -> relu per cell, results into the (now free) X region ----
+    // ---- heads: 1x1 conv -> bn -> relu per cell, results into their own LDS region ----
     // Hd layout: [sample][head][up to 84 floats] with head 0/1 = (cell, 2 planes) interleaved, head 2/3 = 42 cells
-    float* Hd = X;
+    float* Hd = reinterpret_cast<float*>(lds + kRnHdOff);  // behind the zero row
     constexpr int kHdStride = 84 * 2 + 42 * 2;  // floats per sample
-    if (tid < rows_valid) {
-        const int smp = tid / n.P, cell = tid - smp * n.P;
-        const float* u = U + tid * kRnLD;
+    // On MFMA, like the tower (the k-ascending chain of a v_mfma_f32_16x16x4_f32 IS the oracle's fmaf chain): as VALU chains beside the co-resident
+    // workgroup's MFMA stream the heads took 21 % of a workgroup's timeline, and two workgroups that start together reach them together.
+    const int hj = lane & 15, hkq = lane >> 4;
+    {
+        // columns of the 1x1 convolutions side by side: policy 0-1, exploration 2-3, value 4, ube 5 (B operand: W[k][column], zero beyond)
+        const int hh = hj < 2 ? 0 : hj < 4 ? 1 : hj - 2, hco = hj < 4 ? hj & 1 : 0, hnco = hj < 4 ? 2 : 1;
+        const bool hcol = hj < 6;
+        const int h_ = hcol ? hh : 0;
+        float wb[16];
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int nco = h < 2 ? 2 : 1;
-            const float *w = p + n.hc_w[h], *b = p + n.hc_b[h];
-            const float *mean = p + n.hbn_mean[h], *inv = p + n.hbn_inv[h], *off = p + n.hbn_off[h];
-            for (int co = 0; co < nco; ++co) {
-                float a = 0.0f;
-#pragma unroll 8
-                for (int ci = 0; ci < kRnC; ++ci) a = __builtin_fmaf(u[ci], w[ci * nco + co], a);
-                float v = ((a + b[co]) - mean[co]) * inv[co] + off[co];
-                v = v > 0.0f ? v : 0.0f;
-                const int base = smp * kHdStride + (h < 2 ? h * 84 : 168 + (h - 2) * 42);
-                Hd[base + cell * nco + co] = v;  // hk.Flatten keeps (h, w, c) order
+        for (int ks = 0; ks < 16; ++ks) {
+            const float v = p[n.hc_w[h_] + (4 * ks + hkq) * hnco + hco];
+            wb[ks] = hcol ? v : 0.0f;
+        }
+        const float hb = p[n.hc_b[h_] + hco], hmean = p[n.hbn_mean[h_] + hco], hinv = p[n.hbn_inv[h_] + hco], hoff = p[n.hbn_off[h_] + hco];
+        for (int T = wave; T < kRnMT; T += 4) {
+            const float* u = U + (16 * T + hj) * kRnLD + hkq;
+            floatx4 d = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(u[4 * ks], wb[ks], d, 0, 0, 0);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = 16 * T + 4 * hkq + reg;
+                if (hcol && row < rows_valid) {
+                    const int smp = (row >= n.P) + (row >= 2 * n.P) + (row >= 3 * n.P), cell = row - smp * n.P;  // kRnSamples = 4
+                    float v = ((d[reg] + hb) - hmean) * hinv + hoff;
+                    v = v > 0.0f ? v : 0.0f;
+                    const int base = smp * kHdStride + (hh < 2 ? hh * 84 : 168 + (hh - 2) * 42);
+                    Hd[base + cell * hnco + hco] = v;  // hk.Flatten keeps (h, w, c) order
+                }
             }
         }
     }
     __syncthreads();
     EAZ_STAMP(3);
-    // linear layers: policy / exploration (84 -> A) and the first fc of value / ube (42 -> 64, relu) into U
+    // linear layers: policy / exploration (84 -> A; waves 0 / 1) and the first fc of value / ube (42 -> 64, relu; waves 2 / 3) into U.
+    // Rows of the MFMA tile = the workgroup's samples (4 of 16 used), K padded to a multiple of 4 with zero operands (fmaf(0, 0, acc) = acc).
     float* Fc = U;  // [sample][2][64]
-    for (int i = tid; i < nsamp * (2 * n.A + 2 * kRnC); i += 256) {
-        const int smp = i / (2 * n.A + 2 * kRnC), j = i - smp * (2 * n.A + 2 * kRnC);
-        if (j < 2 * n.A) {
+    if (wave < 2 && n.A <= 16) {
+        const int h = wave, K = 2 * n.P;
+        const float *w = p + n.lin_w[h], *b = p + n.lin_b[h];
+        const float* x = Hd + (hj < nsamp ? hj : 0) * kHdStride + h * 84;
+        floatx4 d = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        float av[21], bv[21];  // K <= 84 (the host refuses boards of more than 42 cells): every operand requested before the chain starts
+#pragma unroll
+        for (int i = 0; i < 21; ++i) {
+            const int k = 4 * i + hkq;
+            const bool ok = k < K;
+            const float xa = x[ok ? k : 0], wv = w[(ok ? k : 0) * n.A + (hj < n.A ? hj : 0)];
+            av[i] = ok && hj < nsamp ? xa : 0.0f;
+            bv[i] = ok && hj < n.A ? wv : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 21; ++i) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], d, 0, 0, 0);  // all-zero k-steps past K leave d as it is
+        float* dst = h == 0 ? out.exploit : out.explore;  // resnet.py:84-98
+        if (dst && hkq == 0 && hj < n.A) {
+            const float bb = b[hj];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                if (reg < nsamp) dst[static_cast<long>(s0 + reg) * n.A + hj] = d[reg] + bb;
+        }
+    } else if (wave >= 2) {
+        const int h = wave - 2, K = n.P;  // h: 0 value, 1 ube
+        const float *w = p + n.lin_w[2 + 2 * h], *b = p + n.lin_b[2 + 2 * h];
+        const float* x = Hd + (hj < nsamp ? hj : 0) * kHdStride + 168 + h * 42;
+        floatx4 d[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) d[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        float av[11], bv[11][4];  // K <= 42
+#pragma unroll
+        for (int ks = 0; ks < 11; ++ks) {
+            const int k = 4 * ks + hkq;
+            const bool ok = k < K;
+            const float xa = x[ok ? k : 0];
+            av[ks] = ok && hj < nsamp ? xa : 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float wv = w[(ok ? k : 0) * kRnC + 16 * t + hj];
+                bv[ks][t] = ok ? wv : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 11; ++ks)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks][t], d[t], 0, 0, 0);
+        if (hkq == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int c = 16 * t + hj;
+                const float bb = b[c];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float z = d[t][reg] + bb;
+                    if (reg < nsamp) Fc[(reg * 2 + h) * kRnC + c] = z > 0.0f ? z : 0.0f;  // resnet.py:105-106 / :117-118
+                }
+            }
+        }
+    }
+    if (n.A > 16) {
+        // more actions than one MFMA tile has columns: the policy / exploration layers as plain chains
+        for (int i = tid; i < nsamp * 2 * n.A; i += 256) {
+            const int smp = i / (2 * n.A), j = i - smp * (2 * n.A);
             const int h = j / n.A, a_ = j - h * n.A;
             const float *w = p + n.lin_w[h], *b = p + n.lin_b[h];
             const float* x = Hd + smp * kHdStride + h * 84;
             float z = 0.0f;
             for (int k = 0; k < 2 * n.P; ++k) z = __builtin_fmaf(x[k], w[k * n.A + a_], z);
             z = z + b[a_];
-            float* dst = h == 0 ? out.exploit : out.explore;  // resnet.py:84-98
+            float* dst = h == 0 ? out.exploit : out.explore;
             if (dst) dst[static_cast<long>(s0 + smp) * n.A + a_] = z;
-        } else {
-            const int jj = j - 2 * n.A, h = jj >> 6, c = jj & 63;  // h: 0 value, 1 ube
-            const float *w = p + n.lin_w[2 + 2 * h], *b = p + n.lin_b[2 + 2 * h];
-            const float* x = Hd + smp * kHdStride + 168 + h * 42;
-            float z = 0.0f;
-            for (int k = 0; k < n.P; ++k) z = __builtin_fmaf(x[k], w[k * kRnC + c], z);
-            z = z + b[c];
-            Fc[(smp * 2 + h) * kRnC + c] = z > 0.0f ? z : 0.0f;  // resnet.py:105-106 / :117-118
         }
     }
     __syncthreads();
@@ -303,6 +399,7 @@ __global__ void __launch_bounds__(256, 2) resnet_forward_kernel(ResNetDev n, con
         const float *w = p + n.lin_w[3 + 2 * h], *b = p + n.lin_b[3 + 2 * h];
         const float* x = Fc + (smp * 2 + h) * kRnC;
         float z = 0.0f;
+#pragma unroll 16
         for (int k = 0; k < kRnC; ++k) z = __builtin_fmaf(x[k], w[k], z);
         z = z + b[0];
         if (h == 0) {

@@ -122,7 +122,9 @@ def test_register_budgets_of_the_per_simulation_kernels(asm, pattern):
 @pytest.mark.parametrize("stem", ["search_persist_kernel", "subleq16_search_kernel", "subleq16_selfplay_kernel", "fc16p_forward_kernel", "resnet_forward_kernel"])
 def test_weight_stream_is_buffer_loads(asm, stem):
     body, _ = kernel(asm, stem)
-    assert count(body, "buffer_load_dwordx4") >= 16, "the weight stream (16 k-steps of 16-byte buffer loads in flight) is gone"
+    # the ResNet's 16-byte loads serve four k-steps each (host-packed operand order, net_resnet.hpp): 2 per group of 8 k-steps, 6 per convolution site
+    need = 12 if stem == "resnet_forward_kernel" else 16
+    assert count(body, "buffer_load_dwordx4") >= need, "the weight stream (16 k-steps of 16-byte buffer loads in flight) is gone"
 
 
 @pytest.mark.parametrize("stem", ["subleq16_search_kernel", "subleq16_selfplay_kernel"])
@@ -188,6 +190,6 @@ def test_layer_loops_carry_no_avoidable_vector_alu_work(asm):
     body, _ = kernel(asm, "subleq16_selfplay_kernel")
     assert count(body, "v_cvt_pk_f32_fp8_e32") + count(body, "v_cvt_pk_f32_fp8_sdwa") + count(body, "v_cvt_pk_f32_fp8") >= 24
     body, _ = kernel(asm, "resnet_forward_kernel")
-    assert count(body, "buffer_load_dwordx4") >= 24 and count(body, "global_load_dwordx4") <= 48
+    assert count(body, "buffer_load_dwordx4") >= 12 and count(body, "global_load_dwordx4") <= 48
     _, meta = kernel(asm, "search_persist_kernel")
     assert meta.get("max_flat_workgroup_size", 512) == 512
