@@ -677,7 +677,7 @@ def test_connect4_env_matches_oracle(oracle, eaz, torch):
     assert f["terminated"].any() and not f["terminated"].all()
 
 
-@pytest.mark.parametrize("nb,B", [(1, 50), (5, 97)])
+@pytest.mark.parametrize("nb,B", [(1, 50), (5, 97), (1, 3), (2, 51)])  # the last workgroup holds 2, 1, 3, 3 of its four samples
 def test_resnet_forward_matches_oracle(oracle, eaz, torch, nb, B):
     engine, env, net, oenv, onet = _c4_setup(oracle, eaz, nb, seed=nb)
     ost, _ = oracle.random_play(oenv, B, 11, key=(1, 2))
@@ -687,6 +687,26 @@ def test_resnet_forward_matches_oracle(oracle, eaz, torch, nb, B):
     for n, a, b in zip(["exploit", "explore", "value", "ube", "novelty"], out, ref):
         np.testing.assert_allclose(a.cpu().numpy(), b, rtol=0, atol=ATOL, err_msg=n)
     print("resnet forward bit-exact vs oracle:", all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(out, ref)))
+
+
+@pytest.mark.parametrize("H,W,cin,A,B", [(5, 5, 4, 20, 11), (3, 4, 2, 5, 6), (6, 7, 2, 16, 9)])
+def test_resnet_forward_other_boards_and_action_counts(oracle, eaz, torch, H, W, cin, A, B):
+    """The tower's kernel is specialised for 64 channels and at most 42 cells, not for connect_four: smaller boards (K of the heads' linear layers
+    padded with zero operands), more input planes, and more actions than one MFMA tile has columns (the policy layers then run as plain chains)."""
+    from e_alphazero_amd import engine
+
+    nb = 2
+    params, state = eaz.params.init_resnet_params(H, W, cin, A, 64, nb, seed=H * W + A)
+    bs = eaz.params.init_hash_state(fill=0.3, seed=1)[eaz.params.HASH_MODULE]["binary_set"]
+    state[eaz.params.RESNET_HASH_MODULE] = {"binary_set": bs}
+    env = engine.EnvHandle.connect4(device=0)  # only its context is used
+    net = engine.ResNet(env.ctx, H, W, cin, A, params, state, num_blocks=nb)
+    onet = oracle.OracleNet.resnet(H, W, cin, A, eaz.params.resnet_array_list(params, state, nb), 64, nb, bitset=bs)
+    obs = (np.random.default_rng(B).random((B, H * W * cin)) < 0.4).astype(np.uint8)
+    ref = onet.forward(obs)
+    out = net.forward(torch.from_numpy(obs).cuda())
+    for n, a, b in zip(["exploit", "explore", "value", "ube", "novelty"], out, ref):
+        assert np.array_equal(a.cpu().numpy(), b), n
 
 
 @pytest.mark.parametrize("flags", [{}, dict(directed_exploration=True, exploration_beta=1.0)])
