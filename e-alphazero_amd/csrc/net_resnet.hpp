@@ -148,6 +148,7 @@ __device__ __forceinline__ void rn_conv64(floatx4 (&acc)[kRnMT], const uint8_t* 
     // the taps taken in pairs so that no set is ever copied
     auto one_tap = [&](int tap, const uint4 (&tc)[3], uint4 (&tn)[3]) {
         load_t(tn, tap < 8 ? tap + 1 : tap);
+        __builtin_amdgcn_sched_barrier(0);  // issued here, a tap ahead: left to the scheduler the three reads sink to the end of the tap, in front of their first use
         load_b(b1, tap * 16 + 8);
         __builtin_amdgcn_sched_barrier(kSchedPin);
         compute(b0, tc, 0);
