@@ -802,7 +802,7 @@ static int fc_onehot_launch(eaz_net* n, int B, const int32_t* hot, float* novelt
 static int fc_launch(eaz_net* n, int B, const uint8_t* obs, const NetOut& o, const HeadList& heads, hipStream_t st, uint8_t* scratch) {
     if (B <= 0 || heads.n <= 0) return 0;
     if (n->kind == 1) {  // residual tower: kRnSamples samples per workgroup, all heads in one launch
-        resnet_forward_kernel<<<cdiv(B, kRnSamples), 256, kRnLdsBytes, st>>>(n->rdev, obs, B, o);
+        resnet_forward_kernel<<<cdiv(B, kRnSamples), kRnThreads, kRnLdsBytes, st>>>(n->rdev, obs, B, o);
         LAUNCH_OK();
         return 0;
     }

@@ -21,9 +21,11 @@
 
 namespace eaz {
 
-constexpr int kRnSamples = 4;   // samples per workgroup
-constexpr int kRnMT = 11;       // 16-row MFMA tiles of a workgroup's rows; every wave walks all of them for its own 16 channels
-constexpr int kRnRows = 16 * kRnMT;  // GEMM rows per workgroup (168 used)
+constexpr int kRnSamples = 8;   // samples per workgroup (512 threads: wave w owns channels 16 (w & 3) .. of the rows of half w >> 2)
+constexpr int kRnThreads = 512;
+constexpr int kRnMT0 = 11, kRnMT1 = 10;  // 16-row MFMA tiles of the two row halves: 21 tiles = 336 rows = 8 x 42 cells, no padding rows
+constexpr int kRnHalfRow = 16 * kRnMT0;  // first row of the second half
+constexpr int kRnRows = 16 * (kRnMT0 + kRnMT1);  // GEMM rows per workgroup
 constexpr int kRnLD = 65;       // LDS leading dimension (floats)
 constexpr int kRnC = 64;        // channels the kernel is specialised for (resnet.py:48)
 constexpr int kRnMaxConv = 33;  // conv0 + 2 * 16 blocks
@@ -32,12 +34,12 @@ constexpr int kRnHdFloats = kRnSamples * (84 * 2 + 42 * 2);  // the heads' per-c
 static_assert(kRnHdFloats >= kRnRows, "tap masks fit the heads' region");
 constexpr int kRnHdOff = (((kRnRows + 1) * kRnLD * 4 + 15) / 16) * 16;  // byte offsets into the workgroup's LDS
 constexpr int kRnTabOff = kRnHdOff + kRnHdFloats * 4;
-// neighbour-row table [9 taps][64 lanes][12]: LDS address of (row of the lane's tile row s under the tap, or the zero row) + the lane's k
-// quarter, built once per workgroup -- resolving the 11 rows of a lane per tap in registers cost ~55 VALU instructions per tap, each beside
-// the MFMA stream
-constexpr int kRnTabBytes = 9 * 64 * 12 * 4;
-constexpr int kRnLdsBytes = kRnTabOff + kRnTabBytes;  // 77.7 KB: two workgroups per CU (2048 workgroups on 768 slots would be 2.67 rounds)
-static_assert(kRnTabOff % 16 == 0 && 2 * kRnLdsBytes <= 160 * 1024 && 3 * kRnLdsBytes > 160 * 1024, "ResNet LDS layout");
+// neighbour-row tables [2 halves][9 taps][64 lanes][12]: LDS address of (row of the lane's tile row s under the tap, or the zero row) + the
+// lane's k quarter, built once per workgroup -- resolving the rows of a lane per tap in registers cost ~55 VALU instructions per tap, each
+// beside the MFMA stream
+constexpr int kRnTabBytes = 9 * 64 * 12 * 4;  // one half
+constexpr int kRnLdsBytes = kRnTabOff + 2 * kRnTabBytes;  // 151 KB: one workgroup per CU
+static_assert(kRnTabOff % 16 == 0 && kRnLdsBytes <= 160 * 1024, "ResNet LDS layout");
 
 struct ResNetDev {
     int H, W, Cin, cin_log2, nb, A, P;
@@ -55,9 +57,10 @@ constexpr int kRnPackBytes = 4 * kRnC * 4 * 4;  // one group of four k-steps
 
 // rows of this lane as an A operand: m_s = MT*i + s  (i = lane & 15, s < MT); a 9-bit mask of the taps of the row's cell (h, w) that stay
 // on the board
+template <int MT>
 struct RnLane {
-    int m[kRnMT];
-    unsigned tapmask[kRnMT];
+    int m[MT];
+    unsigned tapmask[MT];
 };
 
 // The tap mask of ONE row (thread t < kRnRows computes row t's; the division by the board's width is not cheap, and a lane needs eleven)
@@ -73,33 +76,35 @@ __device__ __forceinline__ unsigned rn_row_mask(const ResNetDev& n, int m, int r
     return mask;
 }
 
-__device__ __forceinline__ RnLane rn_lane(const uint32_t* row_mask /* LDS, [kRnRows] */, int lane) {
-    RnLane L;
+template <int MT>
+__device__ __forceinline__ RnLane<MT> rn_lane(const uint32_t* row_mask /* LDS, [kRnRows] */, int rbase, int lane) {
+    RnLane<MT> L;
 #pragma unroll
-    for (int s = 0; s < kRnMT; ++s) {
-        L.m[s] = kRnMT * (lane & 15) + s;
+    for (int s = 0; s < MT; ++s) {
+        L.m[s] = rbase + MT * (lane & 15) + s;
         L.tapmask[s] = row_mask[L.m[s]];
     }
     return L;
 }
 
 #define EAZ_RN_MFMA(acc, a, b) \
-    _Pragma("unroll") for (int s_ = 0; s_ < kRnMT; ++s_) acc[s_] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_], b, acc[s_], 0, 0, 0)
+    _Pragma("unroll") for (int s_ = 0; s_ < MT; ++s_) acc[s_] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_], b, acc[s_], 0, 0, 0)
 
 // the input convolution (any Cin, K = 9 * Cin padded to 4) as an implicit GEMM: acc[s] += gather(U)[rows][k] * Wc[k][16 wave + j]; weights in
 // the plain [K][64] layout.  k-steps past the end use an all-zero weight fragment (exact, see net_fc.hpp)
-__device__ __forceinline__ void rn_conv(floatx4 (&acc)[kRnMT], const ResNetDev& n, const float* U, const float* Wc, int K, int cin_log2,
-                                        const RnLane& L, int wave, int lane) {
-    const int kq = lane >> 4, col = 16 * wave + (lane & 15);
+template <int MT>
+__device__ __forceinline__ void rn_conv(floatx4 (&acc)[MT], const ResNetDev& n, const float* U, const float* Wc, int K, int cin_log2,
+                                        const RnLane<MT>& L, int wave, int lane) {
+    const int kq = lane >> 4, col = 16 * (wave & 3) + (lane & 15);
     const int nsteps = K >> 2;
     for (int ks = 0; ks < nsteps; ++ks) {
         const int k = 4 * ks + kq;
         const float b = Wc[static_cast<long>(k) * kRnC + col];
         const int tap = k >> cin_log2, ci = k & ((1 << cin_log2) - 1);
         const int off = (tap / 3 - 1) * n.W + (tap % 3 - 1);
-        float a[kRnMT];
+        float a[MT];
 #pragma unroll
-        for (int s = 0; s < kRnMT; ++s) {
+        for (int s = 0; s < MT; ++s) {
             const bool ok = tap < 9 && ((L.tapmask[s] >> tap) & 1u);
             const int row = ok ? L.m[s] + off : L.m[s];
             const float v = U[row * kRnLD + ci];
@@ -112,19 +117,20 @@ __device__ __forceinline__ void rn_conv(floatx4 (&acc)[kRnMT], const ResNetDev& 
 // 3x3 convolution over 64 input channels: the tap of a k-step is wave-uniform (k = 4*ks + kq, 64 channels per tap -> tap = ks / 16),
 // so the neighbour rows of a lane change ONCE per tap -- three 16-byte reads of the table, requested a tap ahead; off-board taps point at
 // the all-zero row -- and the 16 k-steps of the tap are nothing but 11 ds_read_b32 with immediate offsets + 11 MFMAs each.
-__device__ __forceinline__ void rn_conv64(floatx4 (&acc)[kRnMT], const uint8_t* lds, const float* Wc, int wave, int lane) {
+template <int MT>
+__device__ __forceinline__ void rn_conv64(floatx4 (&acc)[MT], const uint8_t* lds, const float* Wc, int wave, int lane) {
     const int kq = lane >> 4;
     floatx4 b0[2], b1[2];
     // weights through a buffer resource: the lane's part of the address never changes and the k-step group goes into the scalar offset -- a
     // global_load needs three 64-bit VALU instructions per refill, and every VALU instruction between the MFMAs of this loop costs the
     // matrix pipe ~18 clocks
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wc), 0, 9 * kRnC * kRnC * 4, 0x00020000);
-    const int wvoff = (kq * kRnC + 16 * wave + (lane & 15)) * 16;
+    const int wvoff = (kq * kRnC + 16 * (wave & 3) + (lane & 15)) * 16;
     auto load_b = [&](floatx4 (&b)[2], int ks0) {  // the 8 k-steps ks0 .. ks0 + 7 (ks0 a multiple of 8)
 #pragma unroll
         for (int g = 0; g < 2; ++g) b[g] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff, ((ks0 >> 2) + g) * kRnPackBytes, 0));
     };
-    const uint4* tab = reinterpret_cast<const uint4*>(lds + kRnTabOff) + lane * 3;
+    const uint4* tab = reinterpret_cast<const uint4*>(lds + kRnTabOff + (wave >> 2) * kRnTabBytes) + lane * 3;
     auto load_t = [&](uint4 (&t)[3], int tap) {
 #pragma unroll
         for (int g = 0; g < 3; ++g) t[g] = tab[tap * (64 * 3) + g];
@@ -133,9 +139,9 @@ __device__ __forceinline__ void rn_conv64(floatx4 (&acc)[kRnMT], const uint8_t* 
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int ci0 = 4 * (half * 8 + i);
-            float a[kRnMT];
+            float a[MT];
 #pragma unroll
-            for (int s = 0; s < kRnMT; ++s) {
+            for (int s = 0; s < MT; ++s) {
                 const uint32_t o = s & 3 ? (s & 3) == 1 ? t[s >> 2].y : (s & 3) == 2 ? t[s >> 2].z : t[s >> 2].w : t[s >> 2].x;
                 a[s] = ((const __attribute__((address_space(3))) float*)o)[ci0];  // `o` is the LDS address itself: no add per row and tap
             }
@@ -169,68 +175,50 @@ __device__ __forceinline__ void rn_conv64(floatx4 (&acc)[kRnMT], const uint8_t* 
     one_tap(8, t0, t1);
 }
 
-__device__ __forceinline__ void rn_zero(floatx4 (&acc)[kRnMT]) {
+template <int MT>
+__device__ __forceinline__ void rn_zero(floatx4 (&acc)[MT]) {
 #pragma unroll
-    for (int s = 0; s < kRnMT; ++s) acc[s] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s = 0; s < MT; ++s) acc[s] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
 }
 
-// accumulator element (s, reg) of lane (j = lane & 15, kq = lane >> 4) is row MT*(4*kq + reg) + s, channel `ch` = 16*wave + j
+// accumulator element (s, reg) of lane (j = lane & 15, kq = lane >> 4) is row rbase + MT*(4*kq + reg) + s, channel `ch` = 16*(wave & 3) + j
 #define EAZ_RN_FOREACH(BODY)                                              \
     _Pragma("unroll") for (int reg = 0; reg < 4; ++reg)                   \
-        _Pragma("unroll") for (int s = 0; s < kRnMT; ++s) {               \
-            const int row = kRnMT * (4 * (lane >> 4) + reg) + s;          \
+        _Pragma("unroll") for (int s = 0; s < MT; ++s) {                  \
+            const int row = rbase + MT * (4 * (lane >> 4) + reg) + s;     \
             BODY                                                          \
         }
 
-__global__ void __launch_bounds__(256, 2) resnet_forward_kernel(ResNetDev n, const uint8_t* __restrict__ obs, int B, NetOut out) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+// input conv + residual tower of one wave: the rows of its half (MT tiles from row `rbase`) for its 16 channels; leaves U = relu(bn_final(X))
+template <int MT>
+__device__ __forceinline__ void rn_tower(const ResNetDev& n, uint8_t* lds, const uint32_t* row_mask, const int rbase, const int tid, const int wave, const int lane) {
     float* U = reinterpret_cast<float*>(lds);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int ch = 16 * wave + (lane & 15);  // the channel of this lane's accumulator elements
-    const int s0 = blockIdx.x * kRnSamples;
-    const int nsamp = B - s0 < kRnSamples ? B - s0 : kRnSamples;
-    const int rows_valid = nsamp * n.P;
     const float* p = n.p;
-    // the rows' tap masks, one row per thread, through the (still unused) heads' region
-    uint32_t* row_mask = reinterpret_cast<uint32_t*>(lds + kRnHdOff);
-    if (tid < kRnRows) row_mask[tid] = rn_row_mask(n, tid, rows_valid);
-    __syncthreads();
-    const RnLane L = rn_lane(row_mask, lane);
-    const int D = n.P * n.Cin;
-    EAZ_STAMP(0);
-    if (tid < kRnLD) U[kRnZeroRow * kRnLD + tid] = 0.0f;
+    const int ch = 16 * (wave & 3) + (lane & 15);  // the channel of this lane's accumulator elements
+    const RnLane<MT> L = rn_lane<MT>(row_mask, rbase, lane);
     {
-        // the neighbour-row table of rn_conv64 (the same for the four waves: wave w fills taps w, w + 4, w + 8)
-        uint32_t* T = reinterpret_cast<uint32_t*>(lds + kRnTabOff);
-        for (int t = wave; t < 9; t += 4) {
+        // the neighbour-row table of rn_conv64 (the same for the four waves of a half: wave w fills taps w & 3, + 4, + 8)
+        uint32_t* T = reinterpret_cast<uint32_t*>(lds + kRnTabOff + (wave >> 2) * kRnTabBytes);
+        for (int t = wave & 3; t < 9; t += 4) {
             const int off = (t / 3 - 1) * n.W + (t % 3 - 1);
 #pragma unroll
-            for (int s = 0; s < kRnMT; ++s) {
+            for (int s = 0; s < MT; ++s) {
                 const bool ok = (L.tapmask[s] >> t) & 1u;
                 // the low half of an LDS location's flat address is its LDS address
                 T[(t * 64 + lane) * 12 + s] = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(U + (ok ? L.m[s] + off : kRnZeroRow) * kRnLD + (lane >> 4)));
             }
-            T[(t * 64 + lane) * 12 + 11] = 0u;
+#pragma unroll
+            for (int s = MT; s < 12; ++s) T[(t * 64 + lane) * 12 + s] = 0u;
         }
     }
-
-    // ---- input: observation bytes -> U[row][ci] as f32 (resnet.py:69) ----
-    for (int i = tid; i < kRnRows * n.Cin; i += 256) {
-        const int row = i / n.Cin, ci = i - row * n.Cin;
-        float v = 0.0f;
-        if (row < rows_valid) v = static_cast<float>(obs[static_cast<long>(s0) * D + static_cast<long>(row) * n.Cin + ci]);
-        U[row * kRnLD + ci] = v;
-    }
-    __syncthreads();
-
-    floatx4 acc[kRnMT], xr[kRnMT];  // xr: the residual stream X, in the accumulator layout for the whole tower
+    floatx4 acc[MT], xr[MT];  // xr: the residual stream X, in the accumulator layout for the whole tower
     // ---- input conv (resnet.py:70): X = conv0(U) + b ----
-    rn_zero(acc);
-    rn_conv(acc, n, U, p + n.conv_w[0], n.conv_k[0], n.cin_log2, L, wave, lane);
+    rn_zero<MT>(acc);
+    rn_conv<MT>(acc, n, U, p + n.conv_w[0], n.conv_k[0], n.cin_log2, L, wave, lane);
     {
         const float b = p[n.conv_b[0] + ch];
 #pragma unroll
-        for (int s = 0; s < kRnMT; ++s)
+        for (int s = 0; s < MT; ++s)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) xr[s][reg] = acc[s][reg] + b;
     }
@@ -251,8 +239,8 @@ __global__ void __launch_bounds__(256, 2) resnet_forward_kernel(ResNetDev n, con
         __syncthreads();
         if (blk == n.nb) break;
         // conv1, then U = relu(bn2(conv1 + b)) written in place once every wave has finished reading U
-        rn_zero(acc);
-        rn_conv64(acc, lds, p + n.conv_w[1 + 2 * blk], wave, lane);
+        rn_zero<MT>(acc);
+        rn_conv64<MT>(acc, lds, p + n.conv_w[1 + 2 * blk], wave, lane);
         __syncthreads();
         {
             const float b = p[n.conv_b[1 + 2 * blk] + ch];
@@ -264,17 +252,44 @@ __global__ void __launch_bounds__(256, 2) resnet_forward_kernel(ResNetDev n, con
         }
         __syncthreads();
         // conv2 + skip: X = (conv2 + b) + X, in registers
-        rn_zero(acc);
-        rn_conv64(acc, lds, p + n.conv_w[2 + 2 * blk], wave, lane);
+        rn_zero<MT>(acc);
+        rn_conv64<MT>(acc, lds, p + n.conv_w[2 + 2 * blk], wave, lane);
         {
             const float b = p[n.conv_b[2 + 2 * blk] + ch];
 #pragma unroll
-            for (int s = 0; s < kRnMT; ++s)
+            for (int s = 0; s < MT; ++s)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) xr[s][reg] = (acc[s][reg] + b) + xr[s][reg];
         }
         __syncthreads();  // every wave has finished reading U before the next block's bn1 overwrites it
     }
+}
+
+__global__ void __launch_bounds__(kRnThreads, 1) resnet_forward_kernel(ResNetDev n, const uint8_t* __restrict__ obs, int B, NetOut out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    float* U = reinterpret_cast<float*>(lds);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int s0 = blockIdx.x * kRnSamples;
+    const int nsamp = B - s0 < kRnSamples ? B - s0 : kRnSamples;
+    const int rows_valid = nsamp * n.P;
+    const float* p = n.p;
+    // the rows' tap masks, one row per thread, through the (still unused) heads' region
+    uint32_t* row_mask = reinterpret_cast<uint32_t*>(lds + kRnHdOff);
+    if (tid < kRnRows) row_mask[tid] = rn_row_mask(n, tid, rows_valid);
+    const int D = n.P * n.Cin;
+    EAZ_STAMP(0);
+    if (tid < kRnLD) U[kRnZeroRow * kRnLD + tid] = 0.0f;
+    // ---- input: observation bytes -> U[row][ci] as f32 (resnet.py:69) ----
+    for (int i = tid; i < kRnRows * n.Cin; i += kRnThreads) {
+        const int row = i / n.Cin, ci = i - row * n.Cin;
+        float v = 0.0f;
+        if (row < rows_valid) v = static_cast<float>(obs[static_cast<long>(s0) * D + static_cast<long>(row) * n.Cin + ci]);
+        U[row * kRnLD + ci] = v;
+    }
+    __syncthreads();
+    // the two row halves run the same sequence of barriers (the second has one tile less per k-step)
+    if (wave < 4) rn_tower<kRnMT0>(n, lds, row_mask, 0, tid, wave, lane);
+    else rn_tower<kRnMT1>(n, lds, row_mask, kRnHalfRow, tid, wave, lane);
 
     EAZ_STAMP(2);
     // ---- heads: 1x1 conv -> bn -> relu per cell, results into their own LDS region ----
@@ -296,7 +311,7 @@ __global__ void __launch_bounds__(256, 2) resnet_forward_kernel(ResNetDev n, con
             wb[ks] = hcol ? v : 0.0f;
         }
         const float hb = p[n.hc_b[h_] + hco], hmean = p[n.hbn_mean[h_] + hco], hinv = p[n.hbn_inv[h_] + hco], hoff = p[n.hbn_off[h_] + hco];
-        for (int T = wave; T < kRnMT; T += 4) {
+        for (int T = wave; T < kRnMT0 + kRnMT1; T += 8) {
             const float* u = U + (16 * T + hj) * kRnLD + hkq;
             floatx4 d = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -305,7 +320,10 @@ __global__ void __launch_bounds__(256, 2) resnet_forward_kernel(ResNetDev n, con
             for (int reg = 0; reg < 4; ++reg) {
                 const int row = 16 * T + 4 * hkq + reg;
                 if (hcol && row < rows_valid) {
-                    const int smp = (row >= n.P) + (row >= 2 * n.P) + (row >= 3 * n.P), cell = row - smp * n.P;  // kRnSamples = 4
+                    int smp = 0;
+#pragma unroll
+                    for (int q = 1; q < kRnSamples; ++q) smp += row >= q * n.P;
+                    const int cell = row - smp * n.P;
                     float v = ((d[reg] + hb) - hmean) * hinv + hoff;
                     v = v > 0.0f ? v : 0.0f;
                     const int base = smp * kHdStride + (hh < 2 ? hh * 84 : 168 + (hh - 2) * 42);
@@ -336,13 +354,13 @@ __global__ void __launch_bounds__(256, 2) resnet_forward_kernel(ResNetDev n, con
 #pragma unroll
         for (int i = 0; i < 21; ++i) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], d, 0, 0, 0);  // all-zero k-steps past K leave d as it is
         float* dst = h == 0 ? out.exploit : out.explore;  // resnet.py:84-98
-        if (dst && hkq == 0 && hj < n.A) {
+        if (dst && hkq < kRnSamples / 4 && hj < n.A) {
             const float bb = b[hj];
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
-                if (reg < nsamp) dst[static_cast<long>(s0 + reg) * n.A + hj] = d[reg] + bb;
+                if (4 * hkq + reg < nsamp) dst[static_cast<long>(s0 + 4 * hkq + reg) * n.A + hj] = d[reg] + bb;
         }
-    } else if (wave >= 2) {
+    } else if (wave == 2 || wave == 3) {
         const int h = wave - 2, K = n.P;  // h: 0 value, 1 ube
         const float *w = p + n.lin_w[2 + 2 * h], *b = p + n.lin_b[2 + 2 * h];
         const float* x = Hd + (hj < nsamp ? hj : 0) * kHdStride + 168 + h * 42;
@@ -366,7 +384,7 @@ __global__ void __launch_bounds__(256, 2) resnet_forward_kernel(ResNetDev n, con
         for (int ks = 0; ks < 11; ++ks)
 #pragma unroll
             for (int t = 0; t < 4; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks][t], d[t], 0, 0, 0);
-        if (hkq == 0) {
+        if (hkq < kRnSamples / 4) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int c = 16 * t + hj;
@@ -374,14 +392,14 @@ __global__ void __launch_bounds__(256, 2) resnet_forward_kernel(ResNetDev n, con
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const float z = d[t][reg] + bb;
-                    if (reg < nsamp) Fc[(reg * 2 + h) * kRnC + c] = z > 0.0f ? z : 0.0f;  // resnet.py:105-106 / :117-118
+                    if (4 * hkq + reg < nsamp) Fc[((4 * hkq + reg) * 2 + h) * kRnC + c] = z > 0.0f ? z : 0.0f;  // resnet.py:105-106 / :117-118
                 }
             }
         }
     }
     if (n.A > 16) {
         // more actions than one MFMA tile has columns: the policy / exploration layers as plain chains
-        for (int i = tid; i < nsamp * 2 * n.A; i += 256) {
+        for (int i = tid; i < nsamp * 2 * n.A; i += kRnThreads) {
             const int smp = i / (2 * n.A), j = i - smp * (2 * n.A);
             const int h = j / n.A, a_ = j - h * n.A;
             const float *w = p + n.lin_w[h], *b = p + n.lin_b[h];

@@ -26,4 +26,4 @@ tot = st[:, 5] - st[:, 0]
 print(f"{len(st)} workgroups, median total {np.median(tot):.0f} cycles")
 for i, n in enumerate(["input stage + conv0", "tower (5 blocks, 10 convs)", "head 1x1 convs + bn", "head linear layers", "final fc + tanh"]):
     print(f"   {n:28s} median {np.median(d[:, i]):9.0f}  ({100 * np.median(d[:, i]) / np.median(tot):4.1f} %)")
-print(f"   ideal MFMA cycles of the tower (4 samples, 11x1 tiles per wave, alone on the CU): {10 * 144 * 11 * 32}; with two co-resident workgroups: {2 * 10 * 144 * 11 * 32}")
+print(f"   ideal MFMA cycles of the tower per SIMD (8 samples, two waves of 11 and 10 tiles share a SIMD): {10 * 144 * 21 * 32}")
