@@ -6,16 +6,18 @@
 //   hk.BatchNorm (eval): y = (x - mean) * inv + offset, inv = scale / sqrt(var + 1e-5) precomputed on the host
 //   hk.Linear / 1x1 conv: k-ascending fmaf chain, then + b
 //
-// Kernel shape (round 4): one 256-thread workgroup carries FOUR samples (4 x 42 = 168 board cells = rows of the implicit GEMM, padded to
-// 176 = 11 tiles of 16) through the WHOLE tower without touching HBM.  B = 8192 is then 2048 workgroups = exactly four rounds on the 512
-// slots of two workgroups per CU (three samples per workgroup: 2731 workgroups = 5.33 rounds, six paid -- 11 % of the launch).  Wave w owns
-// output channels 16 w .. 16 w + 15 for ALL rows: 11 x 1 tiles of v_mfma_f32_16x16x4_f32 per k-step on one B operand, so a wave streams a
+// Kernel shape (round 4): one 512-thread workgroup carries EIGHT samples (8 x 42 = 336 board cells = rows of the implicit GEMM = exactly
+// 21 tiles of 16: no padding rows) through the WHOLE tower without touching HBM; one workgroup per CU, B = 8192 is 1024 workgroups =
+// exactly four rounds on the 256 CUs.  Wave w owns output channels 16 (w & 3) .. + 15 for the rows of half w >> 2 (11 and 10 tiles): MT x 1
+// tiles of v_mfma_f32_16x16x4_f32 per k-step on one B operand -- the two waves of a SIMD share 21 tiles per k-step -- so a wave streams a
 // quarter of the weights (147 KB per 3x3 conv, shared by every workgroup, from L2 one group of 8 k-steps ahead: two 16-byte buffer loads,
 // the host packs four consecutive k-steps of a lane side by side).  The residual stream X never leaves the accumulator layout (44
-// registers per lane); only the activated conv input U lives in LDS ([176][65] f32 + one zero row, 46 KB) beside a 27 KB table of the
-// neighbour rows per tap (78 KB in all: two workgroups per CU).  The A operand is gathered from U through the table's per-tap row
-// addresses (11 ds_read_b32 per k-step, paired by the compiler), so no im2col buffer exists.
-// (Before: three samples, 2 x 4 tiles per wave, X and U in LDS, 1.996 ms at B = 8192; six samples / 4 x 4 tiles, one workgroup per CU: 2.87 ms.)
+// registers per lane); only the activated conv input U lives in LDS ([336][65] f32 + one zero row, 88 KB) beside two 27 KB tables of the
+// neighbour rows per tap (151 KB in all).  The A operand is gathered from U through the table's per-tap row addresses (MT ds_read_b32 per
+// k-step, paired by the compiler), so no im2col buffer exists.  The two halves run in step (same barriers), so the input stage, the
+// epilogues and the heads run at their own speed instead of beside a foreign MFMA stream.
+// (Before: four samples per 256-thread workgroup, two per CU, 176 rows with 8 of padding: 1.875 ms at B = 8192; three samples, 2 x 4 tiles
+// per wave, X and U in LDS: 1.996 ms; six samples / 4 x 4 tiles, one workgroup per CU: 2.87 ms.)
 #pragma once
 #include "net_fc.hpp"
 

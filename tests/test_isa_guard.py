@@ -52,7 +52,7 @@ BUDGET = {
     "subleq16_search_kernel": 256,     # 512 threads: two waves per SIMD
     "subleq16_selfplay_kernel": 256,   # 512 threads: two waves per SIMD
     "fc16p_forward_kernel": 168,       # three 256-thread workgroups per CU: three waves per SIMD
-    "resnet_forward_kernel": 256,      # two 256-thread workgroups per CU
+    "resnet_forward_kernel": 256,      # one 512-thread workgroup per CU: two waves per SIMD
 }
 
 
